@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- Bellman-sweep throughput of the HIP hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload car7d] [--fibers F]
+
+One "step" = one Bellman sweep over a batch of synthetic fibers: for every varying dimension
+k = 0..d-1, F fibers (x N_k nodes) go through the batched bellman_vi kernel
+(c3sc_hip_bellman_fibers), then the sweep ends the way a value-iteration sweep does: the updated FT
+cores are exchanged (RCCL all-gather over xGMI when N > 1) and re-staged on the device
+(valuef_precompute_cores equivalent, c3sc_hip_upload_value_device).  Inputs (cores, grids, fiber
+indices) are resident in HBM before the timed region.  Fibers are independent units: each rank owns
+its own F fibers per dimension (weak scaling), no collective in the data path.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and
+`cpu_baseline` objects.  The workload is BASELINE.json's headline config ("7D car rank-10":
+SURVEY.md 8d C4 = synthetic 7-D car, 41^7 grid, FT rank 10, 9 brute-force controls).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 vector = FP64 matrix; the microarch guide lists no f64 row
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(w, cores, budget_s=12.0):
+    """Oracle (CPU restatement of the reference algorithm, 1 thread) timed on this box's host
+    cores on a bounded sample of the same workload.  The oracle is only the checker/baseline
+    here -- never the thing measured as the product."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from c3sc_amd import workloads as wl
+
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libc3sc_oracle.so")):
+        oracle_lib.build()
+    P = oracle_lib.Problem(w, cores)
+    nodes, t0, chunk, k = 0, time.perf_counter(), 256, 0
+    while time.perf_counter() - t0 < budget_s:
+        idx = wl.synth_fibers(w, k % w.dx, chunk, seed=0xBA5E + k)
+        P.bellman_fibers(k % w.dx, idx, want_absorbed=False)
+        nodes += chunk * w.ngrid[k % w.dx]
+        k += 1
+    dt = time.perf_counter() - t0
+    return {"value": nodes / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
+            "sample": f"{nodes} node backups ({k} chunks of {chunk} random fibers, dims round-robin) in {dt:.1f} s, "
+                      f"oracle/c3sc_oracle.c -O2 single thread, {os.cpu_count()} host cores visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="car7d")
+    ap.add_argument("--fibers", type=int, default=1 << 17, help="fibers per varying dimension per GPU per step")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from c3sc_amd import workloads as wl
+    from c3sc_amd.engine import BellmanEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    w = wl.WORKLOADS[args.workload]()
+    cores = wl.synth_cores(w)
+    eng = BellmanEngine(local_rank)
+    eng.configure(w, cores)
+    if args.variant:
+        eng.set_variant(args.variant)
+
+    F = args.fibers
+    d = w.dx
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
+    # fiber batches resident in HBM; every rank owns different fibers (seed offset by rank)
+    idx_t = [torch.from_numpy(wl.synth_fibers(w, k, F, seed=0xF1BE + 7919 * rank)).to(dev) for k in range(d)]
+    out_t = [torch.empty((F, w.ngrid[k]), dtype=torch.float64, device=dev) for k in range(d)]
+    # FT cores on the device in the reference layout (what a cross-approximation step produces);
+    # each rank "owns" a 1/world slice of the flattened cores and all-gathers the rest per sweep
+    flat = np.concatenate([c.reshape(-1) for c in cores])
+    pad = (-len(flat)) % world
+    flat_t = torch.from_numpy(np.concatenate([flat, np.zeros(pad)])).to(dev)
+    shard = flat_t.view(world, -1)[rank].clone()
+    gathered = torch.empty_like(flat_t)
+    offs = np.cumsum([0] + [c.size for c in cores])
+
+    def core_views(buf):
+        return [buf[offs[m]:offs[m + 1]] for m in range(d)]
+
+    nodes_per_step = sum(F * w.ngrid[k] for k in range(d))
+    ev = []
+
+    def step(record):
+        for k in range(d):
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            eng.bellman_fibers(k, idx_t[k], out_t[k], stream_ptr=sp)
+            if record:
+                e1.record(stream)
+                ev.append((k, e0, e1))
+        # end of sweep: exchange the updated cores and re-stage them for the next sweep
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, shard)
+            eng.upload_value_device(w.ranks, core_views(gathered), sp)
+        else:
+            eng.upload_value_device(w.ranks, core_views(flat_t), sp)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    status = eng.status()
+
+    # dominant kernel: average launch duration from the HIP events recorded on the launch stream
+    kms = [e0.elapsed_time(e1) for (_, e0, e1) in ev]
+    avg_ms = float(np.mean(kms))
+    Wf = wl.algorithmic_flops_per_node(w)
+    nodes_per_launch = nodes_per_step / d
+    achieved_tflops = Wf * nodes_per_launch / (avg_ms * 1e-3) / 1e12
+    bytes_per_node = float(np.mean([wl.algorithmic_bytes_per_node(w, k) for k in range(d)]))
+    hbm_gbs = bytes_per_node * nodes_per_launch / (avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "Bellman-sweep nodes/sec (7D car rank-10)" if args.workload == "car7d" else f"Bellman-sweep nodes/sec ({w.name})",
+            "value": nodes_per_step * args.steps * world / elapsed,
+            "unit": "nodes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{w.name}: d={w.dx} N={w.ngrid[0]} FT rank {max(w.ranks)} U={w.ncand} controls, "
+                                   f"{F} random fibers per varying dim per GPU per step ({nodes_per_step} node backups/GPU/step), "
+                                   f"seeded synthetic cores (SURVEY.md 8d {'C4' if w.name == 'car7d' else ''})",
+                       "fibers_per_dim_per_gpu": F, "parallelism": f"fiber-sharded x{world}" if world > 1 else "single GPU",
+                       "exchange": "all-gather of FT cores per sweep (RCCL)" if world > 1 else "none"},
+            "vi_iters_to_tol": None,
+            "kernel_status_flags": status,
+            "roofline": {
+                "bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": None,
+                "kernel": eng.last_kernel(), "avg_launch_ms": avg_ms, "launches": len(kms),
+                "algorithmic_flops_per_node": Wf, "nodes_per_launch": nodes_per_launch,
+                "note": "FP64 compute bound (vector FMA path; dense f64 MFMA peak is the same 78.6 TFLOP/s datasheet figure)",
+                "hbm_secondary": {"algorithmic_bytes_per_node": bytes_per_node, "achieved_GBs": hbm_gbs,
+                                  "peak_GBs": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(w, cores, args.cpu_budget)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

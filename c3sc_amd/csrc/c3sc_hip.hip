@@ -1,0 +1,558 @@
+// c3sc_hip.hip -- host side of libc3sc_hip.so: the C-ABI declared in include/c3sc_hip.h.
+// Owns the device-resident problem description (one read-only arena: grids, obstacles, control
+// candidates, rank-padded FT cores), selects a kernel instantiation and launches it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/c3sc_hip.h"
+#include "kernel_common.hpp"
+#include "registry.hpp"
+
+namespace c3sc {
+
+std::vector<KernelEntry> &kernel_registry()
+{
+    static std::vector<KernelEntry> reg;
+    return reg;
+}
+
+// Re-pack one FT core from the reference layout cores[m][j*r0*r1 + a + b*r0] (valuefunc.c:165-189)
+// into the rank-padded device layout: first core [N][RP] (index b), last core [N][RP] (index a),
+// middle cores [N][RP*RP] (a + b*RP); padding entries are zero, which leaves every contraction exact.
+__global__ void k_pad_core(const double *__restrict__ src, double *__restrict__ dst, int N, int r0, int r1, int RP,
+                           int kind /*0 first, 1 middle, 2 last*/)
+{
+    const int per = (kind == 1) ? RP * RP : RP;
+    const long total = (long)N * per;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / per), w = (int)(e - (long)j * per);
+        int a, b;
+        if (kind == 0) { a = 0; b = w; }
+        else if (kind == 2) { a = w; b = 0; }
+        else { a = w % RP; b = w / RP; }
+        double v = 0.0;
+        if (a < r0 && b < r1) v = src[(size_t)j * r0 * r1 + a + (size_t)b * r0];
+        dst[e] = v;
+    }
+}
+
+// FP64 peak probes (DESIGN.md "Roofline peaks"): dependent-free FMA streams per lane
+__global__ void k_peak_fma(double *out, int iters)
+{
+    double a0 = threadIdx.x * 1e-9, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const double m = 1.0000001, c = 1e-9;
+    for (int i = 0; i < iters; i++) {
+        a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c);
+        a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c);
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ void k_peak_mfma(double *out, int iters)
+{
+    v4d c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
+    for (int i = 0; i < iters; i++) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+
+} // namespace c3sc
+
+using namespace c3sc;
+
+struct c3sc_hip_ctx {
+    int device = 0;
+    std::string err;
+    // host copy of the static problem description
+    int d = 0;
+    int ngrid[MAXD] = {0};
+    std::vector<double> xgrid_flat;
+    int xg_off_rel[MAXD] = {0};
+    int bctype[MAXD] = {0};
+    bool have_boundary = false;
+    int nobs = 0;
+    std::vector<double> obs; // [nobs][2][d]
+    bool have_mca = false;
+    double h2 = 0, discount = 0, t[2 * MAXD] = {0};
+    int model = 0;
+    double prm[C3SC_MAX_PARAMS] = {0};
+    int ncand = 0, du = 0;
+    std::vector<double> cands;
+    // value function
+    bool have_value = false;
+    size_t ranks[MAXD + 1] = {0};
+    int rp = 0;
+    // device arena: [xgrid | obs | cands | pad | cores]
+    double *arena = nullptr;
+    size_t arena_cap = 0;     // doubles
+    size_t static_doubles = 0; // size of the static section the arena was laid out with
+    bool static_dirty = true;
+    long core_off[MAXD] = {0};
+    int obs_off = 0, cands_off = 0;
+    unsigned *d_status = nullptr;
+    int variant = C3SC_VARIANT_AUTO;
+    const char *last_kernel = "";
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scratch for the *_host convenience calls
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                 \
+            return C3SC_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+static int fail(c3sc_hip_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static size_t static_layout(c3sc_hip_ctx *c)
+{ // offsets of the static section; returns its size in doubles (rounded to 16)
+    size_t off = c->xgrid_flat.size();
+    c->obs_off = (int)off;
+    off += c->obs.size();
+    c->cands_off = (int)off;
+    off += c->cands.size();
+    return (off + 15) & ~(size_t)15;
+}
+
+static int upload_static(c3sc_hip_ctx *c)
+{
+    std::vector<double> st(c->static_doubles, 0.0);
+    std::copy(c->xgrid_flat.begin(), c->xgrid_flat.end(), st.begin());
+    std::copy(c->obs.begin(), c->obs.end(), st.begin() + c->obs_off);
+    std::copy(c->cands.begin(), c->cands.end(), st.begin() + c->cands_off);
+    HIPCHK(c, hipMemcpy(c->arena, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->static_dirty = false;
+    return C3SC_OK;
+}
+
+static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, int variant)
+{
+    const KernelEntry *best = nullptr;
+    for (const auto &e : kernel_registry()) {
+        if (e.model != model || e.d != d || e.rp < rank_needed || e.max_n < N) continue;
+        if (variant != C3SC_VARIANT_AUTO && e.variant != variant) continue;
+        if (!best || e.rp < best->rp || (e.rp == best->rp && e.variant > best->variant) ||
+            (e.rp == best->rp && e.variant == best->variant && e.npl < best->npl))
+            best = &e;
+    }
+    return best;
+}
+
+static int pick_rp(int d, int maxrank)
+{ // smallest padded rank any instantiation of this dimension offers
+    int rp = 0;
+    for (const auto &e : kernel_registry())
+        if (e.d == d && e.rp >= maxrank && (rp == 0 || e.rp < rp)) rp = e.rp;
+    return rp;
+}
+
+extern "C" {
+
+int c3sc_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int c3sc_hip_ctx_create(int device, c3sc_hip_ctx **out)
+{
+    if (!out) return C3SC_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return C3SC_ERR_NODEVICE;
+    c3sc_hip_ctx *c = new c3sc_hip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&c->d_status, sizeof(unsigned)) != hipSuccess ||
+        hipMemset(c->d_status, 0, sizeof(unsigned)) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return C3SC_ERR_HIP;
+    }
+    *out = c;
+    return C3SC_OK;
+}
+
+void c3sc_hip_ctx_destroy(c3sc_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+const char *c3sc_hip_last_error(const c3sc_hip_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *c3sc_hip_last_kernel(const c3sc_hip_ctx *c) { return c ? c->last_kernel : ""; }
+
+int c3sc_hip_set_grid(c3sc_hip_ctx *c, int d, const size_t *ngrid, const double *const *xgrid)
+{
+    if (!c || !ngrid || !xgrid || d < 2 || d > MAXD) return fail(c, C3SC_ERR_ARG, "set_grid: need 2 <= d <= 12");
+    c->d = d;
+    c->xgrid_flat.clear();
+    for (int m = 0; m < d; m++) {
+        if (ngrid[m] < 2 || ngrid[m] > 4096) return fail(c, C3SC_ERR_ARG, "set_grid: need 2 <= N_m <= 4096");
+        c->ngrid[m] = (int)ngrid[m];
+        c->xg_off_rel[m] = (int)c->xgrid_flat.size();
+        c->xgrid_flat.insert(c->xgrid_flat.end(), xgrid[m], xgrid[m] + ngrid[m]);
+    }
+    c->static_dirty = true;
+    c->have_value = false; // grid change invalidates the uploaded value function
+    return C3SC_OK;
+}
+
+int c3sc_hip_set_boundary(c3sc_hip_ctx *c, const int *bctype, int nobs, const double *obs_lb, const double *obs_ub)
+{
+    if (!c || c->d == 0 || !bctype) return fail(c, C3SC_ERR_ARG, "set_boundary: set_grid first");
+    if (nobs < 0 || nobs > C3SC_MAX_OBSTACLES) return fail(c, C3SC_ERR_ARG, "set_boundary: at most 10 obstacles (boundary.c:393)");
+    for (int m = 0; m < c->d; m++) {
+        if (bctype[m] != C3SC_ABSORB && bctype[m] != C3SC_PERIODIC && bctype[m] != C3SC_REFLECT)
+            return fail(c, C3SC_ERR_ARG, "set_boundary: boundary type must be absorb/periodic/reflect (nodeutil.c:532-535)");
+        c->bctype[m] = bctype[m];
+    }
+    c->nobs = nobs;
+    c->obs.assign((size_t)nobs * 2 * c->d, 0.0);
+    for (int o = 0; o < nobs; o++)
+        for (int m = 0; m < c->d; m++) {
+            c->obs[((size_t)o * 2 + 0) * c->d + m] = obs_lb[(size_t)o * c->d + m];
+            c->obs[((size_t)o * 2 + 1) * c->d + m] = obs_ub[(size_t)o * c->d + m];
+        }
+    c->have_boundary = true;
+    c->static_dirty = true;
+    return C3SC_OK;
+}
+
+int c3sc_hip_set_mca(c3sc_hip_ctx *c, double h2, const double *t, double discount)
+{
+    if (!c || c->d == 0 || !t) return fail(c, C3SC_ERR_ARG, "set_mca: set_grid first");
+    c->h2 = h2;
+    c->discount = discount;
+    for (int i = 0; i < 2 * c->d; i++) c->t[i] = t[i];
+    c->have_mca = true;
+    return C3SC_OK;
+}
+
+int c3sc_hip_set_model(c3sc_hip_ctx *c, int model, const double *params, int nparams)
+{
+    if (!c || model <= 0 || nparams < 0 || nparams > C3SC_MAX_PARAMS) return fail(c, C3SC_ERR_ARG, "set_model: bad arguments");
+    c->model = model;
+    std::memset(c->prm, 0, sizeof(c->prm));
+    for (int i = 0; i < nparams; i++) c->prm[i] = params[i];
+    return C3SC_OK;
+}
+
+int c3sc_hip_set_controls(c3sc_hip_ctx *c, int ncand, int du, const double *cands)
+{
+    if (!c || ncand < 1 || du < 1 || !cands) return fail(c, C3SC_ERR_ARG, "set_controls: bad arguments");
+    c->ncand = ncand;
+    c->du = du;
+    c->cands.assign(cands, cands + (size_t)ncand * du);
+    c->static_dirty = true;
+    return C3SC_OK;
+}
+
+int c3sc_hip_set_variant(c3sc_hip_ctx *c, int variant)
+{
+    if (!c) return C3SC_ERR_ARG;
+    c->variant = variant;
+    return C3SC_OK;
+}
+
+static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_doubles)
+{
+    if (!c || c->d == 0 || !ranks) return fail(c, C3SC_ERR_ARG, "upload_value: set_grid first");
+    const int d = c->d;
+    if (ranks[0] != 1 || ranks[d] != 1) return fail(c, C3SC_ERR_ARG, "upload_value: ranks[0] and ranks[d] must be 1");
+    size_t maxrank = 1;
+    for (int m = 0; m <= d; m++) {
+        if (ranks[m] < 1) return fail(c, C3SC_ERR_ARG, "upload_value: rank < 1");
+        maxrank = std::max(maxrank, ranks[m]);
+    }
+    const int rp = pick_rp(d, (int)maxrank);
+    if (rp == 0) return fail(c, C3SC_ERR_UNSUPPORTED, "upload_value: no kernel instantiation for this (dim, rank)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t stat = static_layout(c);
+    size_t off = stat;
+    long core_off[MAXD];
+    for (int m = 0; m < d; m++) {
+        core_off[m] = (long)off;
+        const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
+        off += ((size_t)c->ngrid[m] * per + 15) & ~(size_t)15;
+    }
+    if (off > c->arena_cap) {
+        if (c->arena) HIPCHK(c, hipFree(c->arena));
+        c->arena = nullptr;
+        c->arena_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->arena, off * sizeof(double)));
+        c->arena_cap = off;
+        c->static_dirty = true;
+    }
+    if (stat != c->static_doubles) c->static_dirty = true;
+    c->static_doubles = stat;
+    for (int m = 0; m < d; m++) c->core_off[m] = core_off[m];
+    for (int m = 0; m <= d; m++) c->ranks[m] = ranks[m];
+    c->rp = rp;
+    *cores_doubles = off - stat;
+    if (c->static_dirty) return upload_static(c);
+    return C3SC_OK;
+}
+
+int c3sc_hip_upload_value(c3sc_hip_ctx *c, const size_t *ranks, const double *const *cores)
+{
+    size_t cd = 0;
+    int rc = prepare_value(c, ranks, &cd);
+    if (rc != C3SC_OK) return rc;
+    const int d = c->d, rp = c->rp;
+    std::vector<double> buf(cd, 0.0);
+    for (int m = 0; m < d; m++) {
+        const size_t r0 = ranks[m], r1 = ranks[m + 1];
+        double *dst = buf.data() + (c->core_off[m] - (long)c->static_doubles);
+        const double *src = cores[m];
+        const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
+        for (int j = 0; j < c->ngrid[m]; j++)
+            for (size_t b = 0; b < r1; b++)
+                for (size_t a = 0; a < r0; a++) {
+                    const double v = src[(size_t)j * r0 * r1 + a + b * r0];
+                    size_t w;
+                    if (m == 0) w = b;
+                    else if (m == d - 1) w = a;
+                    else w = a + b * rp;
+                    dst[(size_t)j * per + w] = v;
+                }
+    }
+    HIPCHK(c, hipMemcpy(c->arena + c->static_doubles, buf.data(), cd * sizeof(double), hipMemcpyHostToDevice));
+    c->have_value = true;
+    return C3SC_OK;
+}
+
+int c3sc_hip_upload_value_device(c3sc_hip_ctx *c, const size_t *ranks, const double *const *d_cores, void *stream)
+{
+    size_t cd = 0;
+    int rc = prepare_value(c, ranks, &cd);
+    if (rc != C3SC_OK) return rc;
+    const int d = c->d, rp = c->rp;
+    for (int m = 0; m < d; m++) {
+        const int kind = (m == 0) ? 0 : (m == d - 1 ? 2 : 1);
+        const long total = (long)c->ngrid[m] * (kind == 1 ? rp * rp : rp);
+        const int grid = (int)std::min<long>((total + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_pad_core, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_cores[m], c->arena + c->core_off[m],
+                           c->ngrid[m], (int)ranks[m], (int)ranks[m + 1], rp, kind);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->have_value = true;
+    return C3SC_OK;
+}
+
+static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model)
+{
+    if (!c) return C3SC_ERR_ARG;
+    if (c->d == 0 || !c->have_boundary || !c->have_value) return fail(c, C3SC_ERR_ARG, "launch: grid, boundary and value must be set");
+    if (need_model && (!c->have_mca || c->model == 0 || c->ncand == 0))
+        return fail(c, C3SC_ERR_ARG, "launch: mca, model and controls must be set");
+    if (k < 0 || k >= c->d) return fail(c, C3SC_ERR_ARG, "launch: dim_vary out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->static_dirty) {
+        if (static_layout(c) != c->static_doubles)
+            return fail(c, C3SC_ERR_ARG, "launch: static data changed size after upload_value; upload the value again");
+        int rc = upload_static(c);
+        if (rc != C3SC_OK) return rc;
+    }
+    std::memset(&A, 0, sizeof(A));
+    A.d = c->d;
+    A.k = k;
+    A.N = c->ngrid[k];
+    A.ncand = c->ncand;
+    A.F = (long)F;
+    for (int m = 0; m < c->d; m++) {
+        A.ngrid[m] = c->ngrid[m];
+        A.bctype[m] = c->bctype[m];
+        A.xg_off[m] = c->xg_off_rel[m];
+        A.core_off[m] = c->core_off[m];
+    }
+    A.nobs = c->nobs;
+    A.obs_off = c->obs_off;
+    A.cands_off = c->cands_off;
+    A.h2 = c->h2;
+    A.discount = c->discount;
+    for (int i = 0; i < 2 * c->d; i++) A.t[i] = c->t[i];
+    for (int i = 0; i < C3SC_MAX_PARAMS; i++) A.prm[i] = c->prm[i];
+    A.status = c->d_status;
+    return C3SC_OK;
+}
+
+int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, double *d_out, int32_t *d_uidx,
+                            int32_t *d_absorbed, void *stream)
+{
+    KArgs A;
+    int rc = fill_args(c, k, F, A, true);
+    if (rc != C3SC_OK) return rc;
+    if (F == 0) return C3SC_OK;
+    if (!d_idx || !d_out) return fail(c, C3SC_ERR_ARG, "bellman_fibers: null buffer");
+    const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant);
+    if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
+    c->last_kernel = e->name;
+    LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, (hipStream_t)stream};
+    HIPCHK(c, e->fn(A, io));
+    return C3SC_OK;
+}
+
+int c3sc_hip_stencil_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, double *d_costs, int32_t *d_absorbed,
+                            void *stream)
+{
+    KArgs A;
+    int rc = fill_args(c, k, F, A, false);
+    if (rc != C3SC_OK) return rc;
+    if (F == 0) return C3SC_OK;
+    if (!d_idx || !d_costs) return fail(c, C3SC_ERR_ARG, "stencil_fibers: null buffer");
+    const KernelEntry *e = find_kernel(0, c->d, c->rp, A.N, C3SC_VARIANT_AUTO);
+    if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "stencil_fibers: no kernel instantiation for (dim, rank, N)");
+    c->last_kernel = e->name;
+    LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, (hipStream_t)stream};
+    HIPCHK(c, e->fn(A, io));
+    return C3SC_OK;
+}
+
+static int ensure_scratch(c3sc_hip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return C3SC_OK;
+    if (c->scratch) HIPCHK(c, hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return C3SC_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, double *h_out, int32_t *h_uidx,
+                                 int32_t *h_absorbed)
+{
+    if (!c || c->d == 0 || k < 0 || k >= c->d) return fail(c, C3SC_ERR_ARG, "bellman_fibers_host: bad arguments");
+    if (F == 0) return C3SC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->ngrid[k];
+    const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * sizeof(double)),
+                 b_i = align256(F * N * sizeof(int32_t));
+    int rc = ensure_scratch(c, b_idx + b_out + 2 * b_i);
+    if (rc != C3SC_OK) return rc;
+    char *base = (char *)c->scratch;
+    int32_t *d_idx = (int32_t *)base;
+    double *d_out = (double *)(base + b_idx);
+    int32_t *d_ui = (int32_t *)(base + b_idx + b_out);
+    int32_t *d_ab = (int32_t *)(base + b_idx + b_out + b_i);
+    HIPCHK(c, hipMemcpy(d_idx, h_idx, F * c->d * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = c3sc_hip_bellman_fibers(c, k, F, d_idx, d_out, h_uidx ? d_ui : nullptr, h_absorbed ? d_ab : nullptr, nullptr);
+    if (rc != C3SC_OK) return rc;
+    HIPCHK(c, hipMemcpy(h_out, d_out, F * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_uidx) HIPCHK(c, hipMemcpy(h_uidx, d_ui, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return C3SC_OK;
+}
+
+int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, double *h_costs, int32_t *h_absorbed)
+{
+    if (!c || c->d == 0 || k < 0 || k >= c->d) return fail(c, C3SC_ERR_ARG, "stencil_fibers_host: bad arguments");
+    if (F == 0) return C3SC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->ngrid[k], S = 2 * c->d + 1;
+    const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * S * sizeof(double)),
+                 b_i = align256(F * N * sizeof(int32_t));
+    int rc = ensure_scratch(c, b_idx + b_out + b_i);
+    if (rc != C3SC_OK) return rc;
+    char *base = (char *)c->scratch;
+    int32_t *d_idx = (int32_t *)base;
+    double *d_out = (double *)(base + b_idx);
+    int32_t *d_ab = (int32_t *)(base + b_idx + b_out);
+    HIPCHK(c, hipMemcpy(d_idx, h_idx, F * c->d * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = c3sc_hip_stencil_fibers(c, k, F, d_idx, d_out, h_absorbed ? d_ab : nullptr, nullptr);
+    if (rc != C3SC_OK) return rc;
+    HIPCHK(c, hipMemcpy(h_costs, d_out, F * N * S * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return C3SC_OK;
+}
+
+int c3sc_hip_sync(c3sc_hip_ctx *c, void *stream)
+{
+    if (!c) return C3SC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    return C3SC_OK;
+}
+
+int c3sc_hip_get_status(c3sc_hip_ctx *c, unsigned *flags, int clear)
+{
+    if (!c || !flags) return C3SC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(flags, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (clear) HIPCHK(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
+    return C3SC_OK;
+}
+
+int c3sc_hip_timer_start(c3sc_hip_ctx *c, void *stream)
+{
+    if (!c) return C3SC_ERR_ARG;
+    HIPCHK(c, hipEventRecord(c->ev0, (hipStream_t)stream));
+    return C3SC_OK;
+}
+
+int c3sc_hip_timer_stop(c3sc_hip_ctx *c, void *stream, float *ms)
+{
+    if (!c || !ms) return C3SC_ERR_ARG;
+    HIPCHK(c, hipEventRecord(c->ev1, (hipStream_t)stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return C3SC_OK;
+}
+
+static int run_peak(c3sc_hip_ctx *c, bool mfma, double *tflops)
+{
+    if (!c || !tflops) return C3SC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int blocks = 256 * 8, threads = 256, iters = 20000;
+    int rc = ensure_scratch(c, (size_t)blocks * threads * sizeof(double));
+    if (rc != C3SC_OK) return rc;
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        HIPCHK(c, hipEventRecord(c->ev0, nullptr));
+        if (mfma) hipLaunchKernelGGL(k_peak_mfma, dim3(blocks), dim3(threads), 0, nullptr, (double *)c->scratch, iters);
+        else hipLaunchKernelGGL(k_peak_fma, dim3(blocks), dim3(threads), 0, nullptr, (double *)c->scratch, iters);
+        HIPCHK(c, hipEventRecord(c->ev1, nullptr));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double waves = (double)blocks * threads / 64.0;
+    const double flop = mfma ? waves * iters * 4.0 * (2.0 * 16 * 16 * 4) : (double)blocks * threads * iters * 8.0 * 2.0;
+    *tflops = flop / (best * 1e-3) / 1e12;
+    return C3SC_OK;
+}
+
+int c3sc_hip_peak_fma_f64(c3sc_hip_ctx *c, double *tflops) { return run_peak(c, false, tflops); }
+int c3sc_hip_peak_mfma_f64(c3sc_hip_ctx *c, double *tflops) { return run_peak(c, true, tflops); }
+
+} // extern "C"

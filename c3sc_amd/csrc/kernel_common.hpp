@@ -1,0 +1,167 @@
+// kernel_common.hpp -- shared device code of the Bellman-backup kernels (gfx950, wave64).
+// Citations are relative to the reference tree (goroda/c3sc).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/c3sc_hip.h"
+
+namespace c3sc {
+
+constexpr int MAXD = C3SC_MAX_DIM;
+
+// Kernel argument block (passed by value; lives in SGPR/kernarg space, all fields wave-uniform).
+struct KArgs {
+    int d, k, N, ncand;
+    long F;
+    int ngrid[MAXD];
+    int bctype[MAXD];
+    // offsets (in doubles) into the read-only arena `ro` passed as a __restrict__ kernel
+    // parameter, so that the compiler may keep wave-uniform reads on the scalar (SGPR) path
+    int xg_off[MAXD];    // xgrid[m][0..N_m)
+    long core_off[MAXD]; // rank-padded cores, see k_pad_core
+    int nobs;
+    int obs_off; // [nobs][2][d]: lb row then ub row per obstacle
+    int cands_off; // [ncand][DU]
+    double h2, discount;
+    double t[2 * MAXD];
+    double prm[C3SC_MAX_PARAMS];
+    unsigned *status;
+};
+
+// Output pointers of one launch (separate __restrict__ kernel parameters).
+struct KOut {
+    double *out;       // [F][N]            (bellman kernel)
+    double *costs;     // [F][N][2d+1]      (stencil kernel)
+    int32_t *uidx;     // [F][N] or null
+    int32_t *absorbed; // [F][N] or null
+};
+
+// Wave-level ordering of LDS traffic inside one wavefront (per-wave scratch, no s_barrier needed).
+__device__ inline void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Neighbour indices of a FIXED dimension with index i on a grid of n nodes and boundary type bc:
+// process_fibers_neighbor, nodeutil.c:513-566.  Returns true when the face is absorbing (the whole
+// fiber is then absorbed, :520-522 / :542-544).  Periodic: node 0 and node n-1 are the same point (Q8).
+__device__ inline bool fixed_neighbors(int i, int n, int bc, int &lo, int &hi)
+{
+    lo = i - 1;
+    hi = i + 1;
+    if (i == 0) {
+        if (bc == C3SC_ABSORB) { lo = i; hi = i; return true; }
+        if (bc == C3SC_REFLECT) { lo = i; hi = i + 1; }
+        else { lo = n - 2; hi = i + 1; }
+    } else if (i == n - 1) {
+        if (bc == C3SC_ABSORB) { lo = i; hi = i; return true; }
+        if (bc == C3SC_REFLECT) { lo = i - 1; hi = i; }
+        else { lo = i - 1; hi = 1; }
+    }
+    return false;
+}
+
+// Neighbour indices of node j along the VARYING dimension and the final absorbed flag:
+// nodeutil.c:570-624 (end points are overwritten by dim_vary's own boundary type -- quirk Q3).
+// `ab_in` is the flag after the obstacle test and the fixed-face test.
+__device__ inline int vary_neighbors(int j, int n, int bc, int ab_in, int &lo, int &hi)
+{
+    int ab = ab_in;
+    if (j == 0) {
+        if (bc == C3SC_ABSORB) { lo = 0; hi = 0; ab = 1; }
+        else if (bc == C3SC_REFLECT) { lo = 0; hi = 1; ab = 0; }
+        else { lo = n - 2; hi = 1; ab = 0; }
+    } else if (j == n - 1) {
+        if (bc == C3SC_ABSORB) { lo = n - 1; hi = n - 1; ab = 1; }
+        else if (bc == C3SC_REFLECT) { lo = n - 2; hi = n - 1; ab = 0; }
+        else { lo = n - 2; hi = 1; ab = 0; }
+    } else if (ab == 0) {
+        lo = j - 1;
+        hi = j + 1;
+    } else {
+        lo = j;
+        hi = j;
+    }
+    return ab;
+}
+
+// boundary_in_obstacle (boundary.c:668-680, bound_rect_inside :329-344): inclusive boxes.
+template <int D>
+__device__ inline bool in_obstacle(const KArgs &A, const double *__restrict__ ro, const double (&x)[D])
+{
+    bool any = false;
+    for (int o = 0; o < A.nobs; o++) {
+        const double *lb = ro + A.obs_off + (size_t)o * 2 * D;
+        const double *ub = lb + D;
+        bool inside = true;
+#pragma unroll
+        for (int m = 0; m < D; m++) inside = inside && !(x[m] < lb[m] || x[m] > ub[m]);
+        any = any || inside;
+    }
+    return any;
+}
+
+// One node of the Bellman operator: bellman_optimal (bellman.c:504-543, BRUTEFORCE branch) over
+// bellman_control (:367-480, no-gradient branch) = user dynamics + transition_assemble
+// (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)
+// neighbour in dim m, V[2D] = value at the node.  The candidate scan keeps the first minimum
+// (strict '<'), as the brute-force c3opt is assumed to.
+template <class Model>
+__device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
+                                     const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st)
+{
+    constexpr int D = Model::D, DU = Model::DU;
+    ui = -1;
+    if (ab == 1) return Model::boundcost(A.prm, x);  // bellman.c:513-523
+    if (ab == -1) return Model::obscost(A.prm, x);   // bellman.c:524-532
+    typename Model::Node nd;
+    Model::prep(A.prm, x, nd);
+    double best = 0.0;
+    for (int c = 0; c < A.ncand; c++) {
+        double u[DU];
+#pragma unroll
+        for (int i = 0; i < DU; i++) u[i] = ro[A.cands_off + c * DU + i];
+        double b[D], s[D], p[2 * D];
+        Model::drift(A.prm, nd, x, u, b);
+        Model::sigma(A.prm, x, u, s);
+        const double stage = Model::stage(A.prm, x, u);
+        double Q = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; m++) { // nodeutil.c:289-309
+            const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
+            double pm = half, pp = half;
+            if (b[m] < -1e-14) pm -= A.t[2 * m] * b[m];
+            else if (b[m] > 1e-14) pp += A.t[2 * m] * b[m];
+            p[2 * m] = pm;
+            p[2 * m + 1] = pp;
+            Q += pm;
+            Q += pp;
+        }
+        if (Q < 1e-14) { // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
+            st |= C3SC_STATUS_STATIONARY;
+            continue;
+        }
+        const double inv = 1.0 / Q;
+        const double dt = A.h2 * inv; // nodeutil.c:369
+        double pself = 1.0, ctg = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2 * D; i++) { // nodeutil.c:397-402 + the ddot of bellman.c:95
+            const double pi = p[i] * inv;
+            pself -= pi;
+            ctg = fma(pi, V[i], ctg);
+        }
+        ctg = fma(pself, V[2 * D], ctg);
+        const double ebt = (A.discount == 0.0) ? 1.0 : exp(-A.discount * dt); // bellman.c:94
+        const double val = dt * stage + ebt * ctg;                            // bellman.c:97
+        if (ui < 0 || val < best) {
+            best = val;
+            ui = c;
+        }
+    }
+    return best;
+}
+
+} // namespace c3sc

@@ -1,0 +1,55 @@
+// launch_fpw.hpp -- host launcher + registration macro for the fiber-per-wave kernels.
+#pragma once
+#include "kernel_fiber_per_wave.hpp"
+#include "registry.hpp"
+
+namespace c3sc {
+
+constexpr int NUM_CU = 256; // MI355X
+
+template <class Model, int RP, int NPL, bool STENCIL>
+hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
+{
+    constexpr int D = Model::D;
+    constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL;
+    const bool kedge = (A.k == 0) || (A.k == D - 1);
+    const size_t shmem = (size_t)(4 * WS + A.N * kcore_stride(RP, kedge)) * sizeof(double);
+    auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL>;
+    static int blocks_per_cu = 0;
+    static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
+    hipError_t e;
+    if (shmem > attr_shmem) { // dynamic LDS above 64 KiB must be opted into
+        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_shmem = shmem;
+    }
+    if (shmem != occ_shmem) {
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, shmem);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb > 0 ? nb : 1;
+        occ_shmem = shmem;
+    }
+    long want = (A.F + 3) / 4;
+    long cap = (long)NUM_CU * blocks_per_cu;
+    int grid = (int)(want < cap ? want : cap);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, io.stream, A, io.ro, io.idx, io.out, io.uidx, io.absorbed);
+    return hipGetLastError();
+}
+
+#define C3SC_CAT2(a, b) a##b
+#define C3SC_CAT(a, b) C3SC_CAT2(a, b)
+
+// MODEL may contain commas/angle brackets, hence the variadic tail
+#define C3SC_REG_FPW(MODEL_ID, RP, NPL, ...)                                                                 \
+    static Registrar C3SC_CAT(reg_fpw_, __COUNTER__)(KernelEntry{                                            \
+        MODEL_ID, __VA_ARGS__::D, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL,                            \
+        &launch_fpw<__VA_ARGS__, RP, NPL, false>, "k_fiber_per_wave<" #__VA_ARGS__ "," #RP "," #NPL ">"});
+
+#define C3SC_REG_STENCIL(DIM, RP, NPL)                                                                       \
+    static Registrar C3SC_CAT(reg_st_, __COUNTER__)(KernelEntry{                                             \
+        0, DIM, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL, &launch_fpw<NoModel<DIM>, RP, NPL, true>,    \
+        "k_fiber_per_wave<stencil," #DIM "," #RP "," #NPL ">"});
+
+} // namespace c3sc

@@ -1,0 +1,163 @@
+// models.hpp -- device problem models for the Bellman-backup kernels (gfx950).
+//
+// The reference describes a problem with five host callbacks (drift, diffusion, stage cost,
+// boundary cost, obstacle cost: src/dynamics.c:127-139,224-239, src/bellman.c:215-217).  A
+// kernel cannot call host function pointers, so each benchmark problem is restated as a
+// compile-time functor that is inlined into the node loop.  Only the DIAGONAL of the diffusion
+// matrix is produced because that is all transition_assemble reads (src/nodeutil.c:294).
+//
+// Every model has
+//   D, DU                       state / control dimension
+//   Node                        per-node invariants (trig etc.) computed once per node, not per control
+//   prep(prm, x, node)
+//   drift(prm, node, x, u, b)   b[D]
+//   sigma(prm, x, u, s)         s[D] diagonal of the diffusion
+//   stage(prm, x, u)            stage cost
+//   boundcost(prm, x), obscost(prm, x)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace c3sc {
+
+// examples/dubinscar_new/dubinscar.c:40-121
+struct Dubins3D {
+    static constexpr int D = 3, DU = 1;
+    struct Node { double c, s; };
+    __device__ static inline void prep(const double *, const double (&x)[D], Node &n) { n.c = cos(x[2]); n.s = sin(x[2]); }
+    __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, double (&b)[D])
+    {
+        b[0] = n.c; b[1] = n.s; b[2] = u[0];
+    }
+    __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&s)[D])
+    {
+        s[0] = 1e0; s[1] = 1e0; s[2] = 1e-2;
+    }
+    __device__ static inline double stage(const double *, const double (&)[D], const double *) { return 1.0; }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 10.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
+// examples/skidding_car/scar.c:40-169 (order = {0,1,2,3})
+struct Scar4D {
+    static constexpr int D = 4, DU = 2;
+    struct Node { double vc, vs, pre; };
+    __device__ static inline void prep(const double *, const double (&x)[D], Node &n)
+    {
+        const double orient = x[2], speed = x[3];
+        const double L = 0.2, vcar = 8.0;
+        n.pre = (1.0 / (1.0 + (speed / vcar))) * (speed / L);
+        n.vc = speed * cos(orient);
+        n.vs = speed * sin(orient);
+    }
+    __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, double (&b)[D])
+    {
+        b[0] = n.vc; b[1] = n.vs; b[2] = n.pre * tan(u[0]); b[3] = 2.0 * u[1];
+    }
+    __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&s)[D])
+    {
+        s[0] = 1.0; s[1] = 1.0; s[2] = 1e-2; s[3] = 1e-2;
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *)
+    {
+        return 1.0 + x[0] * x[0] + x[1] * x[1];
+    }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 10.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
+// synthetic 7-D car: state (x, y, theta, v, omega, delta, a), controls (ddelta, da)
+struct Car7D {
+    static constexpr int D = 7, DU = 2;
+    struct Node { double b0, b1, b4; };
+    __device__ static inline void prep(const double *, const double (&x)[D], Node &n)
+    {
+        const double th = x[2], v = x[3], om = x[4], de = x[5];
+        n.b0 = v * cos(th);
+        n.b1 = v * sin(th);
+        n.b4 = (v / (0.2 * (1.0 + v / 8.0)) * tan(de) - om) / 0.5;
+    }
+    __device__ static inline void drift(const double *, const Node &n, const double (&x)[D], const double *u, double (&b)[D])
+    {
+        b[0] = n.b0; b[1] = n.b1; b[2] = x[4]; b[3] = 2.0 * x[6]; b[4] = n.b4; b[5] = u[0]; b[6] = u[1];
+    }
+    __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&s)[D])
+    {
+        s[0] = 1.0; s[1] = 1.0;
+#pragma unroll
+        for (int i = 2; i < D; i++) s[i] = 1e-2;
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *)
+    {
+        return 1.0 + x[0] * x[0] + x[1] * x[1];
+    }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 10.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
+// examples/lqgnd/lqgnd.c:80-198 (dim = 2 is examples/lqg2d_new/lqg2d.c:72-153); prm = {dim, sig_even, sig_odd}
+template <int DIM>
+struct LqgNd {
+    static constexpr int D = DIM, DU = DIM / 2;
+    struct Node {};
+    __device__ static inline void prep(const double *, const double (&)[D], Node &) {}
+    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, double (&b)[D])
+    {
+#pragma unroll
+        for (int i = 0; i < D; i++) b[i] = ((i % 2) == 0) ? x[(i + 1 < D) ? i + 1 : i] : u[i / 2];
+    }
+    __device__ static inline void sigma(const double *prm, const double (&)[D], const double *, double (&s)[D])
+    {
+#pragma unroll
+        for (int i = 0; i < D; i++) s[i] = ((i % 2) == 0) ? prm[1] : prm[2];
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *u)
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) s += x[i] * x[i];
+#pragma unroll
+        for (int i = 0; i < DU; i++) s += u[i] * u[i];
+        return s;
+    }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 100.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
+// examples/double_int/double_int.c:80-157; prm = {dim, sig, sig_last, stage_mode}
+// stage_mode 0: stage = 1 (double_int.c:126); 1: stage = sum x_i^2 (synthetic quad10d)
+template <int DIM>
+struct Chain {
+    static constexpr int D = DIM, DU = 1;
+    struct Node {};
+    __device__ static inline void prep(const double *, const double (&)[D], Node &) {}
+    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, double (&b)[D])
+    {
+#pragma unroll
+        for (int i = 0; i < D - 1; i++) b[i] = x[i + 1];
+        b[D - 1] = u[0];
+    }
+    __device__ static inline void sigma(const double *prm, const double (&)[D], const double *, double (&s)[D])
+    {
+#pragma unroll
+        for (int i = 0; i < D - 1; i++) s[i] = prm[1];
+        s[D - 1] = prm[2];
+    }
+    __device__ static inline double stage(const double *prm, const double (&x)[D], const double *)
+    {
+        if (prm[3] == 0.0) return 1.0;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) s += x[i] * x[i];
+        return s;
+    }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 1000.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
+// FT stencil only (c3sc_hip_stencil_fibers): no dynamics
+template <int DIM>
+struct NoModel {
+    static constexpr int D = DIM, DU = 1;
+};
+
+} // namespace c3sc

@@ -1,0 +1,39 @@
+// registry.hpp -- table of compiled kernel instantiations (model, dim, padded rank, nodes per lane).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "kernel_common.hpp"
+
+namespace c3sc {
+
+struct LaunchIO {
+    const double *ro;
+    const int32_t *idx;
+    double *out; // bellman: [F][N]; stencil: [F][N][2d+1]
+    int32_t *uidx;
+    int32_t *absorbed;
+    hipStream_t stream;
+};
+
+typedef hipError_t (*launch_fn)(const KArgs &A, const LaunchIO &io);
+
+struct KernelEntry {
+    int model;   // C3SC_MODEL_* or 0 for the stencil-only kernels
+    int d;       // state dimension
+    int rp;      // padded rank
+    int npl;     // nodes per lane (fiber-per-wave) ; 0 = any
+    int variant; // C3SC_VARIANT_*
+    int max_n;   // largest N_k this instantiation handles
+    launch_fn fn;
+    const char *name;
+};
+
+std::vector<KernelEntry> &kernel_registry();
+
+struct Registrar {
+    explicit Registrar(const KernelEntry &e) { kernel_registry().push_back(e); }
+};
+
+} // namespace c3sc

@@ -20,7 +20,7 @@ from typing import List, Tuple
 
 import numpy as np
 
-# model ids -- must match include/c3sc_hip.h (C3SC_MODEL_*) and oracle/c3sc_oracle.h
+# model ids -- must match include/c3sc_hip.h (C3SC_MODEL_*)
 MODEL_DUBINS3D = 1
 MODEL_SCAR4D = 2
 MODEL_CAR7D = 3

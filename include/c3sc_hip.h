@@ -1,0 +1,134 @@
+/* c3sc_hip.h -- C-ABI of libc3sc_hip.so: the MI355X (gfx950) Bellman-backup engine.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int error codes.  No C++/torch types.
+ * This is the boundary a c3sc maintainer binds from the C host code (INTEGRATION.md shows the
+ * stub).  Every entry point names the reference interface it replaces; citations are
+ * relative to the reference tree (goroda/c3sc).
+ *
+ * Data model
+ *   grid      d per-dimension node arrays xgrid[m][0..N_m)     (c3control_create, bellman.c:1962-1999)
+ *   boundary  EBTYPE per dim + <=10 box obstacles              (boundary.c:374-397, 470-481)
+ *   mca       h2 = hmin^2, t[2m] = h2/h_m, t[2m+1] = h2/h_m^2  (mca_add_grid_refs, bellman.c:171-188)
+ *   value     nodal FT cores, cores[m][j*r_m*r_{m+1} + a + b*r_m] (valuef_precompute_cores, valuefunc.c:165-189)
+ *   controls  brute-force candidate list, U x du row-major      (c3opt_set_brute_force_vals, e.g. dubinscar.c:290-293)
+ *   model     device functor id + params replacing the host drift/diff/stagecost/boundcost/obscost
+ *             callbacks (dynamics.c:127-139,224-239; bellman.c:215-217), which a kernel cannot call.
+ *   fibers    F grid fibers along dim k: int32 idx[F*d] fixed indices (entry k ignored)  -- the
+ *             index form of the x[N x d] block C3's cross approximation hands to bellman_vi
+ *             (bellman.c:1295; convert_fiber_to_ind nodeutil.c:437-470 does that mapping on the host).
+ *
+ * Pointers named d_* are DEVICE pointers (hipMalloc / torch CUDA tensors); h_* / unprefixed
+ * configuration pointers are HOST pointers that are copied during the call.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef C3SC_HIP_H
+#define C3SC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C3SC_MAX_DIM 12
+#define C3SC_MAX_OBSTACLES 10 /* boundary.c:393 */
+#define C3SC_MAX_PARAMS 8
+
+/* error codes (0 = ok, like the reference's int returns) */
+enum {
+    C3SC_OK = 0,
+    C3SC_ERR_ARG = 1,         /* bad argument / state not set */
+    C3SC_ERR_HIP = 2,         /* a HIP runtime call failed (c3sc_hip_last_error has the text) */
+    C3SC_ERR_UNSUPPORTED = 3, /* no kernel instantiation for this (model, dim, rank, N) */
+    C3SC_ERR_NODEVICE = 4
+};
+
+/* enum EBTYPE (boundary.h:42-47) */
+enum { C3SC_EB_NONE = 0, C3SC_ABSORB = 1, C3SC_PERIODIC = 2, C3SC_REFLECT = 3 };
+
+/* device problem models (restating the examples' callbacks; see c3sc_amd/csrc/models.hpp) */
+enum {
+    C3SC_MODEL_DUBINS3D = 1, /* examples/dubinscar_new/dubinscar.c:40-121 */
+    C3SC_MODEL_SCAR4D = 2,   /* examples/skidding_car/scar.c:40-169 */
+    C3SC_MODEL_CAR7D = 3,    /* synthetic 7-D car */
+    C3SC_MODEL_LQGND = 4,    /* examples/lqgnd/lqgnd.c:80-198; params {dim, sig_even, sig_odd} */
+    C3SC_MODEL_CHAIN = 5     /* examples/double_int/double_int.c:80-157; params {dim, sig, sig_last, stage_mode} */
+};
+
+/* status bits accumulated by the kernels (c3sc_hip_get_status) */
+enum {
+    C3SC_STATUS_STATIONARY = 1u /* transition_assemble would have returned 1 (Q < 1e-14, nodeutil.c:365);
+                                   the reference asserts (bellman.c:452); the candidate is skipped here */
+};
+
+/* kernel variants (c3sc_hip_set_variant); 0 lets the library choose */
+enum { C3SC_VARIANT_AUTO = 0, C3SC_VARIANT_FIBER_PER_WAVE = 1, C3SC_VARIANT_FIBER_PER_LANE = 2 };
+
+typedef struct c3sc_hip_ctx c3sc_hip_ctx;
+
+/* lifetime: replaces c3control_create/destroy for the device side (bellman.c:1962-2019) */
+int c3sc_hip_ctx_create(int device, c3sc_hip_ctx **out);
+void c3sc_hip_ctx_destroy(c3sc_hip_ctx *ctx);
+const char *c3sc_hip_last_error(const c3sc_hip_ctx *ctx);
+int c3sc_hip_device_count(void);
+
+/* c3control_create's grid (bellman.c:1972-1986): ngrid[d], xgrid[m] host arrays of ngrid[m] doubles */
+int c3sc_hip_set_grid(c3sc_hip_ctx *ctx, int d, const size_t *ngrid, const double *const *xgrid);
+/* c3control_set_external_boundary / c3control_add_obstacle (bellman.c:2047-2062): bctype[d];
+ * obstacles as inclusive boxes lb/ub (nobs x d row-major), lb = center - width/2 (boundary.c:264-267) */
+int c3sc_hip_set_boundary(c3sc_hip_ctx *ctx, const int *bctype, int nobs, const double *obs_lb, const double *obs_ub);
+/* mca_add_grid_refs (bellman.c:171-188) + dp_param_create's discount (bellman.c:220-235) */
+int c3sc_hip_set_mca(c3sc_hip_ctx *ctx, double h2, const double *t, double discount);
+/* replaces c3control_add_drift/diff/stagecost/boundcost/obscost (bellman.c:2064-2103) */
+int c3sc_hip_set_model(c3sc_hip_ctx *ctx, int model, const double *params, int nparams);
+/* replaces c3opt_alloc(BRUTEFORCE)+c3opt_set_brute_force_vals: cands[ncand*du], scanned in order, strict '<' */
+int c3sc_hip_set_controls(c3sc_hip_ctx *ctx, int ncand, int du, const double *cands);
+/* replaces vi_param_add_value + valuef_precompute_cores (bellman.c:1173, valuefunc.c:165-189):
+ * ranks[d+1], cores[m] host arrays in the reference layout */
+int c3sc_hip_upload_value(c3sc_hip_ctx *ctx, const size_t *ranks, const double *const *cores);
+/* same, cores already resident on the device (e.g. after the RCCL all-gather of updated cores) */
+int c3sc_hip_upload_value_device(c3sc_hip_ctx *ctx, const size_t *ranks, const double *const *d_cores, void *stream);
+int c3sc_hip_set_variant(c3sc_hip_ctx *ctx, int variant);
+
+/* THE HOT PATH.  Batched bellman_vi (bellman.c:1295-1423) without the memo: for each of the F
+ * fibers along dim k and each of its N_k nodes: boundary stencil (process_fibers_neighbor,
+ * nodeutil.c:489-627), FT neighbour costs (valuef_eval_fiber_ind_nn, valuefunc.c:369-585),
+ * then bellman_optimal / bellman_control / transition_assemble / bellmanrhs per node
+ * (bellman.c:504-543, 367-480; nodeutil.c:267-406; bellman.c:88-112).
+ *   d_idx      int32 [F*d]        device
+ *   d_out      double [F*N_k]     device, out[f*N_k + j] like the callback's out[]
+ *   d_uidx     int32 [F*N_k] or NULL: winning candidate index, -1 for absorbed nodes
+ *   d_absorbed int32 [F*N_k] or NULL: absorbed[] of process_fibers_neighbor (0 / 1 / -1)
+ * Asynchronous on `stream`. */
+int c3sc_hip_bellman_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, double *d_out,
+                            int32_t *d_uidx, int32_t *d_absorbed, void *stream);
+
+/* Batched mca_get_neighbor_costs (nodeutil.c:647-713) only: d_costs double [F*N_k*(2d+1)],
+ * layout out[j*(2d+1) + 2m + {0,1}] = (-,+) neighbour in dim m, [.. + 2d] = self. */
+int c3sc_hip_stencil_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, double *d_costs,
+                            int32_t *d_absorbed, void *stream);
+
+/* Convenience for host callers (the C facade's bellman_vi): host buffers, synchronous. */
+int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, double *h_out,
+                                 int32_t *h_uidx, int32_t *h_absorbed);
+int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, double *h_costs,
+                                 int32_t *h_absorbed);
+
+int c3sc_hip_sync(c3sc_hip_ctx *ctx, void *stream);
+int c3sc_hip_get_status(c3sc_hip_ctx *ctx, unsigned *flags, int clear);
+/* name of the kernel the last launch used (for profiles) */
+const char *c3sc_hip_last_kernel(const c3sc_hip_ctx *ctx);
+
+/* device-side timing on `stream` with HIP events (used by bench.py's roofline leg) */
+int c3sc_hip_timer_start(c3sc_hip_ctx *ctx, void *stream);
+int c3sc_hip_timer_stop(c3sc_hip_ctx *ctx, void *stream, float *ms);
+
+/* FP64 micro-benchmarks used to confirm the peaks quoted in DESIGN.md (results in TFLOP/s) */
+int c3sc_hip_peak_fma_f64(c3sc_hip_ctx *ctx, double *tflops);
+int c3sc_hip_peak_mfma_f64(c3sc_hip_ctx *ctx, double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: libc3sc_hip.so loads without a GPU and exports every
+symbol include/c3sc_hip.h declares; the product path fails loudly (no CPU fallback) when no device
+is usable."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "c3sc_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(c3sc_hip_\w+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    from c3sc_amd import engine
+
+    lib = engine.load_library()
+    names = _declared()
+    assert len(names) >= 20
+    assert sorted(engine.EXPORTS) == names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/c3sc_hip.h but not exported"
+
+
+def test_signatures_are_plain_c():
+    """No C++/torch types at the boundary: the header must compile as C."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "t.c")
+        open(src, "w").write('#include "c3sc_hip.h"\nint main(void){return C3SC_OK;}\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src,
+                               "-o", os.path.join(td, "t.o")])
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from c3sc_amd.engine import BellmanEngine, C3scHipError
+
+    with pytest.raises(C3scHipError):
+        BellmanEngine(0)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under c3sc_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("c3sc_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".c", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle_lib|c3sc_oracle|libc3sc_oracle|import oracle|from oracle", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

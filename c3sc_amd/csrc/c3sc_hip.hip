@@ -414,13 +414,19 @@ int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_i
     const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
-    LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, (hipStream_t)stream};
+    LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, (hipStream_t)stream};
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
 }
 
 int c3sc_hip_stencil_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, double *d_costs, int32_t *d_absorbed,
                             void *stream)
+{
+    return c3sc_hip_stencil_fibers_nb(c, k, F, d_idx, nullptr, nullptr, d_costs, d_absorbed, stream);
+}
+
+int c3sc_hip_stencil_fibers_nb(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const int32_t *d_nb_fixed,
+                               const int32_t *d_nb_vary, double *d_costs, int32_t *d_absorbed, void *stream)
 {
     KArgs A;
     int rc = fill_args(c, k, F, A, false);
@@ -430,7 +436,7 @@ int c3sc_hip_stencil_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_i
     const KernelEntry *e = find_kernel(0, c->d, c->rp, A.N, C3SC_VARIANT_AUTO);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "stencil_fibers: no kernel instantiation for (dim, rank, N)");
     c->last_kernel = e->name;
-    LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, (hipStream_t)stream};
+    LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, d_nb_fixed, d_nb_vary, (hipStream_t)stream};
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
 }
@@ -475,20 +481,32 @@ int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t
 
 int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, double *h_costs, int32_t *h_absorbed)
 {
+    return c3sc_hip_stencil_fibers_nb_host(c, k, F, h_idx, nullptr, nullptr, h_costs, h_absorbed);
+}
+
+int c3sc_hip_stencil_fibers_nb_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const int32_t *h_nb_fixed,
+                                    const int32_t *h_nb_vary, double *h_costs, int32_t *h_absorbed)
+{
     if (!c || c->d == 0 || k < 0 || k >= c->d) return fail(c, C3SC_ERR_ARG, "stencil_fibers_host: bad arguments");
     if (F == 0) return C3SC_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = c->ngrid[k], S = 2 * c->d + 1;
     const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * S * sizeof(double)),
-                 b_i = align256(F * N * sizeof(int32_t));
-    int rc = ensure_scratch(c, b_idx + b_out + b_i);
+                 b_i = align256(F * N * sizeof(int32_t)), b_nf = align256(F * 2 * (c->d - 1) * sizeof(int32_t)),
+                 b_nv = align256(F * N * 2 * sizeof(int32_t));
+    int rc = ensure_scratch(c, b_idx + b_out + b_i + b_nf + b_nv);
     if (rc != C3SC_OK) return rc;
     char *base = (char *)c->scratch;
     int32_t *d_idx = (int32_t *)base;
     double *d_out = (double *)(base + b_idx);
     int32_t *d_ab = (int32_t *)(base + b_idx + b_out);
+    int32_t *d_nf = (int32_t *)(base + b_idx + b_out + b_i);
+    int32_t *d_nv = (int32_t *)(base + b_idx + b_out + b_i + b_nf);
     HIPCHK(c, hipMemcpy(d_idx, h_idx, F * c->d * sizeof(int32_t), hipMemcpyHostToDevice));
-    rc = c3sc_hip_stencil_fibers(c, k, F, d_idx, d_out, h_absorbed ? d_ab : nullptr, nullptr);
+    if (h_nb_fixed) HIPCHK(c, hipMemcpy(d_nf, h_nb_fixed, F * 2 * (c->d - 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (h_nb_vary) HIPCHK(c, hipMemcpy(d_nv, h_nb_vary, F * N * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = c3sc_hip_stencil_fibers_nb(c, k, F, d_idx, h_nb_fixed ? d_nf : nullptr, h_nb_vary ? d_nv : nullptr, d_out,
+                                    h_absorbed ? d_ab : nullptr, nullptr);
     if (rc != C3SC_OK) return rc;
     HIPCHK(c, hipMemcpy(h_costs, d_out, F * N * S * sizeof(double), hipMemcpyDeviceToHost));
     if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));

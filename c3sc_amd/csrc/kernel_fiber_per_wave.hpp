@@ -69,7 +69,8 @@ __host__ __device__ constexpr int kcore_stride(int rp, bool edge) { return (edge
 template <class Model, int RP, int NPL, bool STENCIL>
 __global__ void __launch_bounds__(256)
     k_fiber_per_wave(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
-                     int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
+                     int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed, const int32_t *__restrict__ nbf,
+                     const int32_t *__restrict__ nbv)
 {
     constexpr int D = Model::D;
     constexpr int S = 2 * D + 1;
@@ -111,6 +112,20 @@ __global__ void __launch_bounds__(256)
             if (m == k) fi[m] = 0;
             const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], nbm[m], nbp[m]);
             if (m != k) fiber_abs = fiber_abs || face;
+        }
+        if constexpr (STENCIL) {
+            // caller-supplied neighbour indices (the literal valuef_eval_fiber_ind_nn interface,
+            // valuefunc.c:369-371: neighbors[2(d-1)] skips dim k)
+            if (nbf) {
+#pragma unroll
+                for (int m = 0; m < D; m++) {
+                    if (m != k) {
+                        const int on = 2 * (m < k ? m : m - 1);
+                        nbm[m] = nbf[f * 2 * (D - 1) + on];
+                        nbp[m] = nbf[f * 2 * (D - 1) + on + 1];
+                    }
+                }
+            }
         }
 
         // ---------------- prefix side: L = G_0[i_0] ... G_{k-1}[i_{k-1}],  q_m = L_{m-1} G_m[nb]
@@ -260,6 +275,12 @@ __global__ void __launch_bounds__(256)
             if (fiber_abs) ab = 1;
             int lo, hi;
             ab = vary_neighbors(jj, N, A.bctype[k], ab, lo, hi);
+            if constexpr (STENCIL) {
+                if (nbv) {
+                    lo = nbv[(f * N + jj) * 2];
+                    hi = nbv[(f * N + jj) * 2 + 1];
+                }
+            }
             const double vlo = sV[lo], vhi = sV[hi];
 #pragma unroll
             for (int m = 0; m < D; m++)

@@ -14,6 +14,8 @@ struct LaunchIO {
     double *out; // bellman: [F][N]; stencil: [F][N][2d+1]
     int32_t *uidx;
     int32_t *absorbed;
+    const int32_t *nbf; // stencil only: explicit fixed-dim neighbours [F][2(d-1)] or null
+    const int32_t *nbv; // stencil only: explicit varying-dim neighbours [F][N][2] or null
     hipStream_t stream;
 };
 

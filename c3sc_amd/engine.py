@@ -27,7 +27,7 @@ EXPORTS = [
     "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_mca", "c3sc_hip_set_model",
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
     "c3sc_hip_bellman_fibers", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
-    "c3sc_hip_stencil_fibers_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
+    "c3sc_hip_stencil_fibers_host", "c3sc_hip_stencil_fibers_nb", "c3sc_hip_stencil_fibers_nb_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
     "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]
 
@@ -62,6 +62,8 @@ def load_library():
         L.c3sc_hip_bellman_fibers_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]
         L.c3sc_hip_stencil_fibers_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.c3sc_hip_stencil_fibers_nb_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p]
         L.c3sc_hip_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.c3sc_hip_timer_start.argtypes = [C.c_void_p, C.c_void_p]
         L.c3sc_hip_timer_stop.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
@@ -227,13 +229,17 @@ class BellmanEngine:
                                                       ab.ctypes.data if ab is not None else None), "bellman_fibers_host")
         return out, ui, ab
 
-    def stencil_fibers_host(self, k: int, idx: np.ndarray):
+    def stencil_fibers_host(self, k: int, idx: np.ndarray, nb_fixed=None, nb_vary=None):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         F, N = idx.shape[0], self.ngrid[k]
         costs = np.empty((F, N, 2 * self.d + 1))
         ab = np.empty((F, N), dtype=np.int32)
-        self._chk(self.L.c3sc_hip_stencil_fibers_host(self.h, k, F, idx.ctypes.data, costs.ctypes.data, ab.ctypes.data),
-                  "stencil_fibers_host")
+        nf = np.ascontiguousarray(nb_fixed, dtype=np.int32) if nb_fixed is not None else None
+        nv = np.ascontiguousarray(nb_vary, dtype=np.int32) if nb_vary is not None else None
+        self._chk(self.L.c3sc_hip_stencil_fibers_nb_host(self.h, k, F, idx.ctypes.data,
+                                                         nf.ctypes.data if nf is not None else None,
+                                                         nv.ctypes.data if nv is not None else None,
+                                                         costs.ctypes.data, ab.ctypes.data), "stencil_fibers_nb_host")
         return costs, ab
 
     # ------------------------------------------------------------------ misc

@@ -1,0 +1,676 @@
+/* c3sc_bellman.c -- host side of the Bellman backup behind the reference's C API: nodal ValueF,
+ * MCA helpers, parameter bundles, and bellman_vi, which keeps the cross-approximation callback ABI
+ * (src/valuefunc.c:615-616) and runs the fiber on the MI355X through include/c3sc_hip.h.
+ * Own implementation of the reference's interface; citations are relative to the reference tree. */
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "c3sc/c3sc.h"
+#include "c3sc_hip.h"
+
+#define DIE(...)                                                                                   \
+    do { fprintf(stderr, "c3sc: " __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } while (0)
+
+static void *xcalloc(size_t n, size_t s)
+{
+    void *p = calloc(n ? n : 1, s);
+    if (p == NULL) DIE("out of memory");
+    return p;
+}
+
+static void hipok(struct c3sc_hip_ctx *ctx, int rc, const char *what)
+{
+    if (rc != C3SC_OK) DIE("%s failed (code %d): %s", what, rc, c3sc_hip_last_error(ctx));
+}
+
+/* =============================================================================== ValueF */
+struct ValueF {
+    size_t d;
+    size_t *N, *ranks;
+    double **cores;
+    unsigned long version;       /* bumps on every construction: identifies an upload */
+    struct c3sc_hip_ctx *bound;  /* device context the cores were uploaded to */
+};
+static unsigned long g_vf_version = 0;
+static unsigned long g_uploaded_version = 0; /* version resident on the (single) device context */
+static struct c3sc_hip_ctx *g_uploaded_ctx = NULL;
+
+struct ValueF *valuef_create_nodal(size_t d, const size_t *N, const size_t *ranks, double **cores)
+{
+    struct ValueF *vf = xcalloc(1, sizeof(*vf));
+    vf->d = d;
+    vf->N = xcalloc(d, sizeof(size_t));
+    vf->ranks = xcalloc(d + 1, sizeof(size_t));
+    vf->cores = xcalloc(d, sizeof(double *));
+    memcpy(vf->N, N, d * sizeof(size_t));
+    memcpy(vf->ranks, ranks, (d + 1) * sizeof(size_t));
+    for (size_t m = 0; m < d; m++) {
+        const size_t n = N[m] * ranks[m] * ranks[m + 1];
+        vf->cores[m] = xcalloc(n, sizeof(double));
+        memcpy(vf->cores[m], cores[m], n * sizeof(double));
+    }
+    vf->version = ++g_vf_version;
+    return vf;
+}
+
+void valuef_destroy(struct ValueF *vf)
+{
+    if (vf == NULL) return;
+    for (size_t m = 0; m < vf->d; m++) free(vf->cores[m]);
+    free(vf->cores); free(vf->N); free(vf->ranks); free(vf);
+}
+
+struct ValueF *valuef_copy(struct ValueF *vf) { return valuef_create_nodal(vf->d, vf->N, vf->ranks, vf->cores); }
+size_t *valuef_get_ranks(struct ValueF *vf) { return vf->ranks; }
+size_t valuef_get_dim(const struct ValueF *vf) { return vf->d; }
+const size_t *valuef_get_N(const struct ValueF *vf) { return vf->N; }
+double **valuef_get_cores(struct ValueF *vf) { return vf->cores; }
+
+double valuef_eval_ind(struct ValueF *vf, const size_t *ind)
+{
+    size_t rmax = 1;
+    for (size_t m = 0; m <= vf->d; m++) if (vf->ranks[m] > rmax) rmax = vf->ranks[m];
+    double *v = xcalloc(2 * rmax, sizeof(double)), *w = v + rmax;
+    v[0] = 1.0;
+    for (size_t m = 0; m < vf->d; m++) {
+        const size_t r0 = vf->ranks[m], r1 = vf->ranks[m + 1];
+        const double *G = vf->cores[m] + ind[m] * r0 * r1;
+        for (size_t b = 0; b < r1; b++) {
+            double s = 0.0;
+            for (size_t a = 0; a < r0; a++) s += v[a] * G[a + b * r0];
+            w[b] = s;
+        }
+        memcpy(v, w, r1 * sizeof(double));
+    }
+    const double out = v[0];
+    free(v);
+    return out;
+}
+
+void valuef_bind_device(struct ValueF *vf, struct c3sc_hip_ctx *ctx)
+{
+    vf->bound = ctx;
+    if (g_uploaded_ctx == ctx && g_uploaded_version == vf->version) return;
+    hipok(ctx, c3sc_hip_upload_value(ctx, vf->ranks, (const double *const *)vf->cores), "c3sc_hip_upload_value");
+    g_uploaded_ctx = ctx;
+    g_uploaded_version = vf->version;
+}
+
+int valuef_eval_fiber_ind_nn(struct ValueF *vf, const size_t *fixed_ind, size_t dim_vary, const size_t *neighbors,
+                             const size_t *neighbors_vary, double *out)
+{
+    if (vf->bound == NULL) DIE("valuef_eval_fiber_ind_nn: value function is not bound to a device (valuef_bind_device)");
+    valuef_bind_device(vf, vf->bound);
+    const size_t d = vf->d, N = vf->N[dim_vary];
+    int32_t idx[C3SC_MAX_DIM], nbf[2 * C3SC_MAX_DIM];
+    int32_t *nbv = xcalloc(2 * N, sizeof(int32_t));
+    for (size_t m = 0; m < d; m++) idx[m] = (m == dim_vary) ? 0 : (int32_t)fixed_ind[m];
+    for (size_t i = 0; i < 2 * (d - 1); i++) nbf[i] = (int32_t)neighbors[i];
+    for (size_t i = 0; i < 2 * N; i++) nbv[i] = (int32_t)neighbors_vary[i];
+    hipok(vf->bound, c3sc_hip_stencil_fibers_nb_host(vf->bound, (int)dim_vary, 1, idx, nbf, nbv, out, NULL),
+          "c3sc_hip_stencil_fibers_nb_host");
+    free(nbv);
+    return 0;
+}
+
+/* =============================================================================== nodeutil */
+int transition_assemble(size_t dx, size_t du, size_t dw, double h2, const double *tv, const double *drift,
+                        const double *grad_drift, const double *ddiff, const double *grad_ddiff, double *prob,
+                        double *grad_prob, double *dt, double *grad_dt, double *space)
+{ /* nodeutil.c:267-406: upwind rates p_m^{-+} = t2_m s_mm^2/2 + t_m max(-+b_m, 0), dead zone 1e-14 */
+    const int want_grad = (grad_prob != NULL);
+    int res = 0;
+    if (space != NULL) for (size_t j = 0; j < du; j++) space[j] = 0.0;
+    double Q = 0.0;
+    for (size_t m = 0; m < dx; m++) {
+        const double t = tv[2 * m], t2 = tv[2 * m + 1];
+        const double s2 = ddiff[m * dx + m] * ddiff[m * dx + m];
+        const double base = t2 * s2 / 2.0;
+        const int sgn = drift[m] < -1e-14 ? -1 : (drift[m] > 1e-14 ? 1 : 0);
+        double *pm = &prob[2 * m], *pp = &prob[2 * m + 1];
+        *pm = base;
+        *pp = base;
+        if (sgn < 0) *pm -= t * drift[m];
+        if (sgn > 0) *pp += t * drift[m];
+        Q += *pm;
+        Q += *pp;
+        if (want_grad) {
+            double *gm = grad_prob + 2 * m * du, *gp = gm + du;
+            for (size_t j = 0; j < du; j++) gm[j] = gp[j] = t2 * grad_ddiff[m * dx + m + j * dx * dw];
+            if (sgn < 0) { for (size_t j = 0; j < du; j++) gm[j] += -t * grad_drift[m + j * dx]; }
+            else if (sgn > 0) { for (size_t j = 0; j < du; j++) gp[j] += t * grad_drift[m + j * dx]; }
+            else {
+                for (size_t j = 0; j < du; j++) {
+                    const double g = grad_drift[j * dx + m];
+                    if (g < 0) { for (size_t q = 0; q < du; q++) gm[q] -= t * grad_drift[m + q * dx]; }
+                    else if (g > 0) { for (size_t q = 0; q < du; q++) gp[q] += t * grad_drift[m + q * dx]; }
+                    else res = 2;
+                }
+            }
+            for (size_t j = 0; j < du; j++) space[j] += gm[j];
+            for (size_t j = 0; j < du; j++) space[j] += gp[j];
+        }
+    }
+    if (Q < 1e-14) return 1; /* stationary: dt, normalised probabilities are not produced (nodeutil.c:365-367) */
+    *dt = h2 / Q;
+    prob[2 * dx] = 1.0;
+    if (want_grad) {
+        const double Q2 = Q * Q, c = h2 / Q2;
+        for (size_t j = 0; j < du; j++) { grad_prob[2 * dx * du + j] = 0.0; grad_dt[j] = -space[j] * c; }
+        for (size_t i = 0; i < 2 * dx; i++) {
+            for (size_t j = 0; j < du; j++) grad_prob[i * du + j] = (Q * grad_prob[i * du + j] - space[j] * prob[i]) / Q2;
+            prob[i] /= Q;
+            prob[2 * dx] -= prob[i];
+            for (size_t j = 0; j < du; j++) grad_prob[2 * dx * du + j] -= grad_prob[i * du + j];
+        }
+    } else {
+        for (size_t i = 0; i < 2 * dx; i++) { prob[i] /= Q; prob[2 * dx] -= prob[i]; }
+    }
+    return res;
+}
+
+static size_t find_node(double x, size_t N, const double *grid)
+{ /* O(N) scan, absolute tolerance 1e-14 (nodeutil.c:408-419, quirk Q9) */
+    size_t i = 0;
+    while (i < N && !(fabs(x - grid[i]) < 1e-14)) i++;
+    return i;
+}
+
+int convert_fiber_to_ind(size_t d, size_t N, const double *x, const size_t *Ngrid, double **xgrid, size_t *fixed_ind,
+                         size_t *dim_vary)
+{ /* nodeutil.c:437-470: node 0 gives the indices, node 1 tells which coordinate moves */
+    for (size_t m = 0; m < d; m++) {
+        fixed_ind[m] = find_node(x[m], Ngrid[m], xgrid[m]);
+        if (fixed_ind[m] == Ngrid[m]) {
+            fprintf(stderr, "Error: evaluation is not on the grid\nx[%zu] = %3.15E\n", m, x[m]);
+            return 1;
+        }
+    }
+    *dim_vary = d;
+    for (size_t m = 0; m < d && *dim_vary == d; m++)
+        if (find_node(x[d + m], Ngrid[m], xgrid[m]) != fixed_ind[m]) *dim_vary = m;
+    if (*dim_vary == d) return 1;
+    return (N != Ngrid[*dim_vary]) ? 2 : 0;
+}
+
+int process_fibers_neighbor(size_t d, const size_t *fixed_ind, size_t dim_vary, const double *x, int *absorbed,
+                            size_t *nv, size_t *nf, const size_t *ngrid, const struct Boundary *bound)
+{ /* nodeutil.c:489-627 */
+    const size_t N = ngrid[dim_vary];
+    int whole = 0;
+    size_t *o = nf;
+    for (size_t m = 0; m < d; m++) {
+        if (m == dim_vary) continue;
+        const size_t i = fixed_ind[m], last = ngrid[m] - 1;
+        const enum EBTYPE b = boundary_type_dim(bound, m, i == 0 ? 0 : 1);
+        o[0] = i - 1;
+        o[1] = i + 1;
+        if (i == 0 || i == last) {
+            if (b == ABSORB) { o[0] = o[1] = i; whole = 1; }
+            else if (b == REFLECT) { if (i == 0) o[0] = i; else o[1] = i; }
+            else if (b == PERIODIC) { if (i == 0) o[0] = ngrid[m] - 2; else o[1] = 1; }
+            else { fprintf(stderr, "No boundary specified!\n"); assert(0); }
+        }
+        o += 2;
+    }
+    for (size_t j = 0; j < N; j++) absorbed[j] = whole ? 1 : (boundary_in_obstacle(bound, x + j * d) ? -1 : 0);
+    /* end points follow dim_vary's own boundary type and overwrite the flags above (quirk Q3) */
+    const enum EBTYPE b = boundary_type_dim(bound, dim_vary, 0);
+    if (b != ABSORB && b != REFLECT && b != PERIODIC) { fprintf(stderr, "Should not be here!\n"); assert(0); }
+    absorbed[0] = absorbed[N - 1] = (b == ABSORB);
+    for (size_t j = 0; j < N; j++) {
+        size_t lo = j, hi = j;
+        if (j == 0) { if (b == REFLECT) hi = 1; else if (b == PERIODIC) { lo = N - 2; hi = 1; } }
+        else if (j == N - 1) { if (b == REFLECT) lo = N - 2; else if (b == PERIODIC) { lo = N - 2; hi = 1; } }
+        else if (absorbed[j] == 0) { lo = j - 1; hi = j + 1; }
+        nv[2 * j] = lo;
+        nv[2 * j + 1] = hi;
+    }
+    return 0;
+}
+
+int mca_get_neighbor_costs(size_t d, size_t N, const double *x, struct Boundary *bound, struct ValueF *vf,
+                           const size_t *ngrid, double **xgrid, size_t *fixed_ind, size_t *dim_vary, int *absorbed,
+                           double *out)
+{ /* nodeutil.c:647-713 */
+    int res = convert_fiber_to_ind(d, N, x, ngrid, xgrid, fixed_ind, dim_vary);
+    if (res != 0) { printf("\n======================================\nError calling convert fiber to _ind!!\n"); }
+    assert(res == 0);
+    size_t *nv = xcalloc(2 * N, sizeof(size_t)), *nf = xcalloc(2 * d, sizeof(size_t));
+    res = process_fibers_neighbor(d, fixed_ind, *dim_vary, x, absorbed, nv, nf, ngrid, bound);
+    assert(res == 0);
+    res = valuef_eval_fiber_ind_nn(vf, fixed_ind, *dim_vary, nf, nv, out);
+    free(nv);
+    free(nf);
+    return res;
+}
+
+/* =============================================================================== bellman */
+double bellmanrhs(size_t dx, size_t du, double stage_cost, const double *stage_grad, double discount,
+                  const double *prob, const double *prob_grad, double dt, const double *dtgrad, const double *cost,
+                  double *grad)
+{ /* bellman.c:88-112 */
+    const double ebt = exp(-discount * dt);
+    double ctg = 0.0;
+    for (size_t i = 0; i < 2 * dx + 1; i++) ctg += prob[i] * cost[i];
+    if (grad != NULL) {
+        for (size_t j = 0; j < du; j++) {
+            double g = stage_grad[j] * dt + dtgrad[j] * stage_cost;
+            g += (-discount) * dtgrad[j] * ebt * ctg;
+            for (size_t i = 0; i < 2 * dx + 1; i++) g += ebt * prob_grad[i * du + j] * cost[i];
+            grad[j] = g;
+        }
+    }
+    return dt * stage_cost + ebt * ctg;
+}
+
+struct MCAparam { size_t dx, du; size_t *ngrid; double **xgrid; double hmin, *hvec, h2, *t; };
+
+struct MCAparam *mca_param_create(size_t dx, size_t du)
+{
+    struct MCAparam *m = xcalloc(1, sizeof(*m));
+    m->dx = dx; m->du = du;
+    return m;
+}
+
+void mca_add_grid_refs(struct MCAparam *m, size_t *ngrid, double **xgrid, double hmin, double *hvec)
+{ /* borrows the grid; t[2i] = h2/h_i, t[2i+1] = h2/h_i^2 (bellman.c:181-186) */
+    m->ngrid = ngrid; m->xgrid = xgrid; m->hmin = hmin; m->hvec = hvec;
+    m->h2 = hmin * hmin;
+    free(m->t);
+    m->t = xcalloc(2 * m->dx, sizeof(double));
+    for (size_t i = 0; i < m->dx; i++) { m->t[2 * i] = m->h2 / hvec[i]; m->t[2 * i + 1] = m->t[2 * i] / hvec[i]; }
+}
+
+void mca_param_destroy(struct MCAparam *m) { if (m) { free(m->t); free(m); } }
+
+struct DPparam {
+    struct Drift *drift;
+    struct Diff *diff;
+    struct Boundary *bound;
+    double discount;
+    int (*stagecost)(double, const double *, const double *, double *, double *);
+    int (*boundcost)(double, const double *, double *);
+    int (*obscost)(const double *, double *);
+    int model;
+    double prm[C3SC_MAX_PARAMS];
+    int nprm;
+    int model_checked;
+};
+
+struct DPparam *dp_param_create(size_t dx, size_t du, size_t dw, double discount)
+{
+    struct DPparam *dp = xcalloc(1, sizeof(*dp));
+    dp->drift = drift_alloc(dx, du);
+    dp->diff = diff_alloc(dx, du, dw);
+    dp->discount = discount;
+    return dp;
+}
+void dp_param_destroy(struct DPparam *dp) { if (dp) { drift_free(dp->drift); diff_free(dp->diff); free(dp); } }
+void dp_param_add_drift(struct DPparam *dp, c3sc_dyn_fn b, void *a) { drift_add_func(dp->drift, b, a); }
+void dp_param_add_diff(struct DPparam *dp, c3sc_dyn_fn s, void *a) { diff_add_func(dp->diff, s, a); }
+void dp_param_add_boundary(struct DPparam *dp, struct Boundary *b) { dp->bound = b; }
+void dp_param_add_stagecost(struct DPparam *dp, int (*f)(double, const double *, const double *, double *, double *)) { dp->stagecost = f; }
+void dp_param_add_boundcost(struct DPparam *dp, int (*f)(double, const double *, double *)) { dp->boundcost = f; }
+void dp_param_add_obscost(struct DPparam *dp, int (*f)(const double *, double *)) { dp->obscost = f; }
+void dp_param_set_device_model(struct DPparam *dp, int model, const double *params, size_t nparams)
+{
+    if (nparams > C3SC_MAX_PARAMS) DIE("dp_param_set_device_model: too many parameters");
+    dp->model = model;
+    dp->nprm = (int)nparams;
+    memset(dp->prm, 0, sizeof(dp->prm));
+    for (size_t i = 0; i < nparams; i++) dp->prm[i] = params[i];
+    dp->model_checked = 0;
+}
+
+struct ControlParams {
+    double time;
+    size_t dx, dw, N;
+    const double *x; /* borrowed (bellman.c:329-335) */
+    struct DPparam *dp;
+    struct MCAparam *mca;
+    struct Workspace *work;
+    struct c3Opt *opt;
+    int res_last_grad;
+};
+
+struct ControlParams *control_params_create(size_t dx, size_t dw, struct DPparam *dp, struct MCAparam *mca,
+                                            struct Workspace *work, struct c3Opt *opt)
+{
+    struct ControlParams *c = xcalloc(1, sizeof(*c));
+    c->dx = dx; c->dw = dw; c->dp = dp; c->mca = mca; c->work = work; c->opt = opt;
+    return c;
+}
+void control_params_add_time_and_states(struct ControlParams *c, double time, size_t N, const double *x) { c->time = time; c->N = N; c->x = x; }
+int control_params_get_last_res(const struct ControlParams *c) { return c->res_last_grad; }
+void control_params_destroy(struct ControlParams *c) { free(c); }
+
+struct Memory { void *shared; size_t private; }; /* bellman.c:59-63 */
+
+double bellman_control(size_t du, const double *u, double *grad_u, void *args)
+{ /* bellman.c:367-480: objective of one control at one node; reads the node's costs/absorbed from the workspace */
+    struct Memory *mem = args;
+    struct ControlParams *p = mem->shared;
+    const size_t node = mem->private, dx = p->dx, dw = p->dw;
+    struct DPparam *dp = p->dp;
+    struct Workspace *w = p->work;
+    const double *x = p->x + node * dx;
+    const int ab = *workspace_get_absorbed(w, node);
+    double val = 0.0;
+    if (grad_u != NULL) for (size_t i = 0; i < du; i++) grad_u[i] = 0.0;
+    if (ab == 1) { int r = dp->boundcost(p->time, x, &val); assert(r == 0); (void)r; return val; }
+    if (ab == -1) { int r = dp->obscost(x, &val); assert(r == 0); (void)r; return val; }
+    if (ab != 0) { fprintf(stderr, "Unrecognized aborbed condition %d\n", ab); exit(1); }
+    double *drift = workspace_get_drift(w, node), *diff = workspace_get_diff(w, node);
+    double *prob = workspace_get_prob(w, node), *dt = workspace_get_dt(w, node);
+    double *costs = workspace_get_costs(w, node);
+    double stage;
+    int res;
+    if (grad_u != NULL) {
+        double *gdrift = workspace_get_grad_drift(w, node), *gdiff = workspace_get_grad_diff(w, node);
+        double *gprob = workspace_get_grad_prob(w, node), *gdt = workspace_get_grad_dt(w, node);
+        double *gstage = workspace_get_grad_stage(w, node), *space = workspace_get_control_size_extra(w, node);
+        res = drift_eval(dp->drift, p->time, x, u, drift, gdrift); assert(res == 0);
+        res = diff_eval(dp->diff, p->time, x, u, diff, gdiff); assert(res == 0);
+        res = dp->stagecost(p->time, x, u, &stage, gstage); assert(res == 0);
+        res = transition_assemble(dx, du, dw, p->mca->h2, p->mca->t, drift, gdrift, diff, gdiff, prob, gprob, dt, gdt, space);
+        p->res_last_grad = res;
+        val = bellmanrhs(dx, du, stage, gstage, dp->discount, prob, gprob, *dt, gdt, costs, grad_u);
+    } else {
+        res = drift_eval(dp->drift, p->time, x, u, drift, NULL); assert(res == 0);
+        res = diff_eval(dp->diff, p->time, x, u, diff, NULL); assert(res == 0);
+        res = dp->stagecost(p->time, x, u, &stage, NULL); assert(res == 0);
+        res = transition_assemble(dx, du, dw, p->mca->h2, p->mca->t, drift, NULL, diff, NULL, prob, NULL, dt, NULL, NULL);
+        assert(res == 0); /* bellman.c:452 */
+        val = bellmanrhs(dx, du, stage, NULL, dp->discount, prob, NULL, *dt, NULL, costs, NULL);
+    }
+    (void)res;
+    return val;
+}
+
+int bellman_optimal(size_t du, double *u, double *val, void *arg)
+{ /* bellman.c:504-543: single node on the host (what c3control_controller needs); BRUTEFORCE only */
+    struct Memory *mem = arg;
+    struct ControlParams *p = mem->shared;
+    const int ab = *workspace_get_absorbed(p->work, mem->private);
+    if (ab != 0) {
+        for (size_t i = 0; i < du; i++) u[i] = 0.0;
+        *val = bellman_control(du, u, NULL, arg);
+        return 0;
+    }
+    struct c3Opt *opt = c3opt_copy(p->opt);
+    c3opt_add_objective(opt, &bellman_control, mem);
+    if (!c3opt_is_bruteforce(opt)) DIE("bellman_optimal: only BRUTEFORCE minimisation is supported");
+    c3opt_minimize(opt, u, val);
+    c3opt_free(opt);
+    return 0;
+}
+
+struct VIparam {
+    struct ControlParams *cp;
+    struct ValueF *vf;
+    size_t nstate_evals, nnode_evals;
+    double convergence, time_in_loop;
+};
+
+struct VIparam *vi_param_create(double convergence)
+{
+    struct VIparam *vi = xcalloc(1, sizeof(*vi));
+    vi->convergence = convergence;
+    return vi;
+}
+void vi_param_destroy(struct VIparam *vi) { free(vi); }
+void vi_param_add_cp(struct VIparam *vi, struct ControlParams *cp) { vi->cp = cp; }
+void vi_param_add_value(struct VIparam *vi, struct ValueF *vf) { vi->vf = vf; vi->nstate_evals = 0; vi->nnode_evals = 0; }
+size_t vi_param_get_nnode_evals(const struct VIparam *vi) { return vi->nnode_evals; }
+
+static uint64_t fnv(uint64_t h, const void *p, size_t n)
+{
+    const unsigned char *b = p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+    return h;
+}
+
+/* push the host-side problem description to the device context (cheap; idempotent) */
+static struct c3sc_hip_ctx *sync_device(struct VIparam *vi)
+{
+    struct ControlParams *cp = vi->cp;
+    struct MCAparam *mca = cp->mca;
+    struct DPparam *dp = cp->dp;
+    struct c3sc_hip_ctx *ctx = workspace_get_hip_ctx(cp->work);
+    static struct c3sc_hip_ctx *cfg_ctx = NULL;
+    static uint64_t cfg_sig = 0;
+    const size_t d = mca->dx;
+    if (dp->model == 0)
+        DIE("bellman_vi: no device model registered (dp_param_set_device_model / c3control_set_device_model); "
+            "host callbacks cannot be called from a kernel");
+    if (!c3opt_is_bruteforce(cp->opt)) DIE("bellman_vi: only BRUTEFORCE control minimisation runs on the device");
+    /* signature of everything the device holds besides the value function */
+    int bc[C3SC_MAX_DIM];
+    double lb[C3SC_MAX_OBSTACLES * C3SC_MAX_DIM], ub[C3SC_MAX_OBSTACLES * C3SC_MAX_DIM];
+    const size_t nobs = boundary_get_nobs(dp->bound);
+    uint64_t sig = 1469598103934665603ULL;
+    for (size_t m = 0; m < d; m++) {
+        bc[m] = (int)boundary_type_dim(dp->bound, m, 0);
+        sig = fnv(sig, &bc[m], sizeof(int));
+        sig = fnv(sig, &mca->ngrid[m], sizeof(size_t));
+        sig = fnv(sig, mca->xgrid[m], mca->ngrid[m] * sizeof(double));
+    }
+    for (size_t o = 0; o < nobs; o++)
+        for (size_t m = 0; m < d; m++) {
+            lb[o * d + m] = boundary_obstacle_get_lb(dp->bound, o)[m];
+            ub[o * d + m] = boundary_obstacle_get_ub(dp->bound, o)[m];
+        }
+    sig = fnv(sig, lb, nobs * d * sizeof(double));
+    sig = fnv(sig, ub, nobs * d * sizeof(double));
+    sig = fnv(sig, mca->t, 2 * d * sizeof(double));
+    sig = fnv(sig, &mca->h2, sizeof(double));
+    sig = fnv(sig, &dp->discount, sizeof(double));
+    sig = fnv(sig, &dp->model, sizeof(int));
+    sig = fnv(sig, dp->prm, sizeof(dp->prm));
+    sig = fnv(sig, c3opt_get_brute_vals(cp->opt), c3opt_get_nbrute(cp->opt) * c3opt_get_d(cp->opt) * sizeof(double));
+    if (cfg_ctx != ctx || cfg_sig != sig) {
+        hipok(ctx, c3sc_hip_set_grid(ctx, (int)d, mca->ngrid, (const double *const *)mca->xgrid), "c3sc_hip_set_grid");
+        hipok(ctx, c3sc_hip_set_boundary(ctx, bc, (int)nobs, lb, ub), "c3sc_hip_set_boundary");
+        hipok(ctx, c3sc_hip_set_mca(ctx, mca->h2, mca->t, dp->discount), "c3sc_hip_set_mca");
+        hipok(ctx, c3sc_hip_set_model(ctx, dp->model, dp->prm, dp->nprm), "c3sc_hip_set_model");
+        hipok(ctx, c3sc_hip_set_controls(ctx, (int)c3opt_get_nbrute(cp->opt), (int)c3opt_get_d(cp->opt), c3opt_get_brute_vals(cp->opt)),
+              "c3sc_hip_set_controls");
+        cfg_ctx = ctx;
+        cfg_sig = sig;
+        g_uploaded_ctx = NULL; /* set_grid invalidates the resident value function */
+    }
+    valuef_bind_device(vi->vf, ctx);
+    return ctx;
+}
+
+/* first-use cross-check of the device model against the host callbacks: a handful of live nodes are
+ * re-evaluated on the host with bellman_optimal (callbacks + transition_assemble + bellmanrhs). */
+static void cross_check_model(struct VIparam *vi, struct c3sc_hip_ctx *ctx, size_t k, const int32_t *idx, size_t N,
+                              const double *x, const double *gpu_out, const int32_t *gpu_abs)
+{
+    struct ControlParams *cp = vi->cp;
+    struct DPparam *dp = cp->dp;
+    if (dp->model_checked || dp->stagecost == NULL || dp->boundcost == NULL || dp->obscost == NULL) return;
+    const size_t dx = cp->dx, S = 2 * dx + 1;
+    double *costs = xcalloc(N * S, sizeof(double));
+    int32_t *ab = xcalloc(N, sizeof(int32_t));
+    hipok(ctx, c3sc_hip_stencil_fibers_host(ctx, (int)k, 1, idx, costs, ab), "c3sc_hip_stencil_fibers_host");
+    control_params_add_time_and_states(cp, 0.0, N, x);
+    double u[16];
+    size_t checked = 0;
+    for (size_t j = 0; j < N && checked < 6; j += (N > 6 ? N / 6 : 1)) {
+        if (ab[j] != gpu_abs[j]) DIE("device/host absorbed flag mismatch at node %zu", j);
+        memcpy(workspace_get_costs(cp->work, 0), costs + j * S, S * sizeof(double));
+        *workspace_get_absorbed(cp->work, 0) = ab[j];
+        struct Memory mem = {cp, 0};
+        const double *xs = cp->x;
+        cp->x = x + j * dx; /* node 0 of a one-node view */
+        double hv;
+        bellman_optimal(c3opt_get_d(cp->opt), u, &hv, &mem);
+        cp->x = xs;
+        const double tol = 1e-9 * (fabs(hv) > 1.0 ? fabs(hv) : 1.0);
+        if (fabs(hv - gpu_out[j]) > tol)
+            DIE("device model %d does not reproduce the host callbacks: node %zu host %.17g device %.17g", dp->model, j, hv, gpu_out[j]);
+        checked++;
+    }
+    dp->model_checked = 1;
+    free(costs);
+    free(ab);
+}
+
+int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg)
+{ /* bellman.c:1295-1423 for F fibers: index conversion + memo on the host, every missing fiber in ONE launch */
+    struct VIparam *vi = arg;
+    struct ControlParams *cp = vi->cp;
+    assert(cp != NULL && vi->vf != NULL);
+    struct MCAparam *mca = cp->mca;
+    const size_t dx = mca->dx;
+    struct c3sc_hip_ctx *ctx = sync_device(vi);
+    struct HTable *ht = workspace_get_vi_htable(cp->work);
+    size_t *ser = workspace_get_ind_to_serialize(cp->work);
+    char key[256];
+
+    int32_t *idx = xcalloc(F * dx, sizeof(int32_t));
+    size_t *kdim = xcalloc(F, sizeof(size_t));
+    unsigned char *need = xcalloc(F, 1);
+    unsigned char *hit = xcalloc(F * N, 1);
+    size_t fi[C3SC_MAX_DIM];
+    size_t k0 = dx;
+    for (size_t f = 0; f < F; f++) {
+        size_t dv;
+        int res = convert_fiber_to_ind(dx, N, x + f * N * dx, mca->ngrid, mca->xgrid, fi, &dv);
+        if (res != 0) { printf("\n======================================\nError calling convert fiber to _ind!!\n"); }
+        assert(res == 0 && dv < dx && N == mca->ngrid[dv]); /* nodeutil.c:681-683 */
+        if (k0 == dx) k0 = dv;
+        if (dv != k0) DIE("bellman_vi_batch: all fibers of a batch must vary the same dimension");
+        kdim[f] = dv;
+        for (size_t m = 0; m < dx; m++) { idx[f * dx + m] = (m == dv) ? 0 : (int32_t)fi[m]; ser[m] = fi[m]; }
+        ser[dx] = 0;                                   /* bellman.c:1337 */
+        ser[dx + 1] = workspace_get_vi_iter(cp->work); /* bellman.c:1338 */
+        for (size_t j = 0; j < N; j++) { /* memo lookup, bellman.c:1341-1353 */
+            ser[dv] = j;
+            size_t_a_to_char(ser, dx + 2, key);
+            size_t nb = 0;
+            double *v = htable_get_element(ht, key, &nb);
+            if (v != NULL) { out[f * N + j] = v[0]; hit[f * N + j] = 1; }
+            else need[f] = 1;
+        }
+    }
+    /* compact the fibers that still need work and run them in one launch */
+    size_t nrun = 0;
+    for (size_t f = 0; f < F; f++) nrun += need[f];
+    if (nrun > 0) {
+        int32_t *ridx = xcalloc(nrun * dx, sizeof(int32_t));
+        double *rout = xcalloc(nrun * N, sizeof(double));
+        int32_t *rabs = xcalloc(nrun * N, sizeof(int32_t));
+        size_t r = 0;
+        for (size_t f = 0; f < F; f++)
+            if (need[f]) memcpy(ridx + (r++) * dx, idx + f * dx, dx * sizeof(int32_t));
+        hipok(ctx, c3sc_hip_bellman_fibers_host(ctx, (int)k0, nrun, ridx, rout, NULL, rabs), "c3sc_hip_bellman_fibers_host");
+        unsigned st = 0;
+        hipok(ctx, c3sc_hip_get_status(ctx, &st, 1), "c3sc_hip_get_status");
+        if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+        r = 0;
+        for (size_t f = 0; f < F; f++) {
+            if (!need[f]) continue;
+            if (r == 0) cross_check_model(vi, ctx, k0, ridx, N, x + f * N * dx, rout, rabs);
+            for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
+            ser[dx] = 0;
+            ser[dx + 1] = workspace_get_vi_iter(cp->work);
+            for (size_t j = 0; j < N; j++) {
+                if (hit[f * N + j]) continue;
+                out[f * N + j] = rout[r * N + j];
+                ser[k0] = j;
+                size_t_a_to_char(ser, dx + 2, key);
+                htable_add_element(ht, key, &out[f * N + j], 1); /* bellman.c:1383, 1413-1417 */
+                vi->nstate_evals++;
+                vi->nnode_evals++;
+            }
+            r++;
+        }
+        free(ridx); free(rout); free(rabs);
+    }
+    free(idx); free(kdim); free(need); free(hit);
+    return 0;
+}
+
+int bellman_vi(size_t N, const double *x, double *out, void *arg) { return bellman_vi_batch(1, N, x, out, arg); }
+
+/* =============================================================================== C3Control */
+struct C3Control {
+    size_t dx, du, dw;
+    size_t *ngrid; /* borrowed (bellman.c:1972) */
+    double **xgrid, *h, hmin;
+    struct Boundary *bound;
+    struct MCAparam *mca;
+    struct DPparam *dp;
+    struct Workspace *work;
+    struct ControlParams *cp_active;
+};
+
+struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, double *ub, size_t *ngrid, double discount)
+{ /* bellman.c:1962-1999 */
+    struct C3Control *c = xcalloc(1, sizeof(*c));
+    c->dx = dx; c->du = du; c->dw = dw; c->ngrid = ngrid;
+    c->xgrid = xcalloc(dx, sizeof(double *));
+    c->h = xcalloc(dx, sizeof(double));
+    c->hmin = ub[0] - lb[0];
+    size_t maxn = ngrid[0];
+    for (size_t m = 0; m < dx; m++) {
+        c->xgrid[m] = xcalloc(ngrid[m], sizeof(double));
+        for (size_t i = 0; i < ngrid[m]; i++) /* C3 linspace */
+            c->xgrid[m][i] = lb[m] + (ub[m] - lb[m]) * (double)i / (double)(ngrid[m] - 1);
+        c->h[m] = c->xgrid[m][1] - c->xgrid[m][0];
+        if (c->h[m] < c->hmin) c->hmin = c->h[m];
+        if (ngrid[m] > maxn) maxn = ngrid[m];
+    }
+    c->bound = boundary_alloc(dx, lb, ub);
+    c->mca = mca_param_create(dx, du);
+    mca_add_grid_refs(c->mca, c->ngrid, c->xgrid, c->hmin, c->h);
+    c->dp = dp_param_create(dx, du, dw, discount);
+    dp_param_add_boundary(c->dp, c->bound);
+    c->work = workspace_alloc(dx, du, dw, maxn);
+    return c;
+}
+
+void c3control_destroy(struct C3Control *c)
+{
+    if (c == NULL) return;
+    boundary_free(c->bound); mca_param_destroy(c->mca); dp_param_destroy(c->dp); workspace_free(c->work);
+    for (size_t m = 0; m < c->dx; m++) free(c->xgrid[m]);
+    free(c->xgrid); free(c->h); free(c);
+}
+
+size_t *c3control_get_ngrid(struct C3Control *c) { return c ? c->ngrid : NULL; }
+double **c3control_get_xgrid(struct C3Control *c) { return c ? c->xgrid : NULL; }
+void c3control_set_external_boundary(struct C3Control *c, size_t dim, char *type) { boundary_external_set_type(c->bound, dim, type); }
+void c3control_add_obstacle(struct C3Control *c, double *center, double *widths) { boundary_add_obstacle(c->bound, center, widths); }
+void c3control_add_drift(struct C3Control *c, c3sc_dyn_fn b, void *a) { dp_param_add_drift(c->dp, b, a); }
+void c3control_add_diff(struct C3Control *c, c3sc_dyn_fn s, void *a) { dp_param_add_diff(c->dp, s, a); }
+void c3control_add_stagecost(struct C3Control *c, int (*f)(double, const double *, const double *, double *, double *)) { dp_param_add_stagecost(c->dp, f); }
+void c3control_add_boundcost(struct C3Control *c, int (*f)(double, const double *, double *)) { dp_param_add_boundcost(c->dp, f); }
+void c3control_add_obscost(struct C3Control *c, int (*f)(const double *, double *)) { dp_param_add_obscost(c->dp, f); }
+void c3control_set_device_model(struct C3Control *c, int model, const double *params, size_t n) { dp_param_set_device_model(c->dp, model, params, n); }
+
+struct VIparam *c3control_begin_vi(struct C3Control *c, struct ValueF *vf, struct c3Opt *opt)
+{ /* the callback state c3control_step_vi assembles before valuef_interp (bellman.c:2192-2199) */
+    c->cp_active = control_params_create(c->dx, c->dw, c->dp, c->mca, c->work, opt);
+    struct VIparam *vi = vi_param_create(1e-10);
+    vi_param_add_cp(vi, c->cp_active);
+    vi_param_add_value(vi, vf);
+    workspace_increment_vi_iter(c->work);
+    return vi;
+}
+
+void c3control_end_vi(struct C3Control *c, struct VIparam *vi, size_t *nevals)
+{
+    if (nevals) *nevals = vi->nnode_evals;
+    vi_param_destroy(vi);
+    control_params_destroy(c->cp_active);
+    c->cp_active = NULL;
+}

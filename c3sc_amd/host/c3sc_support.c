@@ -1,0 +1,374 @@
+/* c3sc_support.c -- host-side problem objects of the c3sc C API that the Bellman path reads:
+ * Boundary (src/boundary.c), Drift/Diff holders (src/dynamics.c), the string-keyed memo
+ * (src/hashgrid.c), ApproxArgs / Workspace (src/util.c) and a brute-force c3Opt.
+ * Own implementation of the reference's interface; citations are relative to the reference tree. */
+#include <assert.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "c3sc/c3sc.h"
+#include "c3sc_hip.h"
+
+static void *xmalloc(size_t n)
+{
+    void *p = calloc(1, n ? n : 1);
+    if (p == NULL) { fprintf(stderr, "c3sc: out of memory\n"); exit(1); }
+    return p;
+}
+
+/* ------------------------------------------------------------------------------ Boundary */
+#define MAX_OBS 10 /* boundary.c:393 */
+struct Box { double *lb, *ub; };
+struct Boundary {
+    size_t d;
+    enum EBTYPE *type;
+    double *lo, *hi;
+    size_t nobs;
+    struct Box obs[MAX_OBS];
+};
+
+struct Boundary *boundary_alloc(size_t d, double *lb, double *ub)
+{
+    struct Boundary *b = xmalloc(sizeof(*b));
+    b->d = d;
+    b->type = xmalloc(d * sizeof(*b->type));
+    b->lo = xmalloc(d * sizeof(double));
+    b->hi = xmalloc(d * sizeof(double));
+    for (size_t m = 0; m < d; m++) {
+        b->type[m] = ABSORB; /* every dimension starts absorbing (boundary.c:387) */
+        b->lo[m] = lb[m];
+        b->hi[m] = ub[m];
+    }
+    return b;
+}
+
+struct Boundary *boundary_copy_deep(struct Boundary *o)
+{
+    if (o == NULL) return NULL;
+    struct Boundary *b = boundary_alloc(o->d, o->lo, o->hi);
+    memcpy(b->type, o->type, o->d * sizeof(*b->type));
+    for (size_t i = 0; i < o->nobs; i++) {
+        b->obs[i].lb = xmalloc(o->d * sizeof(double));
+        b->obs[i].ub = xmalloc(o->d * sizeof(double));
+        memcpy(b->obs[i].lb, o->obs[i].lb, o->d * sizeof(double));
+        memcpy(b->obs[i].ub, o->obs[i].ub, o->d * sizeof(double));
+    }
+    b->nobs = o->nobs;
+    return b;
+}
+
+void boundary_free(struct Boundary *b)
+{
+    if (b == NULL) return;
+    for (size_t i = 0; i < b->nobs; i++) { free(b->obs[i].lb); free(b->obs[i].ub); }
+    free(b->type); free(b->lo); free(b->hi); free(b);
+}
+
+void boundary_external_set_type(struct Boundary *b, size_t dim, char *type)
+{
+    assert(b != NULL && dim < b->d);
+    if (strcmp(type, "absorb") == 0) b->type[dim] = ABSORB;
+    else if (strcmp(type, "periodic") == 0) b->type[dim] = PERIODIC;
+    else if (strcmp(type, "reflect") == 0) b->type[dim] = REFLECT;
+    else { fprintf(stderr, "Boundary type %s unknown\n", type); exit(1); }
+}
+
+void boundary_add_obstacle(struct Boundary *b, double *center, double *lengths)
+{
+    if (b->nobs == MAX_OBS) { fprintf(stderr, "Not enough space allocated for obstacles in boundary\n"); exit(1); }
+    struct Box *o = &b->obs[b->nobs++];
+    o->lb = xmalloc(b->d * sizeof(double));
+    o->ub = xmalloc(b->d * sizeof(double));
+    for (size_t m = 0; m < b->d; m++) { /* boundary.c:264-267 */
+        o->lb[m] = center[m] - lengths[m] / 2.0;
+        o->ub[m] = center[m] + lengths[m] / 2.0;
+    }
+}
+
+size_t boundary_get_nobs(struct Boundary *b) { return b->nobs; }
+size_t boundary_get_dim(const struct Boundary *b) { return b->d; }
+double *boundary_obstacle_get_lb(struct Boundary *b, size_t i) { return b->obs[i].lb; }
+double *boundary_obstacle_get_ub(struct Boundary *b, size_t i) { return b->obs[i].ub; }
+
+enum EBTYPE boundary_type_dim(const struct Boundary *b, size_t dim, int right)
+{
+    (void)right; /* one type per dimension, both faces (boundary.c:604-614) */
+    return b->type[dim];
+}
+
+int boundary_in_obstacle(const struct Boundary *b, const double *x)
+{
+    for (size_t i = 0; i < b->nobs; i++) {
+        size_t m = 0;
+        while (m < b->d && !(x[m] < b->obs[i].lb[m] || x[m] > b->obs[i].ub[m])) m++;
+        if (m == b->d) return 1; /* inclusive box, boundary.c:329-344 */
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------ Drift / Diff */
+struct Drift { size_t dx, du; c3sc_dyn_fn f; void *args; };
+struct Diff { size_t dx, du, dw; c3sc_dyn_fn f; void *args; };
+
+struct Drift *drift_alloc(size_t dx, size_t du)
+{
+    struct Drift *b = xmalloc(sizeof(*b));
+    b->dx = dx; b->du = du;
+    return b;
+}
+void drift_free(struct Drift *b) { free(b); }
+void drift_add_func(struct Drift *b, c3sc_dyn_fn f, void *args) { b->f = f; b->args = args; }
+size_t drift_get_dx(struct Drift *b) { return b->dx; }
+int drift_eval(struct Drift *b, double t, const double *x, const double *u, double *out, double *jac)
+{
+    if (b->f == NULL) { fprintf(stderr, "Warning: drift dynamics (b->bdyn) not yet specified\n"); return 1; }
+    return b->f(t, x, u, out, jac, b->args);
+}
+
+struct Diff *diff_alloc(size_t dx, size_t du, size_t dw)
+{
+    struct Diff *s = xmalloc(sizeof(*s));
+    s->dx = dx; s->du = du; s->dw = dw;
+    return s;
+}
+void diff_free(struct Diff *s) { free(s); }
+void diff_add_func(struct Diff *s, c3sc_dyn_fn f, void *args) { s->f = f; s->args = args; }
+size_t diff_get_dw(struct Diff *s) { return s->dw; }
+int diff_eval(struct Diff *s, double t, const double *x, const double *u, double *out, double *grad)
+{
+    if (s->f == NULL) { fprintf(stderr, "Warning: diff dynamics not yet specified\n"); return 1; }
+    return s->f(t, x, u, out, grad, s->args);
+}
+
+/* ------------------------------------------------------------------------------ memo (hashgrid.c) */
+char *size_t_a_to_char(size_t *arr, size_t n, char *buffer)
+{ /* decimal text, one trailing blank per entry, 256-byte buffer (hashgrid.c:49-61) */
+    int used = 0;
+    for (size_t i = 0; i < n; i++) used += snprintf(buffer + used, (size_t)(256 - used), "%zu ", arr[i]);
+    return buffer;
+}
+
+size_t c3sc_hashchar(size_t size, const char *s)
+{ /* h = c + 31 h with size_t wrap-around (hashgrid.c:75-87) */
+    size_t h = 0;
+    while (*s != '\0') { h = (size_t)*s + (h << 5) - h; s++; }
+    return h % size;
+}
+
+struct HNode { struct HNode *next; size_t N; double *data; char key[256]; };
+struct HTable { size_t size; struct HNode **bucket; };
+
+struct HTable *htable_create(size_t size)
+{
+    if (size < 1) return NULL;
+    struct HTable *ht = xmalloc(sizeof(*ht));
+    ht->size = size;
+    ht->bucket = xmalloc(size * sizeof(*ht->bucket));
+    return ht;
+}
+
+void htable_destroy(struct HTable *ht)
+{
+    if (ht == NULL) return;
+    for (size_t i = 0; i < ht->size; i++)
+        for (struct HNode *n = ht->bucket[i]; n != NULL;) { struct HNode *nx = n->next; free(n->data); free(n); n = nx; }
+    free(ht->bucket);
+    free(ht);
+}
+
+int htable_add_element(struct HTable *ht, char *key, double *data, size_t N)
+{ /* push front, no duplicate check (hashgrid.c:252-261) */
+    struct HNode *n = xmalloc(sizeof(*n));
+    strcpy(n->key, key);
+    n->N = N;
+    n->data = xmalloc(N * sizeof(double));
+    memcpy(n->data, data, N * sizeof(double));
+    struct HNode **head = &ht->bucket[c3sc_hashchar(ht->size, key)];
+    n->next = *head;
+    *head = n;
+    return 0;
+}
+
+double *htable_get_element(struct HTable *ht, char *key, size_t *N)
+{
+    *N = 0;
+    for (struct HNode *n = ht->bucket[c3sc_hashchar(ht->size, key)]; n != NULL; n = n->next)
+        if (strcmp(key, n->key) == 0) { *N = n->N; return n->data; }
+    return NULL;
+}
+
+/* ------------------------------------------------------------------------------ ApproxArgs */
+struct ApproxArgs { double cross_tol, round_tol; size_t kickrank, startrank, maxrank; int adapt; enum function_class fc; };
+
+struct ApproxArgs *approx_args_init(void)
+{
+    struct ApproxArgs *a = xmalloc(sizeof(*a));
+    a->cross_tol = 1e-10; a->round_tol = 1e-10; a->kickrank = 10; a->startrank = 5; a->maxrank = 40; /* util.c:124-130 */
+    a->adapt = 1; a->fc = LINELM;
+    return a;
+}
+void approx_args_free(struct ApproxArgs *a) { free(a); }
+void approx_args_set_function_class(struct ApproxArgs *a, enum function_class fc) { a->fc = fc; }
+enum function_class approx_args_get_function_class(const struct ApproxArgs *a) { return a->fc; }
+void approx_args_set_cross_tol(struct ApproxArgs *a, double v) { a->cross_tol = v; }
+double approx_args_get_cross_tol(const struct ApproxArgs *a) { return a->cross_tol; }
+void approx_args_set_round_tol(struct ApproxArgs *a, double v) { a->round_tol = v; }
+double approx_args_get_round_tol(const struct ApproxArgs *a) { return a->round_tol; }
+void approx_args_set_kickrank(struct ApproxArgs *a, size_t v) { a->kickrank = v; }
+size_t approx_args_get_kickrank(const struct ApproxArgs *a) { return a->kickrank; }
+void approx_args_set_maxrank(struct ApproxArgs *a, size_t v) { a->maxrank = v; }
+size_t approx_args_get_maxrank(const struct ApproxArgs *a) { return a->maxrank; }
+void approx_args_set_startrank(struct ApproxArgs *a, size_t v) { a->startrank = v; }
+size_t approx_args_get_startrank(const struct ApproxArgs *a) { return a->startrank; }
+void approx_args_set_adapt(struct ApproxArgs *a, int v) { a->adapt = v; }
+int approx_args_get_adapt(const struct ApproxArgs *a) { return a->adapt; }
+
+size_t uniform_stride(size_t N, size_t M)
+{ /* largest stride s with s*(M-1) < N-1, at least ... (util.c:995-1006) */
+    assert(N >= M);
+    size_t s = 1;
+    while (s * (M - 1) < (N - 1)) s++;
+    return s - 1;
+}
+
+/* ------------------------------------------------------------------------------ brute-force c3Opt */
+struct c3Opt {
+    enum c3opt_alg alg;
+    size_t d, n;
+    double *vals;
+    double (*f)(size_t, const double *, double *, void *);
+    void *farg;
+};
+
+struct c3Opt *c3opt_alloc(enum c3opt_alg alg, size_t d)
+{
+    if (alg != BRUTEFORCE) {
+        fprintf(stderr, "c3sc (MI355X build): only BRUTEFORCE control minimisation is supported; "
+                        "gradient-based c3opt algorithms live in C3 and are out of scope\n");
+        exit(1);
+    }
+    struct c3Opt *o = xmalloc(sizeof(*o));
+    o->alg = alg; o->d = d;
+    return o;
+}
+
+struct c3Opt *c3opt_copy(struct c3Opt *o)
+{
+    struct c3Opt *c = xmalloc(sizeof(*c));
+    *c = *o;
+    c->vals = xmalloc(o->n * o->d * sizeof(double));
+    memcpy(c->vals, o->vals, o->n * o->d * sizeof(double));
+    return c;
+}
+
+void c3opt_free(struct c3Opt *o) { if (o) { free(o->vals); free(o); } }
+
+void c3opt_set_brute_force_vals(struct c3Opt *o, size_t n, double *vals)
+{
+    free(o->vals);
+    o->n = n;
+    o->vals = xmalloc(n * o->d * sizeof(double));
+    memcpy(o->vals, vals, n * o->d * sizeof(double));
+}
+
+int c3opt_is_bruteforce(const struct c3Opt *o) { return o->alg == BRUTEFORCE; }
+void c3opt_add_objective(struct c3Opt *o, double (*f)(size_t, const double *, double *, void *), void *arg) { o->f = f; o->farg = arg; }
+size_t c3opt_get_nbrute(const struct c3Opt *o) { return o->n; }
+const double *c3opt_get_brute_vals(const struct c3Opt *o) { return o->vals; }
+size_t c3opt_get_d(const struct c3Opt *o) { return o->d; }
+
+int c3opt_minimize(struct c3Opt *o, double *x, double *val)
+{ /* candidates in list order, first strict minimum wins */
+    assert(o->f != NULL && o->n > 0);
+    size_t best = 0;
+    double bv = 0.0;
+    for (size_t c = 0; c < o->n; c++) {
+        double v = o->f(o->d, o->vals + c * o->d, NULL, o->farg);
+        if (c == 0 || v < bv) { bv = v; best = c; }
+    }
+    memcpy(x, o->vals + best * o->d, o->d * sizeof(double));
+    *val = bv;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------ Workspace */
+struct Workspace {
+    size_t dx, du, dw, N;
+    size_t off[11]; /* slab layout util.c:738-748 */
+    double *slab;   /* N nodes x off[10] doubles */
+    double *costs;  /* N x (2dx+1) */
+    int *absorbed;
+    size_t *ind_to_serialize;
+    struct HTable *vi_htable;
+    size_t vi_iter;
+    char **keys;
+    struct c3sc_hip_ctx *hip;
+};
+
+#define NBUCKET 1000000 /* util.c:760 */
+
+struct Workspace *workspace_alloc(size_t dx, size_t du, size_t dw, size_t N)
+{
+    struct Workspace *w = xmalloc(sizeof(*w));
+    w->dx = dx; w->du = du; w->dw = dw; w->N = N;
+    const size_t sz[11] = {dx, dx * du, dx * dw, dx * dw * du, 1, du, 2 * dx + 1, du * (2 * dx + 1), du, du, du};
+    size_t acc = 0;
+    for (int i = 0; i < 11; i++) { acc += sz[i]; w->off[i] = acc; }
+    w->slab = xmalloc(N * w->off[10] * sizeof(double));
+    w->costs = xmalloc(N * (2 * dx + 1) * sizeof(double));
+    w->absorbed = xmalloc(N * sizeof(int));
+    w->ind_to_serialize = xmalloc((dx + 3) * sizeof(size_t));
+    w->vi_htable = htable_create(NBUCKET);
+    w->keys = xmalloc(N * sizeof(char *));
+    for (size_t i = 0; i < N; i++) w->keys[i] = xmalloc(256);
+    return w;
+}
+
+void workspace_free(struct Workspace *w)
+{
+    if (w == NULL) return;
+    for (size_t i = 0; i < w->N; i++) free(w->keys[i]);
+    free(w->keys); free(w->slab); free(w->costs); free(w->absorbed); free(w->ind_to_serialize);
+    htable_destroy(w->vi_htable);
+    if (w->hip) c3sc_hip_ctx_destroy(w->hip);
+    free(w);
+}
+
+void workspace_reset_vi_htable(struct Workspace *w) { htable_destroy(w->vi_htable); w->vi_htable = htable_create(NBUCKET); }
+void workspace_increment_vi_iter(struct Workspace *w) { w->vi_iter++; }
+size_t workspace_get_vi_iter(const struct Workspace *w) { return w->vi_iter; }
+struct HTable *workspace_get_vi_htable(const struct Workspace *w) { return w->vi_htable; }
+
+static double *slot(struct Workspace *w, size_t node, int which)
+{
+    return w->slab + node * w->off[10] + (which == 0 ? 0 : w->off[which - 1]);
+}
+double *workspace_get_drift(struct Workspace *w, size_t n) { return slot(w, n, 0); }
+double *workspace_get_grad_drift(struct Workspace *w, size_t n) { return slot(w, n, 1); }
+double *workspace_get_diff(struct Workspace *w, size_t n) { return slot(w, n, 2); }
+double *workspace_get_grad_diff(struct Workspace *w, size_t n) { return slot(w, n, 3); }
+double *workspace_get_dt(struct Workspace *w, size_t n) { return slot(w, n, 4); }
+double *workspace_get_grad_dt(struct Workspace *w, size_t n) { return slot(w, n, 5); }
+double *workspace_get_prob(struct Workspace *w, size_t n) { return slot(w, n, 6); }
+double *workspace_get_grad_prob(struct Workspace *w, size_t n) { return slot(w, n, 7); }
+double *workspace_get_grad_stage(struct Workspace *w, size_t n) { return slot(w, n, 8); }
+double *workspace_get_control_size_extra(struct Workspace *w, size_t n) { return slot(w, n, 9); }
+double *workspace_get_u(struct Workspace *w, size_t n) { return slot(w, n, 10); }
+double *workspace_get_costs(struct Workspace *w, size_t n) { return w->costs + n * (2 * w->dx + 1); }
+int *workspace_get_absorbed(struct Workspace *w, size_t n) { return w->absorbed + n; }
+size_t *workspace_get_ind_to_serialize(struct Workspace *w) { return w->ind_to_serialize; }
+char **workspace_get_saved_keys(struct Workspace *w) { return w->keys; }
+
+struct c3sc_hip_ctx *workspace_get_hip_ctx(struct Workspace *w)
+{
+    if (w->hip == NULL) {
+        const char *dev = getenv("C3SC_HIP_DEVICE");
+        int rc = c3sc_hip_ctx_create(dev ? atoi(dev) : 0, &w->hip);
+        if (rc != C3SC_OK) { /* no CPU fallback: the reference style is to print and exit(1) */
+            fprintf(stderr, "c3sc: cannot create the MI355X context (code %d); the Bellman backup has no CPU fallback\n", rc);
+            exit(1);
+        }
+    }
+    return w->hip;
+}

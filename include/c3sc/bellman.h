@@ -1,0 +1,76 @@
+/* bellman.h -- Bellman backup API (mirrors src/bellman.h:48-194 for the value-iteration path).
+ * bellman_vi keeps the callback ABI C3's cross approximation uses (valuefunc.c:615-616) and runs
+ * the fiber on the MI355X through include/c3sc_hip.h. */
+#ifndef C3SC_BELLMAN_H
+#define C3SC_BELLMAN_H
+#include <stddef.h>
+
+#include "boundary.h"
+#include "dynamics.h"
+#include "nodeutil.h"
+#include "util.h"
+#include "valuefunc.h"
+
+double bellmanrhs(size_t dx, size_t du, double stage_cost, const double *stage_grad, double discount,
+                  const double *prob, const double *prob_grad, double dt, const double *dtgrad, const double *cost,
+                  double *grad); /* bellman.c:88-112 */
+
+struct MCAparam;
+struct MCAparam *mca_param_create(size_t dx, size_t du);
+void mca_add_grid_refs(struct MCAparam *, size_t *ngrid, double **xgrid, double hmin, double *hvec); /* bellman.c:171-188 */
+void mca_param_destroy(struct MCAparam *);
+
+struct DPparam;
+struct DPparam *dp_param_create(size_t dx, size_t du, size_t dw, double discount);
+void dp_param_destroy(struct DPparam *);
+void dp_param_add_drift(struct DPparam *, c3sc_dyn_fn, void *);
+void dp_param_add_diff(struct DPparam *, c3sc_dyn_fn, void *);
+void dp_param_add_boundary(struct DPparam *, struct Boundary *);
+void dp_param_add_stagecost(struct DPparam *, int (*)(double, const double *, const double *, double *, double *));
+void dp_param_add_boundcost(struct DPparam *, int (*)(double, const double *, double *));
+void dp_param_add_obscost(struct DPparam *, int (*)(const double *, double *));
+/* new (opt-in): the device functor (include/c3sc_hip.h C3SC_MODEL_*) that restates the callbacks above for the
+ * kernels.  bellman_vi cross-checks it against the host callbacks on the first fiber it runs. */
+void dp_param_set_device_model(struct DPparam *, int model, const double *params, size_t nparams);
+
+struct ControlParams;
+struct ControlParams *control_params_create(size_t dx, size_t dw, struct DPparam *, struct MCAparam *, struct Workspace *,
+                                            struct c3Opt *);
+void control_params_add_time_and_states(struct ControlParams *, double time, size_t N, const double *x);
+int control_params_get_last_res(const struct ControlParams *);
+void control_params_destroy(struct ControlParams *);
+
+double bellman_control(size_t du, const double *u, double *grad_u, void *args); /* bellman.c:367-480 */
+int bellman_optimal(size_t du, double *u, double *val, void *arg);             /* bellman.c:504-543 (BRUTEFORCE) */
+
+struct VIparam;
+struct VIparam *vi_param_create(double convergence);
+void vi_param_destroy(struct VIparam *);
+void vi_param_add_cp(struct VIparam *, struct ControlParams *);
+void vi_param_add_value(struct VIparam *, struct ValueF *);
+size_t vi_param_get_nnode_evals(const struct VIparam *);
+int bellman_vi(size_t N, const double *x, double *out, void *arg); /* bellman.c:1295-1423 */
+
+/* new: many fibers in one launch (what an own cross driver would call per core step); x is F blocks of
+ * N x dx; memo semantics identical to F successive bellman_vi calls */
+int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg);
+
+struct C3Control;
+struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, double *ub, size_t *ngrid,
+                                   double discount); /* bellman.c:1962-1999 */
+void c3control_destroy(struct C3Control *);
+size_t *c3control_get_ngrid(struct C3Control *);
+double **c3control_get_xgrid(struct C3Control *);
+void c3control_set_external_boundary(struct C3Control *, size_t dim, char *type);
+void c3control_add_obstacle(struct C3Control *, double *center, double *widths);
+void c3control_add_drift(struct C3Control *, c3sc_dyn_fn, void *);
+void c3control_add_diff(struct C3Control *, c3sc_dyn_fn, void *);
+void c3control_add_stagecost(struct C3Control *, int (*)(double, const double *, const double *, double *, double *));
+void c3control_add_boundcost(struct C3Control *, int (*)(double, const double *, double *));
+void c3control_add_obscost(struct C3Control *, int (*)(const double *, double *));
+void c3control_set_device_model(struct C3Control *, int model, const double *params, size_t nparams); /* new */
+/* one value-iteration sweep's callback state, as c3control_step_vi builds it (bellman.c:2177-2199); the
+ * cross approximation that consumes it (valuef_interp -> C3) is out of scope, so the caller drives the fibers */
+struct VIparam *c3control_begin_vi(struct C3Control *, struct ValueF *vf, struct c3Opt *opt);
+void c3control_end_vi(struct C3Control *, struct VIparam *, size_t *nevals);
+#endif

@@ -1,0 +1,71 @@
+/* util.h -- ApproxArgs, Workspace (mirrors src/util.h:49-125 for what the Bellman path uses) and the
+ * minimal brute-force optimiser object that stands where C3's c3Opt stands in the reference. */
+#ifndef C3SC_UTIL_H
+#define C3SC_UTIL_H
+#include <stddef.h>
+
+#include "hashgrid.h"
+
+/* C3's enum function_class is reduced to the two classes valuefunc.c:655-670 accepts */
+enum function_class { CONSTELM = 4, LINELM = 5 };
+
+struct ApproxArgs;
+struct ApproxArgs *approx_args_init(void); /* defaults util.c:124-130 */
+void approx_args_free(struct ApproxArgs *);
+void approx_args_set_function_class(struct ApproxArgs *, enum function_class);
+enum function_class approx_args_get_function_class(const struct ApproxArgs *);
+void approx_args_set_cross_tol(struct ApproxArgs *, double);
+double approx_args_get_cross_tol(const struct ApproxArgs *);
+void approx_args_set_round_tol(struct ApproxArgs *, double);
+double approx_args_get_round_tol(const struct ApproxArgs *);
+void approx_args_set_kickrank(struct ApproxArgs *, size_t);
+size_t approx_args_get_kickrank(const struct ApproxArgs *);
+void approx_args_set_maxrank(struct ApproxArgs *, size_t);
+size_t approx_args_get_maxrank(const struct ApproxArgs *);
+void approx_args_set_startrank(struct ApproxArgs *, size_t);
+size_t approx_args_get_startrank(const struct ApproxArgs *);
+void approx_args_set_adapt(struct ApproxArgs *, int);
+int approx_args_get_adapt(const struct ApproxArgs *);
+size_t uniform_stride(size_t N, size_t M); /* util.c:995-1006 */
+
+/* ---- brute-force c3Opt subset (C3 lib_optimization.h names, own implementation) ---- */
+enum c3opt_alg { BFGS = 0, LBFGS = 1, BATCHGRAD = 2, BRUTEFORCE = 3 };
+struct c3Opt;
+struct c3Opt *c3opt_alloc(enum c3opt_alg alg, size_t d); /* only BRUTEFORCE is supported; others abort */
+struct c3Opt *c3opt_copy(struct c3Opt *);
+void c3opt_free(struct c3Opt *);
+void c3opt_set_brute_force_vals(struct c3Opt *, size_t n, double *vals /* n x d */);
+int c3opt_is_bruteforce(const struct c3Opt *);
+void c3opt_add_objective(struct c3Opt *, double (*f)(size_t, const double *, double *, void *), void *arg);
+int c3opt_minimize(struct c3Opt *, double *x, double *val); /* scan in order, strict '<' */
+size_t c3opt_get_nbrute(const struct c3Opt *);
+const double *c3opt_get_brute_vals(const struct c3Opt *);
+size_t c3opt_get_d(const struct c3Opt *);
+
+/* ---- Workspace (util.c:689-964): per-node scratch, key buffers, memo tables, + the device context ---- */
+struct Workspace;
+struct Workspace *workspace_alloc(size_t dx, size_t du, size_t dw, size_t N);
+void workspace_free(struct Workspace *);
+void workspace_reset_vi_htable(struct Workspace *);
+void workspace_increment_vi_iter(struct Workspace *);
+size_t workspace_get_vi_iter(const struct Workspace *);
+struct HTable *workspace_get_vi_htable(const struct Workspace *);
+double *workspace_get_drift(struct Workspace *, size_t node);
+double *workspace_get_grad_drift(struct Workspace *, size_t node);
+double *workspace_get_diff(struct Workspace *, size_t node);
+double *workspace_get_grad_diff(struct Workspace *, size_t node);
+double *workspace_get_dt(struct Workspace *, size_t node);
+double *workspace_get_grad_dt(struct Workspace *, size_t node);
+double *workspace_get_prob(struct Workspace *, size_t node);
+double *workspace_get_grad_prob(struct Workspace *, size_t node);
+double *workspace_get_grad_stage(struct Workspace *, size_t node);
+double *workspace_get_control_size_extra(struct Workspace *, size_t node);
+double *workspace_get_u(struct Workspace *, size_t node);
+double *workspace_get_costs(struct Workspace *, size_t node);
+int *workspace_get_absorbed(struct Workspace *, size_t node);
+size_t *workspace_get_ind_to_serialize(struct Workspace *);
+char **workspace_get_saved_keys(struct Workspace *);
+/* new: the MI355X engine this workspace drives (created on first use; aborts if no GPU) */
+struct c3sc_hip_ctx;
+struct c3sc_hip_ctx *workspace_get_hip_ctx(struct Workspace *);
+#endif

@@ -109,6 +109,17 @@ int c3sc_hip_bellman_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d
 int c3sc_hip_stencil_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, double *d_costs,
                             int32_t *d_absorbed, void *stream);
 
+/* The literal valuef_eval_fiber_ind_nn interface (valuefunc.c:369-371) batched: the caller supplies the
+ * neighbour indices instead of having them derived from the boundary types.
+ *   d_nb_fixed int32 [F][2(d-1)]  (-,+) neighbour index of every fixed dim, dims != k in order
+ *   d_nb_vary  int32 [F][N_k][2]  (-,+) neighbour node of every fiber node
+ * either may be NULL (then derived as in c3sc_hip_stencil_fibers). */
+int c3sc_hip_stencil_fibers_nb(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, const int32_t *d_nb_fixed,
+                               const int32_t *d_nb_vary, double *d_costs, int32_t *d_absorbed, void *stream);
+int c3sc_hip_stencil_fibers_nb_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx,
+                                    const int32_t *h_nb_fixed, const int32_t *h_nb_vary, double *h_costs,
+                                    int32_t *h_absorbed);
+
 /* Convenience for host callers (the C facade's bellman_vi): host buffers, synchronous. */
 int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, double *h_out,
                                  int32_t *h_uidx, int32_t *h_absorbed);

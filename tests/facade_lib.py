@@ -1,0 +1,133 @@
+"""ctypes view of c3sc_amd/host/libc3sc.so -- the C host side that keeps the reference's API names
+(include/c3sc/*.h).  Used by tests only; a C program links the library directly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "c3sc_amd", "host", "libc3sc.so")
+_L = None
+
+c_double_p = C.POINTER(C.c_double)
+c_size_p = C.POINTER(C.c_size_t)
+DYN_FN = C.CFUNCTYPE(C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, C.c_void_p)
+STAGE_FN = C.CFUNCTYPE(C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p)
+BOUND_FN = C.CFUNCTYPE(C.c_int, C.c_double, c_double_p, c_double_p)
+OBS_FN = C.CFUNCTYPE(C.c_int, c_double_p, c_double_p)
+
+
+def lib():
+    global _L
+    if _L is None:
+        import torch  # noqa: F401  (same reason as c3sc_amd.engine: one HIP runtime per process)
+
+        L = C.CDLL(PATH)
+        for n in ("boundary_alloc", "drift_alloc", "diff_alloc", "htable_create", "workspace_alloc", "mca_param_create",
+                  "dp_param_create", "control_params_create", "vi_param_create", "c3control_create", "c3opt_alloc",
+                  "valuef_create_nodal", "valuef_copy", "c3control_begin_vi", "approx_args_init"):
+            getattr(L, n).restype = C.c_void_p
+        L.size_t_a_to_char.restype = C.c_char_p
+        L.c3sc_hashchar.restype = C.c_size_t
+        L.c3sc_hashchar.argtypes = [C.c_size_t, C.c_char_p]
+        L.bellmanrhs.restype = C.c_double
+        L.bellmanrhs.argtypes = [C.c_size_t, C.c_size_t, C.c_double, c_double_p, C.c_double, c_double_p, c_double_p,
+                                 C.c_double, c_double_p, c_double_p, c_double_p]
+        L.transition_assemble.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_double] + [c_double_p] * 10
+        L.htable_get_element.restype = c_double_p
+        L.c3control_get_xgrid.restype = C.POINTER(c_double_p)
+        L.valuef_eval_ind.restype = C.c_double
+        L.vi_param_get_nnode_evals.restype = C.c_size_t
+        L.uniform_stride.restype = C.c_size_t
+        L.approx_args_get_cross_tol.restype = C.c_double
+        L.approx_args_get_maxrank.restype = C.c_size_t
+        _L = L
+    return _L
+
+
+def dp(a):
+    return a.ctypes.data_as(c_double_p) if a is not None else None
+
+
+def sp(a):
+    return a.ctypes.data_as(c_size_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def usz(a):
+    return np.ascontiguousarray(a, dtype=np.uintp)
+
+
+def ptrs(arrs):
+    arr = (c_double_p * len(arrs))(*[dp(a) for a in arrs])
+    arr._keep = arrs
+    return arr
+
+
+class Control:
+    """c3control_create + problem wiring from a workloads.Workload (device model + optional host callbacks)."""
+
+    def __init__(self, w, callbacks=None):
+        L = lib()
+        self.L, self.w = L, w
+        self._lb, self._ub, self._ng = f64(w.lb), f64(w.ub), usz(w.ngrid)
+        self.h = C.c_void_p(L.c3control_create(C.c_size_t(w.dx), C.c_size_t(w.du), C.c_size_t(w.dw), dp(self._lb), dp(self._ub),
+                                               sp(self._ng), C.c_double(w.discount)))
+        for m, name in enumerate(w.bc_names()):
+            L.c3control_set_external_boundary(self.h, C.c_size_t(m), name.encode())
+        for cen, wid in w.obstacles:
+            L.c3control_add_obstacle(self.h, dp(f64(cen)), dp(f64(wid)))
+        prm = f64(list(w.params) if len(w.params) else [0.0])
+        L.c3control_set_device_model(self.h, C.c_int(w.model), dp(prm), C.c_size_t(len(w.params)))
+        self._cb = callbacks
+        if callbacks is not None:
+            b, s, st, bd, ob = callbacks
+            L.c3control_add_drift(self.h, b, None)
+            L.c3control_add_diff(self.h, s, None)
+            L.c3control_add_stagecost(self.h, st)
+            L.c3control_add_boundcost(self.h, bd)
+            L.c3control_add_obscost(self.h, ob)
+        self.opt = C.c_void_p(L.c3opt_alloc(C.c_int(3), C.c_size_t(w.du)))
+        cands = f64(w.cands)
+        L.c3opt_set_brute_force_vals(self.opt, C.c_size_t(cands.shape[0]), dp(cands))
+
+    def xgrid(self):
+        pp = self.L.c3control_get_xgrid(self.h)
+        return [np.ctypeslib.as_array(pp[m], shape=(self.w.ngrid[m],)).copy() for m in range(self.w.dx)]
+
+    def valuef(self, cores):
+        cs = [f64(c) for c in cores]
+        return C.c_void_p(self.L.valuef_create_nodal(C.c_size_t(self.w.dx), sp(usz(self.w.ngrid)), sp(usz(self.w.ranks)), ptrs(cs)))
+
+    def begin_vi(self, vf):
+        return C.c_void_p(self.L.c3control_begin_vi(self.h, vf, self.opt))
+
+    def end_vi(self, vi):
+        n = C.c_size_t(0)
+        self.L.c3control_end_vi(self.h, vi, C.byref(n))
+        return n.value
+
+    def bellman_vi(self, vi, x):
+        x = f64(x)
+        out = np.zeros(x.shape[0])
+        rc = self.L.bellman_vi(C.c_size_t(x.shape[0]), dp(x), dp(out), vi)
+        assert rc == 0
+        return out
+
+    def bellman_vi_batch(self, vi, x):
+        x = f64(x)  # (F, N, dx)
+        F, N = x.shape[0], x.shape[1]
+        out = np.zeros((F, N))
+        rc = self.L.bellman_vi_batch(C.c_size_t(F), C.c_size_t(N), dp(x), dp(out), vi)
+        assert rc == 0
+        return out
+
+    def nnode_evals(self, vi):
+        return self.L.vi_param_get_nnode_evals(vi)
+
+    def close(self):
+        self.L.c3opt_free(self.opt)
+        self.L.c3control_destroy(self.h)

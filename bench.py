@@ -69,6 +69,7 @@ def main():
     import torch.distributed as dist
 
     from c3sc_amd import workloads as wl
+    from c3sc_amd.distributed import allgather_cores, pack_cores, padded_len
     from c3sc_amd.engine import BellmanEngine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,12 +100,9 @@ def main():
     out_t = [torch.empty((F, w.ngrid[k]), dtype=torch.float64, device=dev) for k in range(d)]
     # FT cores on the device in the reference layout (what a cross-approximation step produces);
     # each rank "owns" a 1/world slice of the flattened cores and all-gathers the rest per sweep
-    flat = np.concatenate([c.reshape(-1) for c in cores])
-    pad = (-len(flat)) % world
-    flat_t = torch.from_numpy(np.concatenate([flat, np.zeros(pad)])).to(dev)
+    flat, offs = pack_cores(cores)
+    flat_t = torch.from_numpy(np.concatenate([flat, np.zeros(padded_len(len(flat), world) - len(flat))])).to(dev)
     shard = flat_t.view(world, -1)[rank].clone()
-    gathered = torch.empty_like(flat_t)
-    offs = np.cumsum([0] + [c.size for c in cores])
 
     def core_views(buf):
         return [buf[offs[m]:offs[m + 1]] for m in range(d)]
@@ -122,11 +120,8 @@ def main():
                 e1.record(stream)
                 ev.append((k, e0, e1))
         # end of sweep: exchange the updated cores and re-stage them for the next sweep
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, shard)
-            eng.upload_value_device(w.ranks, core_views(gathered), sp)
-        else:
-            eng.upload_value_device(w.ranks, core_views(flat_t), sp)
+        gathered = allgather_cores(shard, world) if world > 1 else flat_t
+        eng.upload_value_device(w.ranks, core_views(gathered), sp)
 
     def fence():
         torch.cuda.synchronize(dev)

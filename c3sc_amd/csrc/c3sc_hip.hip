@@ -145,13 +145,14 @@ static int upload_static(c3sc_hip_ctx *c)
     return C3SC_OK;
 }
 
-static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, int variant)
+static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, int variant, int k)
 {
     const KernelEntry *best = nullptr;
     for (const auto &e : kernel_registry()) {
         if (e.model != model || e.d != d || e.rp < rank_needed || e.max_n < N) continue;
+        if (e.k >= 0 && e.k != k) continue;
         if (variant != C3SC_VARIANT_AUTO && e.variant != variant) continue;
-        if (!best || e.rp < best->rp || (e.rp == best->rp && e.variant > best->variant) ||
+        if (!best || e.rp < best->rp || (e.rp == best->rp && e.variant < best->variant) ||
             (e.rp == best->rp && e.variant == best->variant && e.npl < best->npl))
             best = &e;
     }
@@ -411,7 +412,7 @@ int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_i
     if (rc != C3SC_OK) return rc;
     if (F == 0) return C3SC_OK;
     if (!d_idx || !d_out) return fail(c, C3SC_ERR_ARG, "bellman_fibers: null buffer");
-    const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant);
+    const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant, k);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, (hipStream_t)stream};
@@ -433,7 +434,7 @@ int c3sc_hip_stencil_fibers_nb(c3sc_hip_ctx *c, int k, size_t F, const int32_t *
     if (rc != C3SC_OK) return rc;
     if (F == 0) return C3SC_OK;
     if (!d_idx || !d_costs) return fail(c, C3SC_ERR_ARG, "stencil_fibers: null buffer");
-    const KernelEntry *e = find_kernel(0, c->d, c->rp, A.N, C3SC_VARIANT_AUTO);
+    const KernelEntry *e = find_kernel(0, c->d, c->rp, A.N, C3SC_VARIANT_AUTO, k);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "stencil_fibers: no kernel instantiation for (dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, d_nb_fixed, d_nb_vary, (hipStream_t)stream};

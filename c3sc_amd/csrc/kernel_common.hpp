@@ -124,36 +124,33 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         double u[DU];
 #pragma unroll
         for (int i = 0; i < DU; i++) u[i] = ro[A.cands_off + c * DU + i];
-        double b[D], s[D], p[2 * D];
+        double b[D], s[D];
         Model::drift(A.prm, nd, x, u, b);
         Model::sigma(A.prm, x, u, s);
         const double stage = Model::stage(A.prm, x, u);
-        double Q = 0.0;
+        // nodeutil.c:289-309 fused with the ddot of bellman.c:95: the rates are accumulated un-normalised,
+        // Q = sum p, PV = sum p_i V_i; the reference divides every p_i by Q first (nodeutil.c:397-402) --
+        // same value up to rounding (<= a few ulp), without keeping the 2d rates in registers.
+        double Q = 0.0, PV = 0.0;
 #pragma unroll
-        for (int m = 0; m < D; m++) { // nodeutil.c:289-309
+        for (int m = 0; m < D; m++) {
             const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
             double pm = half, pp = half;
             if (b[m] < -1e-14) pm -= A.t[2 * m] * b[m];
             else if (b[m] > 1e-14) pp += A.t[2 * m] * b[m];
-            p[2 * m] = pm;
-            p[2 * m + 1] = pp;
             Q += pm;
             Q += pp;
+            PV = fma(pm, V[2 * m], PV);
+            PV = fma(pp, V[2 * m + 1], PV);
         }
         if (Q < 1e-14) { // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
             st |= C3SC_STATUS_STATIONARY;
             continue;
         }
         const double inv = 1.0 / Q;
-        const double dt = A.h2 * inv; // nodeutil.c:369
-        double pself = 1.0, ctg = 0.0;
-#pragma unroll
-        for (int i = 0; i < 2 * D; i++) { // nodeutil.c:397-402 + the ddot of bellman.c:95
-            const double pi = p[i] * inv;
-            pself -= pi;
-            ctg = fma(pi, V[i], ctg);
-        }
-        ctg = fma(pself, V[2 * D], ctg);
+        const double dt = A.h2 * inv;              // nodeutil.c:369
+        const double pself = fma(-Q, inv, 1.0);    // 1 - sum_i p_i/Q: rounding residue, as in the reference
+        const double ctg = fma(pself, V[2 * D], PV * inv);
         const double ebt = (A.discount == 0.0) ? 1.0 : exp(-A.discount * dt); // bellman.c:94
         const double val = dt * stage + ebt * ctg;                            // bellman.c:97
         if (ui < 0 || val < best) {

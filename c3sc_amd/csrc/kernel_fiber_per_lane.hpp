@@ -1,0 +1,378 @@
+// kernel_fiber_per_lane.hpp -- "one fiber per lane, node loop" Bellman kernel (gfx950, wave64).
+//
+// Why: in the fiber-per-wave kernel a wavefront owns ONE fiber, so 23 of 64 lanes idle at N = 41, the
+// per-fiber prefix/suffix work runs on 30 lanes, and every node drags its r-vector through d-2 r x r
+// cores.  Here a lane owns a whole fiber and the wavefront walks the nodes j = 0..N-1 together:
+//   * the varying core G_k[j] is THE wave-uniform operand (same j for all 64 fibers) -> scalar loads,
+//     v_fma_f64 with an SGPR matrix element, every lane busy for any N;
+//   * everything that is constant along a fiber is folded ONCE into 2(d-1)+2 short vectors held in
+//     registers:  L = G_0[i_0]..G_{k-1}[i_{k-1}],  R = G_{k+1}[i_{k+1}]..G_{d-1}[i_{d-1}],
+//       w_m^{-+} = L_{m-1} G_m[i_m -+ 1] G_{m+1}[i_{m+1}] .. G_{k-1}[i_{k-1}]      (m < k, length r_k)
+//       z_m^{-+} = G_{k+1}[i_{k+1}] .. G_{m-1}[i_{m-1}] G_m[i_m -+ 1] R_{m+1}      (m > k, length r_{k+1})
+//     so that per node only  c = G_k[j] R,  a = L G_k[j]  (2 r^2 FMAs) and 2d-1 length-r dots remain:
+//       V(j) = L.c,   V_m^{-+}(j) = w_m^{-+}.c  (m < k),   V_m^{-+}(j) = a.z_m^{-+}  (m > k).
+//     Same numbers as valuef_eval_fiber_ind_nn (src/valuefunc.c:369-585), ~640 instead of ~1500 flop/node
+//     at d = 7, r = 10;
+//   * the per-fiber folding needs a DIFFERENT matrix per lane (G_m[i_m] with the lane's own i_m): each
+//     fixed core is staged once per 256-fiber tile in LDS (odd node stride -> spread banks) and every
+//     lane reads its own matrix from there, one LDS read feeding up to 4 FMAs (4 vectors per pass);
+//   * the dim-k neighbours are the previous / next node of the same lane: the control minimisation of
+//     node j-1 is delayed until V(j) is known (register pipeline, no LDS, handles reflect / periodic
+//     ends with two saved values);
+//   * 256-thread workgroups, one per CU, ~400 VGPRs (the vectors live in registers), grid-stride over
+//     256-fiber tiles.
+//
+// Template parameter K = dim_vary is a compile-time constant so that all vector arrays are fully
+// unrolled into registers.
+#pragma once
+#include "kernel_common.hpp"
+
+namespace c3sc {
+
+constexpr int FPL_THREADS = 256;
+#ifndef FPL_NV
+#define FPL_NV 2
+#endif
+
+__host__ __device__ constexpr int fpl_lds_stride(int elems) { return elems | 1; } // odd #doubles per node
+
+// out[b] = sum_a v[a] G[a + b*RP]   (row vector times the lane's own matrix in LDS), NV vectors per pass
+template <int RP, int NV>
+__device__ inline void vecmat_lds(const double *G, double (&v)[NV][RP])
+{
+    double t[NV][RP];
+#pragma unroll
+    for (int b = 0; b < RP; b++) {
+#pragma unroll
+        for (int s = 0; s < NV; s++) t[s][b] = 0.0;
+#pragma unroll
+        for (int a = 0; a < RP; a++) {
+            const double g = G[a + b * RP];
+#pragma unroll
+            for (int s = 0; s < NV; s++) t[s][b] = fma(v[s][a], g, t[s][b]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int b = 0; b < RP; b++) v[s][b] = t[s][b];
+}
+
+// out[a] = sum_b G[a + b*RP] v[b]   (matrix times column vector)
+template <int RP, int NV>
+__device__ inline void matvec_lds(const double *G, double (&v)[NV][RP])
+{
+    double t[NV][RP];
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int a = 0; a < RP; a++) t[s][a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < RP; b++)
+#pragma unroll
+        for (int a = 0; a < RP; a++) {
+            const double g = G[a + b * RP];
+#pragma unroll
+            for (int s = 0; s < NV; s++) t[s][a] = fma(g, v[s][b], t[s][a]);
+        }
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int a = 0; a < RP; a++) v[s][a] = t[s][a];
+}
+
+// apply `op` to W[FIRST .. FIRST+COUNT) in passes of at most 4 vectors (compile-time recursion)
+template <int RP, int NW, int FIRST, int COUNT, bool ROWVEC>
+__device__ inline void apply_core(const double *G, double (&W)[NW][RP])
+{
+    if constexpr (COUNT > 0) {
+        constexpr int NV = COUNT >= FPL_NV ? FPL_NV : COUNT;
+        double tmp[NV][RP];
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) tmp[s][a] = W[FIRST + s][a];
+        if constexpr (ROWVEC) vecmat_lds<RP, NV>(G, tmp);
+        else matvec_lds<RP, NV>(G, tmp);
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) W[FIRST + s][a] = tmp[s][a];
+        apply_core<RP, NW, FIRST + NV, COUNT - NV, ROWVEC>(G, W);
+    }
+}
+
+template <int RP>
+__device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < RP; i++) s = fma(a[i], b[i], s);
+    return s;
+}
+
+// cooperative global -> LDS copy of one core with the padded node stride
+__device__ inline void stage_core(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride)
+{
+    const int total = n_nodes * elems;
+    for (int e = threadIdx.x; e < total; e += FPL_THREADS) {
+        const int j = e / elems, w = e - j * elems;
+        sK[j * stride + w] = src[e];
+    }
+}
+
+template <class Model, int RP, int K>
+__global__ void __launch_bounds__(FPL_THREADS, 1)
+    k_fiber_per_lane(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
+                     int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
+{
+    constexpr int D = Model::D;
+    constexpr int S = 2 * D + 1;
+    constexpr int NL = 2 * K;           // left neighbour vectors  w_m^{-+}, m = 0..K-1  (index 2m + s)
+    constexpr int NR = 2 * (D - 1 - K); // right neighbour vectors z_m^{-+}, m = K+1..D-1 (index 2(m-K-1) + s)
+    constexpr int NLa = NL > 0 ? NL : 1, NRa = NR > 0 ? NR : 1;
+    extern __shared__ double sK[];
+    const int N = A.N;
+    unsigned st = 0;
+    const long ntiles = (A.F + FPL_THREADS - 1) / FPL_THREADS;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long f_raw = tile * FPL_THREADS + threadIdx.x;
+        const bool live = f_raw < A.F;
+        const long f = live ? f_raw : A.F - 1;
+
+        // ---- the lane's fiber: fixed indices, neighbour indices per boundary type (nodeutil.c:513-566)
+        int fi[D], nbm[D], nbp[D];
+        bool fiber_abs = false;
+        double x[D];
+#pragma unroll
+        for (int m = 0; m < D; m++) {
+            fi[m] = (m == K) ? 0 : idx[f * D + m];
+            const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], nbm[m], nbp[m]);
+            if (m != K) fiber_abs = fiber_abs || face;
+            x[m] = ro[A.xg_off[m] + fi[m]];
+        }
+
+        double L[RP], R[RP], WL[NLa][RP], WR[NRa][RP];
+#pragma unroll
+        for (int a = 0; a < RP; a++) { L[a] = (a == 0) ? 1.0 : 0.0; R[a] = (a == 0) ? 1.0 : 0.0; }
+
+        // ---- prefix side: fold cores 0..K-1 into L and the left neighbour vectors
+        if constexpr (K > 0) {
+            { // core 0 is a 1 x r row per node
+                constexpr int str = fpl_lds_stride(RP);
+                __syncthreads();
+                stage_core(sK, ro + A.core_off[0], A.ngrid[0], RP, str);
+                __syncthreads();
+#pragma unroll
+                for (int b = 0; b < RP; b++) {
+                    L[b] = sK[fi[0] * str + b];
+                    WL[0][b] = sK[nbm[0] * str + b];
+                    WL[1][b] = sK[nbp[0] * str + b];
+                }
+            }
+            auto left_step = [&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int str = fpl_lds_stride(RP * RP);
+                __syncthreads();
+                stage_core(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str);
+                __syncthreads();
+                // new pair from the running prefix, then push everything through G_m[i_m]
+                double q[2][RP];
+#pragma unroll
+                for (int a = 0; a < RP; a++) { q[0][a] = L[a]; q[1][a] = L[a]; }
+                {
+                    double t0[1][RP], t1[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { t0[0][a] = L[a]; t1[0][a] = L[a]; }
+                    vecmat_lds<RP, 1>(sK + nbm[m] * str, t0);
+                    vecmat_lds<RP, 1>(sK + nbp[m] * str, t1);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { q[0][a] = t0[0][a]; q[1][a] = t1[0][a]; }
+                }
+                const double *G = sK + fi[m] * str;
+                apply_core<RP, NLa, 0, 2 * m, true>(G, WL);
+                {
+                    double t[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) t[0][a] = L[a];
+                    vecmat_lds<RP, 1>(G, t);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) L[a] = t[0][a];
+                }
+#pragma unroll
+                for (int a = 0; a < RP; a++) { WL[2 * m][a] = q[0][a]; WL[2 * m + 1][a] = q[1][a]; }
+            };
+            // compile-time loop m = 1 .. K-1
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (left_step(std::integral_constant<int, Ms + 1>{}), ...); }
+            (std::make_integer_sequence<int, (K > 1 ? K - 1 : 0)>{});
+        }
+
+        // ---- suffix side: fold cores D-1..K+1 into R and the right neighbour vectors
+        if constexpr (K < D - 1) {
+            { // core D-1 is an r x 1 column per node
+                constexpr int str = fpl_lds_stride(RP);
+                __syncthreads();
+                stage_core(sK, ro + A.core_off[D - 1], A.ngrid[D - 1], RP, str);
+                __syncthreads();
+                constexpr int o = 2 * (D - 1 - K - 1);
+#pragma unroll
+                for (int a = 0; a < RP; a++) {
+                    R[a] = sK[fi[D - 1] * str + a];
+                    WR[o][a] = sK[nbm[D - 1] * str + a];
+                    WR[o + 1][a] = sK[nbp[D - 1] * str + a];
+                }
+            }
+            auto right_step = [&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value; // D-2 down to K+1
+                constexpr int str = fpl_lds_stride(RP * RP);
+                constexpr int o = 2 * (m - K - 1);     // slot of this dim's pair; later dims sit above it
+                __syncthreads();
+                stage_core(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str);
+                __syncthreads();
+                double t0[1][RP], t1[1][RP];
+#pragma unroll
+                for (int a = 0; a < RP; a++) { t0[0][a] = R[a]; t1[0][a] = R[a]; }
+                matvec_lds<RP, 1>(sK + nbm[m] * str, t0);
+                matvec_lds<RP, 1>(sK + nbp[m] * str, t1);
+                const double *G = sK + fi[m] * str;
+                apply_core<RP, NRa, o + 2, NR - (o + 2), false>(G, WR);
+                {
+                    double t[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) t[0][a] = R[a];
+                    matvec_lds<RP, 1>(G, t);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) R[a] = t[0][a];
+                }
+#pragma unroll
+                for (int a = 0; a < RP; a++) { WR[o][a] = t0[0][a]; WR[o + 1][a] = t1[0][a]; }
+            };
+            // compile-time loop m = D-2 .. K+1
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (right_step(std::integral_constant<int, D - 2 - Ms>{}), ...); }
+            (std::make_integer_sequence<int, (D - 2 - K > 0 ? D - 2 - K : 0)>{});
+        }
+
+        // ---- node loop: FT values of node j, then (delayed by one node) the Bellman backup of node j-1
+        const int bck = A.bctype[K];
+        const double *Gk = ro + A.core_off[K];
+        // value of one node only (needed ahead of time for the periodic wrap: lo(0) = N-2)
+        auto node_value = [&](int j) __attribute__((always_inline)) -> double {
+            if constexpr (K == 0) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b < RP; b++) v = fma(Gk[(size_t)j * RP + b], R[b], v);
+                return v;
+            } else if constexpr (K == D - 1) {
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < RP; a++) v = fma(L[a], Gk[(size_t)j * RP + a], v);
+                return v;
+            } else {
+                const double *G = Gk + (size_t)j * RP * RP;
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < RP; a++) {
+                    double ca = 0.0;
+#pragma unroll
+                    for (int b = 0; b < RP; b++) ca = fma(G[a + b * RP], R[b], ca);
+                    v = fma(L[a], ca, v);
+                }
+                return v;
+            }
+        };
+        double v_wrap_lo = 0.0; // v[N-2], the left neighbour of node 0 under a periodic boundary (quirk Q8)
+        if (bck == C3SC_PERIODIC) v_wrap_lo = node_value(N - 2);
+        double v_one = 0.0;     // v[1], the right neighbour of node N-1 under a periodic boundary
+
+        double Vp[S];           // stencil of the previous node, waiting for its right neighbour
+        double v_pp = 0.0, v_p = 0.0; // v[j-2], v[j-1]
+#pragma unroll
+        for (int s = 0; s < S; s++) Vp[s] = 0.0;
+
+        for (int j = 0; j <= N; j++) {
+            double V[S];
+            double vj = 0.0;
+            if (j < N) {
+                if constexpr (K == 0) {
+                    double a[RP];
+                    double v = 0.0;
+#pragma unroll
+                    for (int b = 0; b < RP; b++) { a[b] = Gk[(size_t)j * RP + b]; v = fma(a[b], R[b], v); }
+                    vj = v;
+#pragma unroll
+                    for (int i = 0; i < NR; i++) V[2 * (K + 1) + i] = dot_reg<RP>(a, WR[i]);
+                } else if constexpr (K == D - 1) {
+                    double c[RP];
+                    double v = 0.0;
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { c[a] = Gk[(size_t)j * RP + a]; v = fma(L[a], c[a], v); }
+                    vj = v;
+#pragma unroll
+                    for (int i = 0; i < NL; i++) V[i] = dot_reg<RP>(WL[i], c);
+                } else {
+                    const double *G = Gk + (size_t)j * RP * RP;
+                    double c[RP], a[RP];
+#pragma unroll
+                    for (int i = 0; i < RP; i++) c[i] = 0.0;
+#pragma unroll
+                    for (int b = 0; b < RP; b++) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < RP; i++) {
+                            const double g = G[i + b * RP];
+                            c[i] = fma(g, R[b], c[i]);
+                            s = fma(L[i], g, s);
+                        }
+                        a[b] = s;
+                    }
+                    vj = dot_reg<RP>(L, c);
+#pragma unroll
+                    for (int i = 0; i < NL; i++) V[i] = dot_reg<RP>(WL[i], c);
+#pragma unroll
+                    for (int i = 0; i < NR; i++) V[2 * (K + 1) + i] = dot_reg<RP>(a, WR[i]);
+                }
+                V[2 * D] = vj;
+                V[2 * K] = 0.0;
+                V[2 * K + 1] = 0.0;
+                if (j == 1) v_one = vj;
+            }
+            if (j >= 1) { // node j-1 now knows both neighbours along dim K (nodeutil.c:570-624)
+                const int jn = j - 1;
+                double vlo = v_pp, vhi = vj;
+                if (jn == 0) {
+                    vlo = (bck == C3SC_PERIODIC) ? v_wrap_lo : v_p;
+                    vhi = (bck == C3SC_ABSORB) ? v_p : vj;
+                }
+                if (jn == N - 1) {
+                    vlo = (bck == C3SC_ABSORB) ? v_p : v_pp;
+                    vhi = (bck == C3SC_PERIODIC) ? v_one : v_p;
+                }
+                Vp[2 * K] = vlo;
+                Vp[2 * K + 1] = vhi;
+                // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
+                x[K] = ro[A.xg_off[K] + jn];
+                int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
+                if (fiber_abs) ab = 1;
+                int lo, hi;
+                ab = vary_neighbors(jn, N, bck, ab, lo, hi);
+                int ui;
+                const double val = node_backup<Model>(A, ro, x, Vp, ab, ui, st);
+                if (live) {
+                    outv[(size_t)f * N + jn] = val;
+                    if (uidx) uidx[(size_t)f * N + jn] = ui;
+                    if (absorbed) absorbed[(size_t)f * N + jn] = ab;
+                }
+            }
+            if (j < N) {
+#pragma unroll
+                for (int s = 0; s < S; s++) Vp[s] = V[s];
+                v_pp = v_p;
+                v_p = vj;
+            }
+        }
+    }
+    if (st) atomicOr(A.status, st);
+}
+
+} // namespace c3sc

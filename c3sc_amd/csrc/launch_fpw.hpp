@@ -45,12 +45,12 @@ hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
 // MODEL may contain commas/angle brackets, hence the variadic tail
 #define C3SC_REG_FPW(MODEL_ID, RP, NPL, ...)                                                                 \
     static Registrar C3SC_CAT(reg_fpw_, __COUNTER__)(KernelEntry{                                            \
-        MODEL_ID, __VA_ARGS__::D, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL,                            \
+        MODEL_ID, __VA_ARGS__::D, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL, -1,                          \
         &launch_fpw<__VA_ARGS__, RP, NPL, false>, "k_fiber_per_wave<" #__VA_ARGS__ "," #RP "," #NPL ">"});
 
 #define C3SC_REG_STENCIL(DIM, RP, NPL)                                                                       \
     static Registrar C3SC_CAT(reg_st_, __COUNTER__)(KernelEntry{                                             \
-        0, DIM, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL, &launch_fpw<NoModel<DIM>, RP, NPL, true>,    \
+        0, DIM, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL, -1, &launch_fpw<NoModel<DIM>, RP, NPL, true>,    \
         "k_fiber_per_wave<stencil," #DIM "," #RP "," #NPL ">"});
 
 } // namespace c3sc

@@ -28,6 +28,7 @@ struct KernelEntry {
     int npl;     // nodes per lane (fiber-per-wave) ; 0 = any
     int variant; // C3SC_VARIANT_*
     int max_n;   // largest N_k this instantiation handles
+    int k;       // dim_vary this instantiation is compiled for, -1 = any
     launch_fn fn;
     const char *name;
 };

@@ -12,11 +12,13 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-12
 
 
-def _engine(w, cores):
+def _engine(w, cores, variant=0):
     from c3sc_amd.engine import BellmanEngine
 
     eng = BellmanEngine(0)
     eng.configure(w, cores)
+    if variant:
+        eng.set_variant(variant)
     return eng
 
 
@@ -59,6 +61,29 @@ def test_bellman_fibers_vs_oracle(oracle, name, kw):
         idx[1, :] = np.array(w.ngrid) - 1
         idx[:, k] = 0
         _check(eng, P, w, k, idx)
+
+
+FPL = [("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)), ("car7d", dict(ngrid=(11, 12, 9, 13, 10, 11, 12), rank=10))]
+
+
+@pytest.mark.parametrize("name,kw", FPL, ids=[f"{n}-r{k['rank']}" for n, k in FPL])
+def test_fiber_per_lane_kernel_vs_oracle(oracle, name, kw):
+    """The fiber-per-lane kernels (one per varying dimension) against the oracle, incl. ragged tiles
+    (F not a multiple of 256), boundary faces and the periodic wrap."""
+    from c3sc_amd.engine import VARIANT_FIBER_PER_LANE
+
+    w = wl.WORKLOADS[name]().scaled(**kw)
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    eng = _engine(w, cores, VARIANT_FIBER_PER_LANE)
+    for k in range(w.dx):
+        idx = wl.synth_fibers(w, k, 300)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        idx[2, :] = 1
+        idx[:, k] = 0
+        _check(eng, P, w, k, idx)
+        assert "fiber_per_lane" in eng.last_kernel()
 
 
 @pytest.mark.parametrize("name,kw", SMALL[:5], ids=[f"{n}-{i}" for i, (n, k) in enumerate(SMALL[:5])])

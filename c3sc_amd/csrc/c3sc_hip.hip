@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -99,7 +100,7 @@ struct c3sc_hip_ctx {
     size_t static_doubles = 0; // size of the static section the arena was laid out with
     bool static_dirty = true;
     long core_off[MAXD] = {0};
-    int obs_off = 0, cands_off = 0;
+    int obs_off = 0, cands_off = 0, tab_off[4] = {0, 0, 0, 0}, cfeat_off = 0;
     unsigned *d_status = nullptr;
     int variant = C3SC_VARIANT_AUTO;
     const char *last_kernel = "";
@@ -124,6 +125,25 @@ static int fail(c3sc_hip_ctx *ctx, int code, const char *msg)
     return code;
 }
 
+// Host companions of the device models (models.hpp): the univariate functions of a grid coordinate and of
+// a control candidate are evaluated HERE with libm, exactly as the reference's callbacks would
+// (dubinscar.c:48-49, scar.c:65-67), and handed to the kernels as tables.
+static int model_ntab(int model) { return model == C3SC_MODEL_DUBINS3D || model == C3SC_MODEL_SCAR4D ? 2 : (model == C3SC_MODEL_CAR7D ? 3 : 0); }
+static int model_tab_dim(int model, int t) { return (model == C3SC_MODEL_CAR7D && t == 2) ? 5 : 2; }
+static double model_table_value(int model, int t, double xv)
+{
+    (void)model;
+    if (t == 0) return cos(xv);
+    if (t == 1) return sin(xv);
+    return tan(xv);
+}
+static int model_ncf(int model) { return model == C3SC_MODEL_SCAR4D ? 1 : 0; }
+static double model_cand_feature(int model, int q, const double *u)
+{
+    (void)model; (void)q;
+    return tan(u[0]); /* scar.c:67 */
+}
+
 static size_t static_layout(c3sc_hip_ctx *c)
 { // offsets of the static section; returns its size in doubles (rounded to 16)
     size_t off = c->xgrid_flat.size();
@@ -131,6 +151,15 @@ static size_t static_layout(c3sc_hip_ctx *c)
     off += c->obs.size();
     c->cands_off = (int)off;
     off += c->cands.size();
+    for (int t = 0; t < 4; t++) c->tab_off[t] = 0;
+    const int nt = model_ntab(c->model);
+    for (int t = 0; t < nt; t++) {
+        const int dim = model_tab_dim(c->model, t);
+        c->tab_off[t] = (int)off;
+        off += (dim < c->d) ? (size_t)c->ngrid[dim] : 0;
+    }
+    c->cfeat_off = (int)off;
+    off += (size_t)model_ncf(c->model) * c->ncand;
     return (off + 15) & ~(size_t)15;
 }
 
@@ -140,6 +169,16 @@ static int upload_static(c3sc_hip_ctx *c)
     std::copy(c->xgrid_flat.begin(), c->xgrid_flat.end(), st.begin());
     std::copy(c->obs.begin(), c->obs.end(), st.begin() + c->obs_off);
     std::copy(c->cands.begin(), c->cands.end(), st.begin() + c->cands_off);
+    const int nt = model_ntab(c->model);
+    for (int t = 0; t < nt; t++) {
+        const int dim = model_tab_dim(c->model, t);
+        if (dim >= c->d) continue;
+        const double *g = c->xgrid_flat.data() + c->xg_off_rel[dim];
+        for (int i = 0; i < c->ngrid[dim]; i++) st[c->tab_off[t] + i] = model_table_value(c->model, t, g[i]);
+    }
+    const int ncf = model_ncf(c->model);
+    for (int q = 0; q < c->ncand * ncf; q++)
+        st[c->cfeat_off + q] = model_cand_feature(c->model, q % ncf, c->cands.data() + (size_t)(q / ncf) * c->du);
     HIPCHK(c, hipMemcpy(c->arena, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
     c->static_dirty = false;
     return C3SC_OK;
@@ -262,6 +301,7 @@ int c3sc_hip_set_model(c3sc_hip_ctx *c, int model, const double *params, int npa
     c->model = model;
     std::memset(c->prm, 0, sizeof(c->prm));
     for (int i = 0; i < nparams; i++) c->prm[i] = params[i];
+    c->static_dirty = true; // model tables live in the static section
     return C3SC_OK;
 }
 
@@ -396,6 +436,8 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
     A.nobs = c->nobs;
     A.obs_off = c->obs_off;
     A.cands_off = c->cands_off;
+    for (int t = 0; t < 4; t++) A.tab_off[t] = c->tab_off[t];
+    A.cfeat_off = c->cfeat_off;
     A.h2 = c->h2;
     A.discount = c->discount;
     for (int i = 0; i < 2 * c->d; i++) A.t[i] = c->t[i];

@@ -23,6 +23,8 @@ struct KArgs {
     int nobs;
     int obs_off; // [nobs][2][d]: lb row then ub row per obstacle
     int cands_off; // [ncand][DU]
+    int tab_off[4]; // model tables (univariate functions of a grid coordinate, host libm)
+    int cfeat_off;  // [ncand][NCF] per-candidate features (host libm)
     double h2, discount;
     double t[2 * MAXD];
     double prm[C3SC_MAX_PARAMS];
@@ -92,16 +94,16 @@ __device__ inline int vary_neighbors(int j, int n, int bc, int ab_in, int &lo, i
 template <int D>
 __device__ inline bool in_obstacle(const KArgs &A, const double *__restrict__ ro, const double (&x)[D])
 {
-    bool any = false;
+    int any = 0;
     for (int o = 0; o < A.nobs; o++) {
         const double *lb = ro + A.obs_off + (size_t)o * 2 * D;
         const double *ub = lb + D;
-        bool inside = true;
+        int outside = 0; // branch-free: the reference's early exit (boundary.c:338-341) only saves time
 #pragma unroll
-        for (int m = 0; m < D; m++) inside = inside && !(x[m] < lb[m] || x[m] > ub[m]);
-        any = any || inside;
+        for (int m = 0; m < D; m++) outside |= (int)(x[m] < lb[m]) | (int)(x[m] > ub[m]);
+        any |= (outside == 0);
     }
-    return any;
+    return any != 0;
 }
 
 // One node of the Bellman operator: bellman_optimal (bellman.c:504-543, BRUTEFORCE branch) over
@@ -111,21 +113,26 @@ __device__ inline bool in_obstacle(const KArgs &A, const double *__restrict__ ro
 // (strict '<'), as the brute-force c3opt is assumed to.
 template <class Model>
 __device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
-                                     const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st)
+                                     const int (&ix)[Model::D], const double (&V)[2 * Model::D + 1], int ab, int &ui,
+                                     unsigned &st)
 {
     constexpr int D = Model::D, DU = Model::DU;
     ui = -1;
     if (ab == 1) return Model::boundcost(A.prm, x);  // bellman.c:513-523
     if (ab == -1) return Model::obscost(A.prm, x);   // bellman.c:524-532
+    constexpr int NT = Model::NTAB > 0 ? Model::NTAB : 1;
+    const double *tab[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) tab[t] = ro + A.tab_off[t < Model::NTAB ? t : 0];
     typename Model::Node nd;
-    Model::prep(A.prm, x, nd);
+    Model::prep(A.prm, x, tab, ix, nd);
     double best = 0.0;
     for (int c = 0; c < A.ncand; c++) {
         double u[DU];
 #pragma unroll
         for (int i = 0; i < DU; i++) u[i] = ro[A.cands_off + c * DU + i];
         double b[D], s[D];
-        Model::drift(A.prm, nd, x, u, b);
+        Model::drift(A.prm, nd, x, u, ro + A.cfeat_off + c * Model::NCF, b);
         Model::sigma(A.prm, x, u, s);
         const double stage = Model::stage(A.prm, x, u);
         // nodeutil.c:289-309 fused with the ddot of bellman.c:95: the rates are accumulated un-normalised,

@@ -1,0 +1,430 @@
+// kernel_fiber_pair.hpp -- "one fiber per lane, two wavefronts per 64 fibers" Bellman kernel (gfx950).
+//
+// Same algebra as kernel_fiber_per_lane.hpp (fold everything that is constant along a fiber into
+// L, R and the 2(d-1) neighbour vectors w_m^{-+} / z_m^{-+}; per node only c = G_k[j] R, a = L G_k[j]
+// and 2d-1 short dots remain), but the folded vectors do not fit the 256 VALU-addressable VGPRs of a
+// lane (2(d-1) r doubles = 240 VGPRs at d = 7, r = 10).  So a WORKGROUP OF TWO WAVEFRONTS owns 64
+// fibers and the rank index is split in halves: wave h holds components [h r/2, (h+1) r/2) of every
+// neighbour vector (60 doubles), computes the matching half of c and a with the wave-uniform matrix
+// element as an SGPR operand (both waves see the same j, their element offsets differ by a wave-uniform
+// constant), and produces PARTIAL dots; the two waves exchange the 2d-1 partial sums per node through
+// LDS and take turns running the control minimisation (wave 0: even nodes, wave 1: odd nodes, delayed
+// by one node pair so the dim-k neighbours are known).  One s_barrier pair per two nodes.
+//
+// Folding (once per 64-fiber tile): each wave folds the neighbour vectors of half of the dims (full
+// length, 6 x r doubles in registers) through the fixed cores staged in LDS -- exactly as the
+// fiber-per-lane kernel does -- and the halves are swapped through LDS afterwards.
+//
+// Budget: 128-thread workgroups, <= 256 VGPRs (2 waves per SIMD with 4 workgroups per CU), LDS = one
+// staged core (33 KB at N = 41, r = 10), reused as the exchange buffer during the node loop.
+#pragma once
+#include <utility>
+
+#include "kernel_fiber_per_lane.hpp"
+
+namespace c3sc {
+
+constexpr int FPP_THREADS = 128;
+
+__device__ inline void stage_core_n(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride, int nthreads)
+{
+    const int total = n_nodes * elems;
+    for (int e = threadIdx.x; e < total; e += nthreads) {
+        const int j = e / elems, w = e - j * elems;
+        sK[j * stride + w] = src[e];
+    }
+}
+
+__device__ inline void pair_barrier()
+{ // workgroup barrier + LDS visibility between the two wavefronts
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// which wave folds the neighbour pair of dim m (m != K): alternate by distance from K so the O(distance)
+// propagation work is balanced
+template <int K>
+__host__ __device__ constexpr int pair_owner(int m) { return m < K ? ((K - 1 - m) & 1) : ((m - K) & 1); }
+
+template <int D, int K, int H>
+__host__ __device__ constexpr int own_left_before(int m)
+{ // number of left dims < m owned by H
+    int c = 0;
+    for (int q = 0; q < m && q < K; q++) c += (pair_owner<K>(q) == H);
+    return c;
+}
+template <int D, int K, int H>
+__host__ __device__ constexpr int own_right_after(int m)
+{ // number of right dims > m owned by H
+    int c = 0;
+    for (int q = D - 1; q > m && q > K; q--) c += (pair_owner<K>(q) == H);
+    return c;
+}
+
+// dims-neighbour vector index (skips K): (m, s) -> 0 .. 2(D-1)-1
+template <int K>
+__host__ __device__ constexpr int gvec(int m, int s) { return (m < K ? 2 * m : 2 * (m - 1)) + s; }
+
+// neighbour values along the varying dim for node jn (nodeutil.c:570-624)
+__device__ inline void dimk_values(int jn, int N, int bck, double vL, double vC, double vR, double vwrap, double vone,
+                                   double &lo, double &hi)
+{
+    lo = vL;
+    hi = vR;
+    if (jn == 0) {
+        lo = (bck == C3SC_PERIODIC) ? vwrap : vC;
+        hi = (bck == C3SC_ABSORB) ? vC : vR;
+    }
+    if (jn == N - 1) {
+        lo = (bck == C3SC_ABSORB) ? vC : vL;
+        hi = (bck == C3SC_PERIODIC) ? vone : vC;
+        if (N == 1) lo = vC;
+    }
+}
+
+template <class Model, int RP, int K, int H>
+__device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArgs &A, const double *__restrict__ ro,
+                                                                     const int32_t *__restrict__ idx, double *__restrict__ outv,
+                                                                     int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed,
+                                                                     double *sK, unsigned &st)
+{
+    constexpr int D = Model::D;
+    constexpr int S = 2 * D + 1;
+    constexpr int RH = RP / 2;
+    constexpr int NV = 2 * (D - 1);                      // neighbour vectors in total
+    constexpr int NOL = 2 * own_left_before<D, K, H>(K); // own left vectors (slots [0, NOL))
+    constexpr int NOR = 2 * own_right_after<D, K, H>(K); // own right vectors (slots [NOL, NOL+NOR))
+    constexpr int NOWN = (NOL + NOR) > 0 ? (NOL + NOR) : 1;
+    constexpr int NP = NV + 1; // partial sums per node: NV neighbour values + the node value
+    static_assert(RP % 2 == 0, "rank-split kernel needs an even padded rank");
+    const int lane = threadIdx.x & 63;
+    const int N = A.N;
+    const long ntiles = (A.F + 63) / 64;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long f_raw = tile * 64 + lane;
+        const bool live = f_raw < A.F;
+        const long f = live ? f_raw : A.F - 1;
+
+        int fi[D], nbm[D], nbp[D];
+        bool fiber_abs = false;
+        double x[D];
+#pragma unroll
+        for (int m = 0; m < D; m++) {
+            fi[m] = (m == K) ? 0 : idx[f * D + m];
+            const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], nbm[m], nbp[m]);
+            if (m != K) fiber_abs = fiber_abs || face;
+            x[m] = ro[A.xg_off[m] + fi[m]];
+        }
+
+        double L[RP], R[RP], W[NOWN][RP];
+#pragma unroll
+        for (int a = 0; a < RP; a++) { L[a] = (a == 0) ? 1.0 : 0.0; R[a] = (a == 0) ? 1.0 : 0.0; }
+
+        // ------------------------------------------------------------ fold the prefix side
+        if constexpr (K > 0) {
+            {
+                constexpr int str = fpl_lds_stride(RP);
+                pair_barrier();
+                stage_core_n(sK, ro + A.core_off[0], A.ngrid[0], RP, str, FPP_THREADS);
+                pair_barrier();
+#pragma unroll
+                for (int b = 0; b < RP; b++) {
+                    L[b] = sK[fi[0] * str + b];
+                    if constexpr (pair_owner<K>(0) == H) {
+                        W[0][b] = sK[nbm[0] * str + b];
+                        W[1][b] = sK[nbp[0] * str + b];
+                    }
+                }
+            }
+            auto left_step = [&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int str = fpl_lds_stride(RP * RP);
+                constexpr int before = 2 * own_left_before<D, K, H>(m); // own vectors created so far
+                pair_barrier();
+                stage_core_n(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str, FPP_THREADS);
+                pair_barrier();
+                const double *G = sK + fi[m] * str;
+                apply_core<RP, NOWN, 0, before, true>(G, W);
+                if constexpr (pair_owner<K>(m) == H) {
+                    double t0[1][RP], t1[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { t0[0][a] = L[a]; t1[0][a] = L[a]; }
+                    vecmat_lds<RP, 1>(sK + nbm[m] * str, t0);
+                    vecmat_lds<RP, 1>(sK + nbp[m] * str, t1);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { W[before][a] = t0[0][a]; W[before + 1][a] = t1[0][a]; }
+                }
+                {
+                    double t[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) t[0][a] = L[a];
+                    vecmat_lds<RP, 1>(G, t);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) L[a] = t[0][a];
+                }
+            };
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (left_step(std::integral_constant<int, Ms + 1>{}), ...); }
+            (std::make_integer_sequence<int, (K > 1 ? K - 1 : 0)>{});
+        }
+
+        // ------------------------------------------------------------ fold the suffix side
+        if constexpr (K < D - 1) {
+            {
+                constexpr int str = fpl_lds_stride(RP);
+                pair_barrier();
+                stage_core_n(sK, ro + A.core_off[D - 1], A.ngrid[D - 1], RP, str, FPP_THREADS);
+                pair_barrier();
+#pragma unroll
+                for (int a = 0; a < RP; a++) {
+                    R[a] = sK[fi[D - 1] * str + a];
+                    if constexpr (pair_owner<K>(D - 1) == H) {
+                        W[NOL][a] = sK[nbm[D - 1] * str + a];
+                        W[NOL + 1][a] = sK[nbp[D - 1] * str + a];
+                    }
+                }
+            }
+            auto right_step = [&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value; // D-2 down to K+1
+                constexpr int str = fpl_lds_stride(RP * RP);
+                constexpr int after = 2 * own_right_after<D, K, H>(m);
+                pair_barrier();
+                stage_core_n(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str, FPP_THREADS);
+                pair_barrier();
+                const double *G = sK + fi[m] * str;
+                apply_core<RP, NOWN, NOL, after, false>(G, W);
+                if constexpr (pair_owner<K>(m) == H) {
+                    double t0[1][RP], t1[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { t0[0][a] = R[a]; t1[0][a] = R[a]; }
+                    matvec_lds<RP, 1>(sK + nbm[m] * str, t0);
+                    matvec_lds<RP, 1>(sK + nbp[m] * str, t1);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { W[NOL + after][a] = t0[0][a]; W[NOL + after + 1][a] = t1[0][a]; }
+                }
+                {
+                    double t[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) t[0][a] = R[a];
+                    matvec_lds<RP, 1>(G, t);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) R[a] = t[0][a];
+                }
+            };
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (right_step(std::integral_constant<int, D - 2 - Ms>{}), ...); }
+            (std::make_integer_sequence<int, (D - 2 - K > 0 ? D - 2 - K : 0)>{});
+        }
+
+        // ------------------------------------------------------------ swap halves: Wh[g][i] = component H*RH + i of vector g
+        double Wh[NV][RH];
+        {
+            double *X = sK; // [NV][RH][64]
+            pair_barrier();
+            auto put_get_own = [&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (m != K && pair_owner<K>(m) == H) {
+                    constexpr int slot = (m < K) ? 2 * own_left_before<D, K, H>(m) : NOL + 2 * own_right_after<D, K, H>(m);
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int g = gvec<K>(m, s);
+#pragma unroll
+                        for (int i = 0; i < RH; i++) {
+                            X[(g * RH + i) * 64 + lane] = W[slot + s][(1 - H) * RH + i];
+                            Wh[g][i] = W[slot + s][H * RH + i];
+                        }
+                    }
+                }
+            };
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (put_get_own(std::integral_constant<int, Ms>{}), ...); }
+            (std::make_integer_sequence<int, D>{});
+            pair_barrier();
+            auto get_other = [&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (m != K && pair_owner<K>(m) != H) {
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        const int g = gvec<K>(m, s);
+#pragma unroll
+                        for (int i = 0; i < RH; i++) Wh[g][i] = X[(g * RH + i) * 64 + lane];
+                    }
+                }
+            };
+            [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (get_other(std::integral_constant<int, Ms>{}), ...); }
+            (std::make_integer_sequence<int, D>{});
+            pair_barrier();
+        }
+
+        // ------------------------------------------------------------ node loop
+        const int bck = A.bctype[K];
+        const double *Gk = ro + A.core_off[K];
+        // partial sums of node j owned by this wave: P[g] for the NV neighbour vectors, P[NV] = node value
+        auto partials = [&](int j, double (&P)[NP]) __attribute__((always_inline)) {
+            if constexpr (K == 0) { // G_0[j] is a 1 x r row: a = row, no left vectors
+                double ah[RH];
+#pragma unroll
+                for (int i = 0; i < RH; i++) ah[i] = Gk[(size_t)j * RP + H * RH + i];
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < RH; i++) v = fma(ah[i], R[H * RH + i], v);
+                P[NV] = v;
+#pragma unroll
+                for (int g = 0; g < NV; g++) P[g] = dot_reg<RH>(ah, Wh[g]);
+            } else if constexpr (K == D - 1) { // G_{d-1}[j] is an r x 1 column: c = column, no right vectors
+                double ch[RH];
+#pragma unroll
+                for (int i = 0; i < RH; i++) ch[i] = Gk[(size_t)j * RP + H * RH + i];
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < RH; i++) v = fma(L[H * RH + i], ch[i], v);
+                P[NV] = v;
+#pragma unroll
+                for (int g = 0; g < NV; g++) P[g] = dot_reg<RH>(Wh[g], ch);
+            } else {
+                const double *G = Gk + (size_t)j * RP * RP;
+                double ch[RH], ah[RH];
+#pragma unroll
+                for (int i = 0; i < RH; i++) { ch[i] = 0.0; ah[i] = 0.0; }
+                // c_h[i] = sum_b G[H*RH+i, b] R[b]
+#pragma unroll
+                for (int b = 0; b < RP; b++)
+#pragma unroll
+                    for (int i = 0; i < RH; i++) ch[i] = fma(G[H * RH + i + b * RP], R[b], ch[i]);
+                // a_h[i] = sum_a L[a] G[a, H*RH+i]
+#pragma unroll
+                for (int i = 0; i < RH; i++)
+#pragma unroll
+                    for (int a = 0; a < RP; a++) ah[i] = fma(L[a], G[a + (H * RH + i) * RP], ah[i]);
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < RH; i++) v = fma(L[H * RH + i], ch[i], v);
+                P[NV] = v;
+#pragma unroll
+                for (int g = 0; g < 2 * K; g++) P[g] = dot_reg<RH>(Wh[g], ch);
+#pragma unroll
+                for (int g = 2 * K; g < NV; g++) P[g] = dot_reg<RH>(ah, Wh[g]);
+            }
+        };
+        // LDS exchange slots (doubles): each value is a row of 64 lanes
+        double *B0 = sK;                 // wave 0 -> wave 1 : P_0(j1)[NP], then v_0(j0)
+        double *B1 = sK + (NP + 1) * 64; // wave 1 -> wave 0 : P_1(j0)[NP], then v_1(j1)
+        double *B2 = B1 + (NP + 1) * 64; // wave 1 own       : P_1(j1)[NP]
+
+        // finalise one node: V holds the NV neighbour values in gvec order and the node value in V[NV]
+        auto finalize = [&](int jn, const double (&Vt)[NP], double vlo, double vhi) __attribute__((always_inline)) {
+            double V[S];
+#pragma unroll
+            for (int m = 0; m < D; m++) {
+                if (m == K) { V[2 * m] = vlo; V[2 * m + 1] = vhi; }
+                else { V[2 * m] = Vt[gvec<K>(m, 0)]; V[2 * m + 1] = Vt[gvec<K>(m, 1)]; }
+            }
+            V[2 * D] = Vt[NV];
+            x[K] = ro[A.xg_off[K] + jn];
+            fi[K] = jn;
+            int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
+            if (fiber_abs) ab = 1;
+            int lo, hi;
+            ab = vary_neighbors(jn, N, bck, ab, lo, hi);
+            int ui;
+            const double val = node_backup<Model>(A, ro, x, fi, V, ab, ui, st);
+            if (live) {
+                outv[(size_t)f * N + jn] = val;
+                if (uidx) uidx[(size_t)f * N + jn] = ui;
+                if (absorbed) absorbed[(size_t)f * N + jn] = ab;
+            }
+        };
+
+        // value of node N-2 (left neighbour of node 0 under a periodic boundary)
+        double vwrap = 0.0;
+        if (bck == C3SC_PERIODIC) {
+            double P[NP];
+            partials(N - 2, P);
+            sK[H * 64 + lane] = P[NV];
+            pair_barrier();
+            vwrap = P[NV] + sK[(1 - H) * 64 + lane];
+            pair_barrier();
+        }
+        double vone = 0.0;            // v[1]
+        double v_m2 = 0.0, v_m1 = 0.0; // v[2t-2], v[2t-1]
+        double Vd[NP];                 // wave 1: stencil of node 2t-1 waiting for v[2t]
+#pragma unroll
+        for (int g = 0; g < NP; g++) Vd[g] = 0.0;
+
+        const int T = N / 2 + 1;
+        for (int t = 0; t < T; t++) {
+            const int j0 = 2 * t, j1 = 2 * t + 1;
+            const bool has0 = j0 < N, has1 = j1 < N;
+            double P0[NP], pv0 = 0.0, pv1 = 0.0;
+            if (has0) {
+                partials(j0, P0);
+                pv0 = P0[NV];
+                if constexpr (H == 1) {
+#pragma unroll
+                    for (int g = 0; g < NP; g++) B1[g * 64 + lane] = P0[g];
+                } else {
+                    B0[NP * 64 + lane] = pv0;
+                }
+            }
+            if (has1) {
+                double P1[NP];
+                partials(j1, P1);
+                pv1 = P1[NV];
+                if constexpr (H == 0) {
+#pragma unroll
+                    for (int g = 0; g < NP; g++) B0[g * 64 + lane] = P1[g];
+                } else {
+#pragma unroll
+                    for (int g = 0; g < NP; g++) B2[g * 64 + lane] = P1[g];
+                    B1[NP * 64 + lane] = pv1;
+                }
+            }
+            pair_barrier();
+            double v0 = 0.0, v1 = 0.0; // totals v[j0], v[j1]
+            if constexpr (H == 0) {
+                if (has1) v1 = pv1 + B1[NP * 64 + lane];
+                if (has0) {
+#pragma unroll
+                    for (int g = 0; g < NP; g++) P0[g] += B1[g * 64 + lane];
+                    v0 = P0[NV];
+                    double vlo, vhi;
+                    dimk_values(j0, N, bck, v_m1, v0, v1, vwrap, (j0 == 0 ? v1 : vone), vlo, vhi);
+                    finalize(j0, P0, vlo, vhi);
+                }
+            } else {
+                if (has0) v0 = pv0 + B0[NP * 64 + lane];
+                if (t >= 1) { // node 2t-1
+                    const int jn = j0 - 1;
+                    double vlo, vhi;
+                    dimk_values(jn, N, bck, v_m2, Vd[NV], v0, vwrap, (jn == 1 ? Vd[NV] : vone), vlo, vhi);
+                    finalize(jn, Vd, vlo, vhi);
+                }
+                if (has1) {
+#pragma unroll
+                    for (int g = 0; g < NP; g++) Vd[g] = B0[g * 64 + lane] + B2[g * 64 + lane];
+                    v1 = Vd[NV];
+                }
+            }
+            if (t == 0) vone = v1;
+            v_m2 = v0;
+            v_m1 = v1;
+            pair_barrier();
+        }
+    }
+}
+
+template <class Model, int RP, int K>
+__global__ void __launch_bounds__(FPP_THREADS, 2)
+    k_fiber_pair(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
+                 int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
+{
+    extern __shared__ double sKp[];
+    unsigned st = 0;
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (h == 0) fiber_pair_body<Model, RP, K, 0>(A, ro, idx, outv, uidx, absorbed, sKp, st);
+    else fiber_pair_body<Model, RP, K, 1>(A, ro, idx, outv, uidx, absorbed, sKp, st);
+    if (st) atomicOr(A.status, st);
+}
+
+} // namespace c3sc

@@ -25,6 +25,8 @@
 // Template parameter K = dim_vary is a compile-time constant so that all vector arrays are fully
 // unrolled into registers.
 #pragma once
+#include <utility>
+
 #include "kernel_common.hpp"
 
 namespace c3sc {
@@ -33,24 +35,46 @@ constexpr int FPL_THREADS = 256;
 #ifndef FPL_NV
 #define FPL_NV 2
 #endif
+// keep the scheduler from hoisting whole matrices of loads ahead of their FMAs (register pressure)
+#ifndef FPL_NO_FENCE
+#define FPL_SCHED_FENCE() asm volatile("" ::: "memory")
+#else
+#define FPL_SCHED_FENCE()
+#endif
 
 __host__ __device__ constexpr int fpl_lds_stride(int elems) { return elems | 1; } // odd #doubles per node
+
+// Scheduling control.  hipcc's schedulers happily hoist every LDS load of an unrolled r x r product above
+// the FMAs (200 live VGPRs per matrix -> AGPR/scratch spills that made the first version of this kernel
+// 20x slower than its instruction count).  The products below are therefore software-pipelined BY HAND:
+// column b+1 is loaded while column b is consumed, and an empty asm that "modifies" the accumulators and
+// clobbers memory pins each column's FMAs between its neighbours' loads.
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void mem_fence() { asm volatile("" ::: "memory"); }
 
 // out[b] = sum_a v[a] G[a + b*RP]   (row vector times the lane's own matrix in LDS), NV vectors per pass
 template <int RP, int NV>
 __device__ inline void vecmat_lds(const double *G, double (&v)[NV][RP])
 {
     double t[NV][RP];
+    double g[2][RP];
+#pragma unroll
+    for (int a = 0; a < RP; a++) g[0][a] = G[a];
 #pragma unroll
     for (int b = 0; b < RP; b++) {
+        if (b + 1 < RP) {
 #pragma unroll
-        for (int s = 0; s < NV; s++) t[s][b] = 0.0;
-#pragma unroll
-        for (int a = 0; a < RP; a++) {
-            const double g = G[a + b * RP];
-#pragma unroll
-            for (int s = 0; s < NV; s++) t[s][b] = fma(v[s][a], g, t[s][b]);
+            for (int a = 0; a < RP; a++) g[(b + 1) & 1][a] = G[a + (b + 1) * RP];
         }
+#pragma unroll
+        for (int s = 0; s < NV; s++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < RP; a++) acc = fma(v[s][a], g[b & 1][a], acc);
+            pin(acc);
+            t[s][b] = acc;
+        }
+        mem_fence();
     }
 #pragma unroll
     for (int s = 0; s < NV; s++)
@@ -63,18 +87,28 @@ template <int RP, int NV>
 __device__ inline void matvec_lds(const double *G, double (&v)[NV][RP])
 {
     double t[NV][RP];
+    double g[2][RP];
 #pragma unroll
     for (int s = 0; s < NV; s++)
 #pragma unroll
         for (int a = 0; a < RP; a++) t[s][a] = 0.0;
 #pragma unroll
-    for (int b = 0; b < RP; b++)
+    for (int a = 0; a < RP; a++) g[0][a] = G[a];
 #pragma unroll
-        for (int a = 0; a < RP; a++) {
-            const double g = G[a + b * RP];
+    for (int b = 0; b < RP; b++) {
+        if (b + 1 < RP) {
 #pragma unroll
-            for (int s = 0; s < NV; s++) t[s][a] = fma(g, v[s][b], t[s][a]);
+            for (int a = 0; a < RP; a++) g[(b + 1) & 1][a] = G[a + (b + 1) * RP];
         }
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) {
+                t[s][a] = fma(g[b & 1][a], v[s][b], t[s][a]);
+                pin(t[s][a]);
+            }
+        mem_fence();
+    }
 #pragma unroll
     for (int s = 0; s < NV; s++)
 #pragma unroll
@@ -121,6 +155,18 @@ __device__ inline void stage_core(double *sK, const double *__restrict__ src, in
     }
 }
 
+// number of neighbour vectors that live in LDS instead of registers: the 2(D-1) vectors need
+// 2(D-1)*RP*2 VGPRs, but only 256 VGPRs are addressable by VALU instructions (the other 256 of the
+// unified file are AGPRs).  Vectors g < NLDS sit in LDS as [g][c/2][lane][2] (one conflict-free
+// ds_read_b128 per pair of components), the rest in registers.
+template <int D, int RP>
+__host__ __device__ constexpr int fpl_nlds()
+{
+    const int nv = 2 * (D - 1);
+    const int max_reg_vecs = 120 / (2 * RP) > 0 ? 120 / (2 * RP) : 0; // ~120 VGPRs for resident vectors
+    return nv > max_reg_vecs ? nv - max_reg_vecs : 0;
+}
+
 template <class Model, int RP, int K>
 __global__ void __launch_bounds__(FPL_THREADS, 1)
     k_fiber_per_lane(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
@@ -128,11 +174,17 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
 {
     constexpr int D = Model::D;
     constexpr int S = 2 * D + 1;
-    constexpr int NL = 2 * K;           // left neighbour vectors  w_m^{-+}, m = 0..K-1  (index 2m + s)
-    constexpr int NR = 2 * (D - 1 - K); // right neighbour vectors z_m^{-+}, m = K+1..D-1 (index 2(m-K-1) + s)
-    constexpr int NLa = NL > 0 ? NL : 1, NRa = NR > 0 ? NR : 1;
-    extern __shared__ double sK[];
+    constexpr int NV = 2 * (D - 1);   // neighbour vectors, index g = (m < K ? 2m : 2(m-1)) + s
+    constexpr int NLDS = fpl_nlds<D, RP>();
+    constexpr int NREG = NV - NLDS;
+    constexpr int NREGa = NREG > 0 ? NREG : 1;
+    constexpr int RPe = RP + (RP & 1); // components per LDS vector, even
+    static_assert(RP % 2 == 0 || NLDS == 0, "LDS-resident vectors need an even padded rank");
+    extern __shared__ double smem[];
+    double *sW = smem;                                      // [NLDS][RPe/2][256][2]
+    double *sK = smem + (size_t)NLDS * RPe * FPL_THREADS;   // staged core
     const int N = A.N;
+    const int tid = threadIdx.x;
     unsigned st = 0;
     const long ntiles = (A.F + FPL_THREADS - 1) / FPL_THREADS;
 
@@ -153,23 +205,48 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
             x[m] = ro[A.xg_off[m] + fi[m]];
         }
 
-        double L[RP], R[RP], WL[NLa][RP], WR[NRa][RP];
+        double L[RP], R[RP], WR[NREGa][RP];
 #pragma unroll
         for (int a = 0; a < RP; a++) { L[a] = (a == 0) ? 1.0 : 0.0; R[a] = (a == 0) ? 1.0 : 0.0; }
 
-        // ---- prefix side: fold cores 0..K-1 into L and the left neighbour vectors
+        // vector g: load / store (LDS slot of this lane or register array)
+        auto vload = [&](auto gc, double (&v)[RP]) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < NLDS) {
+#pragma unroll
+                for (int c = 0; c < RP; c++) v[c] = sW[(((size_t)g * (RPe / 2) + c / 2) * FPL_THREADS + tid) * 2 + (c & 1)];
+            } else {
+#pragma unroll
+                for (int c = 0; c < RP; c++) v[c] = WR[g - NLDS][c];
+            }
+        };
+        auto vstore = [&](auto gc, const double (&v)[RP]) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < NLDS) {
+#pragma unroll
+                for (int c = 0; c < RP; c++) sW[(((size_t)g * (RPe / 2) + c / 2) * FPL_THREADS + tid) * 2 + (c & 1)] = v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < RP; c++) WR[g - NLDS][c] = v[c];
+            }
+        };
+
+        // ---- prefix side: fold cores 0..K-1 into L and the left neighbour vectors (g = 2m + s)
         if constexpr (K > 0) {
             { // core 0 is a 1 x r row per node
                 constexpr int str = fpl_lds_stride(RP);
                 __syncthreads();
                 stage_core(sK, ro + A.core_off[0], A.ngrid[0], RP, str);
                 __syncthreads();
+                double q0[RP], q1[RP];
 #pragma unroll
                 for (int b = 0; b < RP; b++) {
                     L[b] = sK[fi[0] * str + b];
-                    WL[0][b] = sK[nbm[0] * str + b];
-                    WL[1][b] = sK[nbp[0] * str + b];
+                    q0[b] = sK[nbm[0] * str + b];
+                    q1[b] = sK[nbp[0] * str + b];
                 }
+                vstore(std::integral_constant<int, 0>{}, q0);
+                vstore(std::integral_constant<int, 1>{}, q1);
             }
             auto left_step = [&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value;
@@ -177,21 +254,27 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 __syncthreads();
                 stage_core(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str);
                 __syncthreads();
-                // new pair from the running prefix, then push everything through G_m[i_m]
-                double q[2][RP];
-#pragma unroll
-                for (int a = 0; a < RP; a++) { q[0][a] = L[a]; q[1][a] = L[a]; }
+                const double *G = sK + fi[m] * str;
+                // push the existing left vectors through G_m[i_m], one at a time
+                [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
+                    (([&] {
+                         double t[1][RP];
+                         vload(std::integral_constant<int, Gs>{}, t[0]);
+                         vecmat_lds<RP, 1>(G, t);
+                         vstore(std::integral_constant<int, Gs>{}, t[0]);
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, 2 * m>{});
+                // the new pair from the running prefix
                 {
                     double t0[1][RP], t1[1][RP];
 #pragma unroll
                     for (int a = 0; a < RP; a++) { t0[0][a] = L[a]; t1[0][a] = L[a]; }
                     vecmat_lds<RP, 1>(sK + nbm[m] * str, t0);
+                    vstore(std::integral_constant<int, 2 * m>{}, t0[0]);
                     vecmat_lds<RP, 1>(sK + nbp[m] * str, t1);
-#pragma unroll
-                    for (int a = 0; a < RP; a++) { q[0][a] = t0[0][a]; q[1][a] = t1[0][a]; }
+                    vstore(std::integral_constant<int, 2 * m + 1>{}, t1[0]);
                 }
-                const double *G = sK + fi[m] * str;
-                apply_core<RP, NLa, 0, 2 * m, true>(G, WL);
                 {
                     double t[1][RP];
 #pragma unroll
@@ -200,43 +283,54 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
 #pragma unroll
                     for (int a = 0; a < RP; a++) L[a] = t[0][a];
                 }
-#pragma unroll
-                for (int a = 0; a < RP; a++) { WL[2 * m][a] = q[0][a]; WL[2 * m + 1][a] = q[1][a]; }
             };
-            // compile-time loop m = 1 .. K-1
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (left_step(std::integral_constant<int, Ms + 1>{}), ...); }
             (std::make_integer_sequence<int, (K > 1 ? K - 1 : 0)>{});
         }
 
-        // ---- suffix side: fold cores D-1..K+1 into R and the right neighbour vectors
+        // ---- suffix side: fold cores D-1..K+1 into R and the right neighbour vectors (g = 2(m-1) + s)
         if constexpr (K < D - 1) {
             { // core D-1 is an r x 1 column per node
                 constexpr int str = fpl_lds_stride(RP);
                 __syncthreads();
                 stage_core(sK, ro + A.core_off[D - 1], A.ngrid[D - 1], RP, str);
                 __syncthreads();
-                constexpr int o = 2 * (D - 1 - K - 1);
+                double q0[RP], q1[RP];
 #pragma unroll
                 for (int a = 0; a < RP; a++) {
                     R[a] = sK[fi[D - 1] * str + a];
-                    WR[o][a] = sK[nbm[D - 1] * str + a];
-                    WR[o + 1][a] = sK[nbp[D - 1] * str + a];
+                    q0[a] = sK[nbm[D - 1] * str + a];
+                    q1[a] = sK[nbp[D - 1] * str + a];
                 }
+                vstore(std::integral_constant<int, 2 * (D - 2)>{}, q0);
+                vstore(std::integral_constant<int, 2 * (D - 2) + 1>{}, q1);
             }
             auto right_step = [&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value; // D-2 down to K+1
                 constexpr int str = fpl_lds_stride(RP * RP);
-                constexpr int o = 2 * (m - K - 1);     // slot of this dim's pair; later dims sit above it
+                constexpr int g0 = 2 * (m - 1);        // this dim's pair; the dims above it are g0+2 .. NV-1
                 __syncthreads();
                 stage_core(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str);
                 __syncthreads();
-                double t0[1][RP], t1[1][RP];
-#pragma unroll
-                for (int a = 0; a < RP; a++) { t0[0][a] = R[a]; t1[0][a] = R[a]; }
-                matvec_lds<RP, 1>(sK + nbm[m] * str, t0);
-                matvec_lds<RP, 1>(sK + nbp[m] * str, t1);
                 const double *G = sK + fi[m] * str;
-                apply_core<RP, NRa, o + 2, NR - (o + 2), false>(G, WR);
+                [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
+                    (([&] {
+                         double t[1][RP];
+                         vload(std::integral_constant<int, g0 + 2 + Gs>{}, t[0]);
+                         matvec_lds<RP, 1>(G, t);
+                         vstore(std::integral_constant<int, g0 + 2 + Gs>{}, t[0]);
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, NV - (g0 + 2)>{});
+                {
+                    double t0[1][RP], t1[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) { t0[0][a] = R[a]; t1[0][a] = R[a]; }
+                    matvec_lds<RP, 1>(sK + nbm[m] * str, t0);
+                    vstore(std::integral_constant<int, g0>{}, t0[0]);
+                    matvec_lds<RP, 1>(sK + nbp[m] * str, t1);
+                    vstore(std::integral_constant<int, g0 + 1>{}, t1[0]);
+                }
                 {
                     double t[1][RP];
 #pragma unroll
@@ -245,10 +339,7 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
 #pragma unroll
                     for (int a = 0; a < RP; a++) R[a] = t[0][a];
                 }
-#pragma unroll
-                for (int a = 0; a < RP; a++) { WR[o][a] = t0[0][a]; WR[o + 1][a] = t1[0][a]; }
             };
-            // compile-time loop m = D-2 .. K+1
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (right_step(std::integral_constant<int, D - 2 - Ms>{}), ...); }
             (std::make_integer_sequence<int, (D - 2 - K > 0 ? D - 2 - K : 0)>{});
         }
@@ -256,6 +347,22 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
         // ---- node loop: FT values of node j, then (delayed by one node) the Bellman backup of node j-1
         const int bck = A.bctype[K];
         const double *Gk = ro + A.core_off[K];
+        // dot of neighbour vector g with a register vector
+        auto vdot = [&](auto gc, const double (&u)[RP]) __attribute__((always_inline)) -> double {
+            constexpr int g = decltype(gc)::value;
+            double acc = 0.0;
+            if constexpr (g < NLDS) {
+#pragma unroll
+                for (int c = 0; c < RP; c++)
+                    acc = fma(sW[(((size_t)g * (RPe / 2) + c / 2) * FPL_THREADS + tid) * 2 + (c & 1)], u[c], acc);
+                pin(acc);
+                mem_fence();
+            } else {
+#pragma unroll
+                for (int c = 0; c < RP; c++) acc = fma(WR[g - NLDS][c], u[c], acc);
+            }
+            return acc;
+        };
         // value of one node only (needed ahead of time for the periodic wrap: lo(0) = N-2)
         auto node_value = [&](int j) __attribute__((always_inline)) -> double {
             if constexpr (K == 0) {
@@ -294,25 +401,17 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
             double V[S];
             double vj = 0.0;
             if (j < N) {
+                double c[RP], a[RP];
                 if constexpr (K == 0) {
-                    double a[RP];
-                    double v = 0.0;
 #pragma unroll
-                    for (int b = 0; b < RP; b++) { a[b] = Gk[(size_t)j * RP + b]; v = fma(a[b], R[b], v); }
-                    vj = v;
-#pragma unroll
-                    for (int i = 0; i < NR; i++) V[2 * (K + 1) + i] = dot_reg<RP>(a, WR[i]);
+                    for (int b = 0; b < RP; b++) { a[b] = Gk[(size_t)j * RP + b]; c[b] = 0.0; }
+                    vj = dot_reg<RP>(a, R);
                 } else if constexpr (K == D - 1) {
-                    double c[RP];
-                    double v = 0.0;
 #pragma unroll
-                    for (int a = 0; a < RP; a++) { c[a] = Gk[(size_t)j * RP + a]; v = fma(L[a], c[a], v); }
-                    vj = v;
-#pragma unroll
-                    for (int i = 0; i < NL; i++) V[i] = dot_reg<RP>(WL[i], c);
+                    for (int i = 0; i < RP; i++) { c[i] = Gk[(size_t)j * RP + i]; a[i] = 0.0; }
+                    vj = dot_reg<RP>(L, c);
                 } else {
                     const double *G = Gk + (size_t)j * RP * RP;
-                    double c[RP], a[RP];
 #pragma unroll
                     for (int i = 0; i < RP; i++) c[i] = 0.0;
 #pragma unroll
@@ -327,11 +426,13 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                         a[b] = s;
                     }
                     vj = dot_reg<RP>(L, c);
-#pragma unroll
-                    for (int i = 0; i < NL; i++) V[i] = dot_reg<RP>(WL[i], c);
-#pragma unroll
-                    for (int i = 0; i < NR; i++) V[2 * (K + 1) + i] = dot_reg<RP>(a, WR[i]);
                 }
+                // neighbour values: left vectors against c, right vectors against a
+                [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
+                    ((V[(Gs < 2 * K) ? Gs : Gs + 2] = (Gs < 2 * K) ? vdot(std::integral_constant<int, Gs>{}, c)
+                                                                   : vdot(std::integral_constant<int, Gs>{}, a)),
+                     ...);
+                }(std::make_integer_sequence<int, NV>{});
                 V[2 * D] = vj;
                 V[2 * K] = 0.0;
                 V[2 * K + 1] = 0.0;
@@ -352,12 +453,13 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 Vp[2 * K + 1] = vhi;
                 // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
                 x[K] = ro[A.xg_off[K] + jn];
+                fi[K] = jn;
                 int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
                 if (fiber_abs) ab = 1;
                 int lo, hi;
                 ab = vary_neighbors(jn, N, bck, ab, lo, hi);
                 int ui;
-                const double val = node_backup<Model>(A, ro, x, Vp, ab, ui, st);
+                const double val = node_backup<Model>(A, ro, x, fi, Vp, ab, ui, st);
                 if (live) {
                     outv[(size_t)f * N + jn] = val;
                     if (uidx) uidx[(size_t)f * N + jn] = ui;

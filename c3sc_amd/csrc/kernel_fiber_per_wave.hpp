@@ -269,8 +269,12 @@ __global__ void __launch_bounds__(256)
 
             // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
             double x[D];
+            int ix[D];
 #pragma unroll
-            for (int m = 0; m < D; m++) x[m] = ro[A.xg_off[m] + (m == k ? jj : fi[m])];
+            for (int m = 0; m < D; m++) {
+                ix[m] = (m == k) ? jj : fi[m];
+                x[m] = ro[A.xg_off[m] + ix[m]];
+            }
             int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
@@ -295,7 +299,7 @@ __global__ void __launch_bounds__(256)
                 }
             } else {
                 int ui;
-                const double val = node_backup<Model>(A, ro, x, V, ab, ui, st);
+                const double val = node_backup<Model>(A, ro, x, ix, V, ab, ui, st);
                 if (live) {
                     outv[(size_t)f * N + j] = val;
                     if (uidx) uidx[(size_t)f * N + j] = ui;

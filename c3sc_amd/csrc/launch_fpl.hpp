@@ -19,7 +19,9 @@ hipError_t launch_fpl(const KArgs &A, const LaunchIO &io)
         const size_t need = (size_t)A.ngrid[m] * fpl_lds_stride(elems);
         if (need > doubles) doubles = need;
     }
-    const size_t shmem = doubles * sizeof(double);
+    constexpr int NLDS = fpl_nlds<D, RP>();
+    constexpr int RPe = RP + (RP & 1);
+    const size_t shmem = (doubles + (size_t)NLDS * RPe * FPL_THREADS) * sizeof(double);
     auto kern = k_fiber_per_lane<Model, RP, K>;
     static int blocks_per_cu = 0;
     static size_t attr_shmem = 0, occ_shmem = (size_t)-1;

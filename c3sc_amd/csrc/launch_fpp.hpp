@@ -1,0 +1,53 @@
+// launch_fpp.hpp -- host launcher + registration macro for the fiber-pair (rank-split) kernels.
+#pragma once
+#include "kernel_fiber_pair.hpp"
+#include "registry.hpp"
+
+namespace c3sc {
+
+template <class Model, int RP, int K>
+hipError_t launch_fpp(const KArgs &A, const LaunchIO &io)
+{
+    constexpr int D = Model::D;
+    constexpr int NV = 2 * (D - 1), NP = NV + 1, RH = RP / 2;
+    // LDS: max(largest staged fixed core, half-swap buffer, per-node exchange buffers)
+    size_t doubles = (size_t)NV * RH * 64;
+    const size_t exch = (size_t)((NP + 1) * 2 + NP) * 64;
+    if (exch > doubles) doubles = exch;
+    for (int m = 0; m < D; m++) {
+        if (m == K) continue;
+        const int elems = (m == 0 || m == D - 1) ? RP : RP * RP;
+        const size_t need = (size_t)A.ngrid[m] * fpl_lds_stride(elems);
+        if (need > doubles) doubles = need;
+    }
+    const size_t shmem = doubles * sizeof(double);
+    auto kern = k_fiber_pair<Model, RP, K>;
+    static int blocks_per_cu = 0;
+    static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
+    hipError_t e;
+    if (shmem > attr_shmem) {
+        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_shmem = shmem;
+    }
+    if (shmem != occ_shmem) {
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, FPP_THREADS, shmem);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb > 0 ? nb : 1;
+        occ_shmem = shmem;
+    }
+    const long ntiles = (A.F + 63) / 64;
+    const long cap = 256L * blocks_per_cu;
+    int grid = (int)(ntiles < cap ? ntiles : cap);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FPP_THREADS), shmem, io.stream, A, io.ro, io.idx, io.out, io.uidx, io.absorbed);
+    return hipGetLastError();
+}
+
+#define C3SC_REG_FPP1(MODEL_ID, RP, K, ...)                                                                   \
+    static Registrar C3SC_CAT(reg_fpp_, __COUNTER__)(KernelEntry{                                             \
+        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_PAIR, 1 << 20, K, &launch_fpp<__VA_ARGS__, RP, K>, \
+        "k_fiber_pair<" #__VA_ARGS__ "," #RP ",K=" #K ">"});
+
+} // namespace c3sc

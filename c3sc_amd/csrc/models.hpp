@@ -6,11 +6,19 @@
 // compile-time functor that is inlined into the node loop.  Only the DIAGONAL of the diffusion
 // matrix is produced because that is all transition_assemble reads (src/nodeutil.c:294).
 //
+// Transcendentals never run on the device: every model lists the univariate functions of a grid
+// coordinate it needs (cos(theta_i), tan(delta_i), ...) as TABLES over that dimension's nodes and the
+// functions of a control candidate (tan(u0)) as per-candidate FEATURES; the host fills both with libm
+// (c3sc_hip.hip: model_table_value / model_cand_feature), so the kernels read the very doubles the
+// reference's callbacks would compute and no polynomial constants occupy VGPRs.
+//
 // Every model has
 //   D, DU                       state / control dimension
-//   Node                        per-node invariants (trig etc.) computed once per node, not per control
-//   prep(prm, x, node)
-//   drift(prm, node, x, u, b)   b[D]
+//   NTAB, tab_dim(t)            number of tables and the dimension each one is indexed by
+//   NCF                         number of per-candidate features
+//   Node                        per-node invariants computed once per node, not per control
+//   prep(prm, x, tab, ix, node) tab[t] = pointer to table t, ix[m] = grid index of the node in dim m
+//   drift(prm, node, x, u, cf, b)   b[D]; cf = this candidate's features
 //   sigma(prm, x, u, s)         s[D] diagonal of the diffusion
 //   stage(prm, x, u)            stage cost
 //   boundcost(prm, x), obscost(prm, x)
@@ -22,9 +30,16 @@ namespace c3sc {
 // examples/dubinscar_new/dubinscar.c:40-121
 struct Dubins3D {
     static constexpr int D = 3, DU = 1;
+    static constexpr int NTAB = 2, NCF = 0; // tables: cos(x2), sin(x2)
+    __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double c, s; };
-    __device__ static inline void prep(const double *, const double (&x)[D], Node &n) { n.c = cos(x[2]); n.s = sin(x[2]); }
-    __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, double (&b)[D])
+    __device__ static inline void prep(const double *, const double (&)[D], const double *const (&tab)[2], const int (&ix)[D], Node &n)
+    {
+        n.c = tab[0][ix[2]];
+        n.s = tab[1][ix[2]];
+    }
+    __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, const double *,
+                                        double (&b)[D])
     {
         b[0] = n.c; b[1] = n.s; b[2] = u[0];
     }
@@ -40,18 +55,21 @@ struct Dubins3D {
 // examples/skidding_car/scar.c:40-169 (order = {0,1,2,3})
 struct Scar4D {
     static constexpr int D = 4, DU = 2;
+    static constexpr int NTAB = 2, NCF = 1; // tables: cos(x2), sin(x2); candidate feature: tan(u0)
+    __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double vc, vs, pre; };
-    __device__ static inline void prep(const double *, const double (&x)[D], Node &n)
+    __device__ static inline void prep(const double *, const double (&x)[D], const double *const (&tab)[2], const int (&ix)[D], Node &n)
     {
-        const double orient = x[2], speed = x[3];
+        const double speed = x[3];
         const double L = 0.2, vcar = 8.0;
         n.pre = (1.0 / (1.0 + (speed / vcar))) * (speed / L);
-        n.vc = speed * cos(orient);
-        n.vs = speed * sin(orient);
+        n.vc = speed * tab[0][ix[2]];
+        n.vs = speed * tab[1][ix[2]];
     }
-    __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, double (&b)[D])
+    __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, const double *cf,
+                                        double (&b)[D])
     {
-        b[0] = n.vc; b[1] = n.vs; b[2] = n.pre * tan(u[0]); b[3] = 2.0 * u[1];
+        b[0] = n.vc; b[1] = n.vs; b[2] = n.pre * cf[0]; b[3] = 2.0 * u[1];
     }
     __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&s)[D])
     {
@@ -68,15 +86,18 @@ struct Scar4D {
 // synthetic 7-D car: state (x, y, theta, v, omega, delta, a), controls (ddelta, da)
 struct Car7D {
     static constexpr int D = 7, DU = 2;
+    static constexpr int NTAB = 3, NCF = 0; // tables: cos(x2), sin(x2), tan(x5)
+    __host__ __device__ static constexpr int tab_dim(int t) { return t == 2 ? 5 : 2; }
     struct Node { double b0, b1, b4; };
-    __device__ static inline void prep(const double *, const double (&x)[D], Node &n)
+    __device__ static inline void prep(const double *, const double (&x)[D], const double *const (&tab)[3], const int (&ix)[D], Node &n)
     {
-        const double th = x[2], v = x[3], om = x[4], de = x[5];
-        n.b0 = v * cos(th);
-        n.b1 = v * sin(th);
-        n.b4 = (v / (0.2 * (1.0 + v / 8.0)) * tan(de) - om) / 0.5;
+        const double v = x[3], om = x[4];
+        n.b0 = v * tab[0][ix[2]];
+        n.b1 = v * tab[1][ix[2]];
+        n.b4 = (v / (0.2 * (1.0 + v / 8.0)) * tab[2][ix[5]] - om) / 0.5;
     }
-    __device__ static inline void drift(const double *, const Node &n, const double (&x)[D], const double *u, double (&b)[D])
+    __device__ static inline void drift(const double *, const Node &n, const double (&x)[D], const double *u, const double *,
+                                        double (&b)[D])
     {
         b[0] = n.b0; b[1] = n.b1; b[2] = x[4]; b[3] = 2.0 * x[6]; b[4] = n.b4; b[5] = u[0]; b[6] = u[1];
     }
@@ -98,9 +119,12 @@ struct Car7D {
 template <int DIM>
 struct LqgNd {
     static constexpr int D = DIM, DU = DIM / 2;
+    static constexpr int NTAB = 0, NCF = 0;
+    __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
-    __device__ static inline void prep(const double *, const double (&)[D], Node &) {}
-    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, double (&b)[D])
+    __device__ static inline void prep(const double *, const double (&)[D], const double *const (&)[1], const int (&)[D], Node &) {}
+    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, const double *,
+                                        double (&b)[D])
     {
 #pragma unroll
         for (int i = 0; i < D; i++) b[i] = ((i % 2) == 0) ? x[(i + 1 < D) ? i + 1 : i] : u[i / 2];
@@ -128,9 +152,12 @@ struct LqgNd {
 template <int DIM>
 struct Chain {
     static constexpr int D = DIM, DU = 1;
+    static constexpr int NTAB = 0, NCF = 0;
+    __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
-    __device__ static inline void prep(const double *, const double (&)[D], Node &) {}
-    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, double (&b)[D])
+    __device__ static inline void prep(const double *, const double (&)[D], const double *const (&)[1], const int (&)[D], Node &) {}
+    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, const double *,
+                                        double (&b)[D])
     {
 #pragma unroll
         for (int i = 0; i < D - 1; i++) b[i] = x[i + 1];

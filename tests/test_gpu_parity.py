@@ -67,15 +67,14 @@ FPL = [("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)), ("car7d", dict(ng
 
 
 @pytest.mark.parametrize("name,kw", FPL, ids=[f"{n}-r{k['rank']}" for n, k in FPL])
-def test_fiber_per_lane_kernel_vs_oracle(oracle, name, kw):
-    """The fiber-per-lane kernels (one per varying dimension) against the oracle, incl. ragged tiles
-    (F not a multiple of 256), boundary faces and the periodic wrap."""
-    from c3sc_amd.engine import VARIANT_FIBER_PER_LANE
-
+@pytest.mark.parametrize("variant,tag", [(2, "fiber_per_lane"), (3, "fiber_pair")])
+def test_fiber_per_lane_kernel_vs_oracle(oracle, name, kw, variant, tag):
+    """The fiber-per-lane / fiber-pair kernels (one per varying dimension) against the oracle, incl.
+    ragged tiles (F not a multiple of the tile), boundary faces and the periodic wrap."""
     w = wl.WORKLOADS[name]().scaled(**kw)
     cores = wl.synth_cores(w)
     P = oracle.Problem(w, cores)
-    eng = _engine(w, cores, VARIANT_FIBER_PER_LANE)
+    eng = _engine(w, cores, variant)
     for k in range(w.dx):
         idx = wl.synth_fibers(w, k, 300)
         idx[0, :] = 0
@@ -83,7 +82,7 @@ def test_fiber_per_lane_kernel_vs_oracle(oracle, name, kw):
         idx[2, :] = 1
         idx[:, k] = 0
         _check(eng, P, w, k, idx)
-        assert "fiber_per_lane" in eng.last_kernel()
+        assert tag in eng.last_kernel()
 
 
 @pytest.mark.parametrize("name,kw", SMALL[:5], ids=[f"{n}-{i}" for i, (n, k) in enumerate(SMALL[:5])])

@@ -106,6 +106,37 @@ __device__ inline bool in_obstacle(const KArgs &A, const double *__restrict__ ro
     return any != 0;
 }
 
+// The obstacle test split for kernels where one lane walks a fiber: bit o of the returned mask is set when
+// the point is inside box o in every dim except `skip` (constant along the fiber) ...
+template <int D>
+__device__ inline unsigned obstacle_mask_fixed(const KArgs &A, const double *__restrict__ ro, const double (&x)[D], int skip)
+{
+    unsigned mask = 0;
+    for (int o = 0; o < A.nobs; o++) {
+        const double *lb = ro + A.obs_off + (size_t)o * 2 * D;
+        const double *ub = lb + D;
+        int outside = 0;
+#pragma unroll
+        for (int m = 0; m < D; m++)
+            if (m != skip) outside |= (int)(x[m] < lb[m]) | (int)(x[m] > ub[m]);
+        mask |= (outside == 0 ? 1u : 0u) << o;
+    }
+    return mask;
+}
+// ... and bit o set when coordinate xk of dim k lies inside box o's k-range (wave-uniform along the node loop)
+template <int D>
+__device__ inline unsigned obstacle_mask_dim(const KArgs &A, const double *__restrict__ ro, int k, double xk)
+{
+    unsigned mask = 0;
+    for (int o = 0; o < A.nobs; o++) {
+        const double lb = ro[A.obs_off + (size_t)o * 2 * D + k], ub = ro[A.obs_off + (size_t)o * 2 * D + D + k];
+        mask |= ((xk < lb || xk > ub) ? 0u : 1u) << o;
+    }
+    return mask;
+}
+
+__device__ __forceinline__ void pin_vgpr(double &x) { asm volatile("" : "+v"(x)); }
+
 // One node of the Bellman operator: bellman_optimal (bellman.c:504-543, BRUTEFORCE branch) over
 // bellman_control (:367-480, no-gradient branch) = user dynamics + transition_assemble
 // (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)
@@ -126,6 +157,44 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     for (int t = 0; t < NT; t++) tab[t] = ro + A.tab_off[t < Model::NTAB ? t : 0];
     typename Model::Node nd;
     Model::prep(A.prm, x, tab, ix, nd);
+    // Everything that does not depend on the control is done once per node: the rates of the dims whose
+    // drift / diffusion ignore u (Model::UDEP_MASK), their share of Q = sum p and of PV = sum p_i V_i
+    // (nodeutil.c:289-309 fused with the ddot of bellman.c:95: rates are accumulated un-normalised; the
+    // reference divides every p_i by Q first, nodeutil.c:397-402 -- same value up to a few ulp).
+    constexpr unsigned UM = Model::UDEP_MASK;
+    // scalars the candidate loop needs are parked in VGPRs: left as SGPRs the compiler spills whole
+    // s_load tuples to VGPR lanes and restores them with dozens of v_readlane per candidate
+    double tl[D], t2l[D], h2l = A.h2, discl = A.discount;
+#pragma unroll
+    for (int m = 0; m < D; m++) {
+        tl[m] = A.t[2 * m];
+        t2l[m] = A.t[2 * m + 1];
+        if ((UM >> m) & 1u) { pin_vgpr(tl[m]); pin_vgpr(t2l[m]); }
+    }
+    pin_vgpr(h2l);
+    pin_vgpr(discl);
+    double Q0 = 0.0, PV0 = 0.0, stage0 = 0.0;
+    {
+        double u[DU], b[D], s[D];
+#pragma unroll
+        for (int i = 0; i < DU; i++) u[i] = ro[A.cands_off + i];
+        Model::drift(A.prm, nd, x, u, ro + A.cfeat_off, b);
+        Model::sigma(A.prm, x, u, s);
+        if constexpr (!Model::STAGE_UDEP) stage0 = Model::stage(A.prm, x, u);
+#pragma unroll
+        for (int m = 0; m < D; m++) {
+            if (!((UM >> m) & 1u)) {
+                const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
+                double pm = half, pp = half;
+                if (b[m] < -1e-14) pm -= A.t[2 * m] * b[m];
+                else if (b[m] > 1e-14) pp += A.t[2 * m] * b[m];
+                Q0 += pm;
+                Q0 += pp;
+                PV0 = fma(pm, V[2 * m], PV0);
+                PV0 = fma(pp, V[2 * m + 1], PV0);
+            }
+        }
+    }
     double best = 0.0;
     for (int c = 0; c < A.ncand; c++) {
         double u[DU];
@@ -134,31 +203,30 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         double b[D], s[D];
         Model::drift(A.prm, nd, x, u, ro + A.cfeat_off + c * Model::NCF, b);
         Model::sigma(A.prm, x, u, s);
-        const double stage = Model::stage(A.prm, x, u);
-        // nodeutil.c:289-309 fused with the ddot of bellman.c:95: the rates are accumulated un-normalised,
-        // Q = sum p, PV = sum p_i V_i; the reference divides every p_i by Q first (nodeutil.c:397-402) --
-        // same value up to rounding (<= a few ulp), without keeping the 2d rates in registers.
-        double Q = 0.0, PV = 0.0;
+        const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
+        double Q = Q0, PV = PV0;
 #pragma unroll
         for (int m = 0; m < D; m++) {
-            const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
-            double pm = half, pp = half;
-            if (b[m] < -1e-14) pm -= A.t[2 * m] * b[m];
-            else if (b[m] > 1e-14) pp += A.t[2 * m] * b[m];
-            Q += pm;
-            Q += pp;
-            PV = fma(pm, V[2 * m], PV);
-            PV = fma(pp, V[2 * m + 1], PV);
+            if ((UM >> m) & 1u) {
+                const double half = t2l[m] * (s[m] * s[m]) / 2.0;
+                double pm = half, pp = half;
+                if (b[m] < -1e-14) pm -= tl[m] * b[m];
+                else if (b[m] > 1e-14) pp += tl[m] * b[m];
+                Q += pm;
+                Q += pp;
+                PV = fma(pm, V[2 * m], PV);
+                PV = fma(pp, V[2 * m + 1], PV);
+            }
         }
         if (Q < 1e-14) { // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
             st |= C3SC_STATUS_STATIONARY;
             continue;
         }
         const double inv = 1.0 / Q;
-        const double dt = A.h2 * inv;              // nodeutil.c:369
+        const double dt = h2l * inv;               // nodeutil.c:369
         const double pself = fma(-Q, inv, 1.0);    // 1 - sum_i p_i/Q: rounding residue, as in the reference
         const double ctg = fma(pself, V[2 * D], PV * inv);
-        const double ebt = (A.discount == 0.0) ? 1.0 : exp(-A.discount * dt); // bellman.c:94
+        const double ebt = (A.discount == 0.0) ? 1.0 : exp(-discl * dt);      // bellman.c:94
         const double val = dt * stage + ebt * ctg;                            // bellman.c:97
         if (ui < 0 || val < best) {
             best = val;

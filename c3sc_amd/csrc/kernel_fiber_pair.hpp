@@ -118,6 +118,8 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             x[m] = ro[A.xg_off[m] + fi[m]];
         }
 
+        const unsigned obs_fixed = obstacle_mask_fixed<D>(A, ro, x, K);
+
         double L[RP], R[RP], W[NOWN][RP];
 #pragma unroll
         for (int a = 0; a < RP; a++) { L[a] = (a == 0) ? 1.0 : 0.0; R[a] = (a == 0) ? 1.0 : 0.0; }
@@ -323,7 +325,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             V[2 * D] = Vt[NV];
             x[K] = ro[A.xg_off[K] + jn];
             fi[K] = jn;
-            int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
+            int ab = (obs_fixed & obstacle_mask_dim<D>(A, ro, K, x[K])) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
             ab = vary_neighbors(jn, N, bck, ab, lo, hi);

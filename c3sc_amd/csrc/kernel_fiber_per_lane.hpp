@@ -205,6 +205,8 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
             x[m] = ro[A.xg_off[m] + fi[m]];
         }
 
+        const unsigned obs_fixed = obstacle_mask_fixed<D>(A, ro, x, K);
+
         double L[RP], R[RP], WR[NREGa][RP];
 #pragma unroll
         for (int a = 0; a < RP; a++) { L[a] = (a == 0) ? 1.0 : 0.0; R[a] = (a == 0) ? 1.0 : 0.0; }
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
                 x[K] = ro[A.xg_off[K] + jn];
                 fi[K] = jn;
-                int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
+                int ab = (obs_fixed & obstacle_mask_dim<D>(A, ro, K, x[K])) ? -1 : 0;
                 if (fiber_abs) ab = 1;
                 int lo, hi;
                 ab = vary_neighbors(jn, N, bck, ab, lo, hi);

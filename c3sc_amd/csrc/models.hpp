@@ -31,6 +31,8 @@ namespace c3sc {
 struct Dubins3D {
     static constexpr int D = 3, DU = 1;
     static constexpr int NTAB = 2, NCF = 0; // tables: cos(x2), sin(x2)
+    static constexpr unsigned UDEP_MASK = 1u << 2; // dims whose drift/diffusion depend on the control
+    static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double c, s; };
     __device__ static inline void prep(const double *, const double (&)[D], const double *const (&tab)[2], const int (&ix)[D], Node &n)
@@ -56,6 +58,8 @@ struct Dubins3D {
 struct Scar4D {
     static constexpr int D = 4, DU = 2;
     static constexpr int NTAB = 2, NCF = 1; // tables: cos(x2), sin(x2); candidate feature: tan(u0)
+    static constexpr unsigned UDEP_MASK = (1u << 2) | (1u << 3);
+    static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double vc, vs, pre; };
     __device__ static inline void prep(const double *, const double (&x)[D], const double *const (&tab)[2], const int (&ix)[D], Node &n)
@@ -87,6 +91,8 @@ struct Scar4D {
 struct Car7D {
     static constexpr int D = 7, DU = 2;
     static constexpr int NTAB = 3, NCF = 0; // tables: cos(x2), sin(x2), tan(x5)
+    static constexpr unsigned UDEP_MASK = (1u << 5) | (1u << 6);
+    static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int t) { return t == 2 ? 5 : 2; }
     struct Node { double b0, b1, b4; };
     __device__ static inline void prep(const double *, const double (&x)[D], const double *const (&tab)[3], const int (&ix)[D], Node &n)
@@ -120,6 +126,8 @@ template <int DIM>
 struct LqgNd {
     static constexpr int D = DIM, DU = DIM / 2;
     static constexpr int NTAB = 0, NCF = 0;
+    static constexpr unsigned UDEP_MASK = 0xAAAAAAAAu & ((1u << DIM) - 1u); // odd dims are driven by a control
+    static constexpr bool STAGE_UDEP = true;
     __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
     __device__ static inline void prep(const double *, const double (&)[D], const double *const (&)[1], const int (&)[D], Node &) {}
@@ -153,6 +161,8 @@ template <int DIM>
 struct Chain {
     static constexpr int D = DIM, DU = 1;
     static constexpr int NTAB = 0, NCF = 0;
+    static constexpr unsigned UDEP_MASK = 1u << (DIM - 1);
+    static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
     __device__ static inline void prep(const double *, const double (&)[D], const double *const (&)[1], const int (&)[D], Node &) {}

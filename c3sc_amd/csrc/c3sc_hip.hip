@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -102,6 +103,7 @@ struct c3sc_hip_ctx {
     long core_off[MAXD] = {0};
     int obs_off = 0, cands_off = 0, tab_off[4] = {0, 0, 0, 0}, cfeat_off = 0;
     unsigned *d_status = nullptr;
+    unsigned long long *d_dbg = nullptr; // diagnostic stamps (C3SC_DBG & 128)
     int variant = C3SC_VARIANT_AUTO;
     const char *last_kernel = "";
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -191,7 +193,8 @@ static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, 
         if (e.model != model || e.d != d || e.rp < rank_needed || e.max_n < N) continue;
         if (e.k >= 0 && e.k != k) continue;
         if (variant != C3SC_VARIANT_AUTO && e.variant != variant) continue;
-        if (!best || e.rp < best->rp || (e.rp == best->rp && e.variant < best->variant) ||
+        auto pref = [](int v) { return v == C3SC_VARIANT_FIBER_PAIR ? 0 : (v == C3SC_VARIANT_FIBER_PER_WAVE ? 1 : 2); };
+        if (!best || e.rp < best->rp || (e.rp == best->rp && pref(e.variant) < pref(best->variant)) ||
             (e.rp == best->rp && e.variant == best->variant && e.npl < best->npl))
             best = &e;
     }
@@ -443,6 +446,9 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
     for (int i = 0; i < 2 * c->d; i++) A.t[i] = c->t[i];
     for (int i = 0; i < C3SC_MAX_PARAMS; i++) A.prm[i] = c->prm[i];
     A.status = c->d_status;
+    if (!c->d_dbg) { HIPCHK(c, hipMalloc((void **)&c->d_dbg, 65536 * 8 * sizeof(unsigned long long))); }
+    A.dbgbuf = c->d_dbg;
+    { const char *e = getenv("C3SC_DBG"); A.dbg = e ? atoi(e) : 0; if (A.dbg & 8) A.ncand = 1; if (A.dbg & 16) A.ncand = 3; }
     return C3SC_OK;
 }
 
@@ -573,6 +579,13 @@ int c3sc_hip_get_status(c3sc_hip_ctx *c, unsigned *flags, int clear)
     return C3SC_OK;
 }
 
+int c3sc_hip_debug_read(c3sc_hip_ctx *c, unsigned long long *out, size_t n)
+{
+    if (!c || !c->d_dbg || !out) return C3SC_ERR_ARG;
+    HIPCHK(c, hipMemcpy(out, c->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return C3SC_OK;
+}
+
 int c3sc_hip_timer_start(c3sc_hip_ctx *c, void *stream)
 {
     if (!c) return C3SC_ERR_ARG;
@@ -593,7 +606,8 @@ static int run_peak(c3sc_hip_ctx *c, bool mfma, double *tflops)
 {
     if (!c || !tflops) return C3SC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    const int blocks = 256 * 8, threads = 256, iters = 20000;
+    const char *ev = getenv("C3SC_PEAK_BLOCKS_PER_CU");
+    const int blocks = 256 * (ev ? atoi(ev) : 8), threads = 256, iters = 20000;
     int rc = ensure_scratch(c, (size_t)blocks * threads * sizeof(double));
     if (rc != C3SC_OK) return rc;
     float best = 1e30f;

@@ -6,6 +6,13 @@
 
 #include "../../include/c3sc_hip.h"
 
+// in-kernel cycle stamps / ablation switches exist only in diagnostic builds (make STAMPS=1)
+#ifdef C3SC_STAMPS
+#define C3SC_STAMPS_ON 1
+#else
+#define C3SC_STAMPS_ON 0
+#endif
+
 namespace c3sc {
 
 constexpr int MAXD = C3SC_MAX_DIM;
@@ -29,6 +36,8 @@ struct KArgs {
     double t[2 * MAXD];
     double prm[C3SC_MAX_PARAMS];
     unsigned *status;
+    unsigned long long *dbgbuf; // [waves][8] segment cycle sums when (dbg & 128)
+    int dbg; // ablation switches for profiling builds (0 in production): see kernel_fiber_pair.hpp
 };
 
 // Output pointers of one launch (separate __restrict__ kernel parameters).
@@ -137,26 +146,104 @@ __device__ inline unsigned obstacle_mask_dim(const KArgs &A, const double *__res
 
 __device__ __forceinline__ void pin_vgpr(double &x) { asm volatile("" : "+v"(x)); }
 
+// Wave-uniform tables without memory latency: lane l keeps entry l in a VGPR, v_readlane_b32 broadcasts the
+// entry selected by a wave-uniform index into SGPRs (two 32-bit halves per double).
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Lane-distributed per-node data of the varying dimension K (N_K <= 128): coordinate, obstacle k-range
+// mask and the model tables indexed by dim K.  Everything the node loop needs per node is then a
+// v_readlane away instead of a scalar-memory round trip.
+template <class Model, int K>
+struct NodeRegs {
+    static constexpr int NT = Model::NTAB > 0 ? Model::NTAB : 1;
+    __host__ __device__ static constexpr int nkt()
+    { // number of tables indexed by dim K
+        int n = 0;
+        for (int t = 0; t < Model::NTAB; t++) n += (Model::tab_dim(t) == K);
+        return n;
+    }
+    __host__ __device__ static constexpr int kslot(int t)
+    { // slot of table t among the K-indexed tables
+        int n = 0;
+        for (int q = 0; q < t; q++) n += (Model::tab_dim(q) == K);
+        return n;
+    }
+    static constexpr int NKT = nkt() > 0 ? nkt() : 1;
+    double xk[2];
+    unsigned km[2];
+    double tk[NKT][2];
+    __device__ inline void load(const KArgs &A, const double *__restrict__ ro)
+    {
+        constexpr int D = Model::D;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int j = min((int)(threadIdx.x & 63) + 64 * q, A.N - 1);
+            xk[q] = ro[A.xg_off[K] + j];
+            km[q] = obstacle_mask_dim<D>(A, ro, K, xk[q]);
+#pragma unroll
+            for (int t = 0; t < Model::NTAB; t++)
+                if (Model::tab_dim(t) == K) tk[kslot(t)][q] = ro[A.tab_off[t] + j];
+        }
+    }
+    __device__ inline double x_at(int j) const { return j < 64 ? readlane_f64(xk[0], j) : readlane_f64(xk[1], j - 64); }
+    __device__ inline unsigned mask_at(int j) const
+    {
+        return j < 64 ? (unsigned)__builtin_amdgcn_readlane((int)km[0], j) : (unsigned)__builtin_amdgcn_readlane((int)km[1], j - 64);
+    }
+    __device__ inline double tab_at(int t, int j) const
+    {
+        return j < 64 ? readlane_f64(tk[kslot(t)][0], j) : readlane_f64(tk[kslot(t)][1], j - 64);
+    }
+};
+
+// Lane-distributed copy of the control candidates and their features (lane c holds candidate c; ncand <= 64)
+template <class Model>
+struct CandRegs {
+    double u[Model::DU];
+    double cf[Model::NCF > 0 ? Model::NCF : 1];
+    __device__ inline void load(const KArgs &A, const double *__restrict__ ro)
+    {
+        const int c = min((int)(threadIdx.x & 63), A.ncand - 1);
+#pragma unroll
+        for (int i = 0; i < Model::DU; i++) u[i] = ro[A.cands_off + c * Model::DU + i];
+        cf[0] = 0.0;
+#pragma unroll
+        for (int i = 0; i < Model::NCF; i++) cf[i] = ro[A.cfeat_off + c * Model::NCF + i];
+    }
+};
+
+// values of the model's tables at the node with grid indices ix[]
+template <class Model>
+__device__ inline void table_values(const KArgs &A, const double *__restrict__ ro, const int (&ix)[Model::D],
+                                    double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1])
+{
+    tv[0] = 0.0;
+#pragma unroll
+    for (int t = 0; t < Model::NTAB; t++) tv[t] = ro[A.tab_off[t] + ix[Model::tab_dim(t)]];
+}
+
 // One node of the Bellman operator: bellman_optimal (bellman.c:504-543, BRUTEFORCE branch) over
 // bellman_control (:367-480, no-gradient branch) = user dynamics + transition_assemble
 // (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)
 // neighbour in dim m, V[2D] = value at the node.  The candidate scan keeps the first minimum
 // (strict '<'), as the brute-force c3opt is assumed to.
-template <class Model>
+template <class Model, int CG = 1>
 __device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
-                                     const int (&ix)[Model::D], const double (&V)[2 * Model::D + 1], int ab, int &ui,
-                                     unsigned &st)
+                                     const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1], const CandRegs<Model> &cr,
+                                     const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st)
 {
     constexpr int D = Model::D, DU = Model::DU;
     ui = -1;
     if (ab == 1) return Model::boundcost(A.prm, x);  // bellman.c:513-523
     if (ab == -1) return Model::obscost(A.prm, x);   // bellman.c:524-532
-    constexpr int NT = Model::NTAB > 0 ? Model::NTAB : 1;
-    const double *tab[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) tab[t] = ro + A.tab_off[t < Model::NTAB ? t : 0];
     typename Model::Node nd;
-    Model::prep(A.prm, x, tab, ix, nd);
+    Model::prep(A.prm, x, tv, nd);
     // Everything that does not depend on the control is done once per node: the rates of the dims whose
     // drift / diffusion ignore u (Model::UDEP_MASK), their share of Q = sum p and of PV = sum p_i V_i
     // (nodeutil.c:289-309 fused with the ddot of bellman.c:95: rates are accumulated un-normalised; the
@@ -177,17 +264,21 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     {
         double u[DU], b[D], s[D];
 #pragma unroll
-        for (int i = 0; i < DU; i++) u[i] = ro[A.cands_off + i];
-        Model::drift(A.prm, nd, x, u, ro + A.cfeat_off, b);
+        for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], 0);
+        double cf0[Model::NCF > 0 ? Model::NCF : 1];
+        cf0[0] = 0.0;
+#pragma unroll
+        for (int i = 0; i < Model::NCF; i++) cf0[i] = readlane_f64(cr.cf[i], 0);
+        Model::drift(A.prm, nd, x, u, cf0, b);
         Model::sigma(A.prm, x, u, s);
         if constexpr (!Model::STAGE_UDEP) stage0 = Model::stage(A.prm, x, u);
 #pragma unroll
         for (int m = 0; m < D; m++) {
             if (!((UM >> m) & 1u)) {
                 const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
-                double pm = half, pp = half;
-                if (b[m] < -1e-14) pm -= A.t[2 * m] * b[m];
-                else if (b[m] > 1e-14) pp += A.t[2 * m] * b[m];
+                const double tb = A.t[2 * m] * b[m];
+                const double pm = (b[m] < -1e-14) ? half - tb : half;
+                const double pp = (b[m] > 1e-14) ? half + tb : half;
                 Q0 += pm;
                 Q0 += pp;
                 PV0 = fma(pm, V[2 * m], PV0);
@@ -196,41 +287,59 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         }
     }
     double best = 0.0;
-    for (int c = 0; c < A.ncand; c++) {
-        double u[DU];
+    constexpr int NCFa = Model::NCF > 0 ? Model::NCF : 1;
+    // Candidates are evaluated CG at a time (CG = 1 where registers are tight): one candidate is a ~40-deep chain of dependent f64 operations
+    // (rates -> Q -> 1/Q -> dt -> value), and with one or two wavefronts per SIMD nothing else hides that
+    // latency, so independent candidates are interleaved.  The scan order / strict '<' is kept.
+    for (int c0 = 0; c0 < A.ncand; c0 += CG) {
+        double val[CG];
+        bool ok[CG];
 #pragma unroll
-        for (int i = 0; i < DU; i++) u[i] = ro[A.cands_off + c * DU + i];
-        double b[D], s[D];
-        Model::drift(A.prm, nd, x, u, ro + A.cfeat_off + c * Model::NCF, b);
-        Model::sigma(A.prm, x, u, s);
-        const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
-        double Q = Q0, PV = PV0;
+        for (int q = 0; q < CG; q++) {
+            const int c = (c0 + q < A.ncand) ? c0 + q : A.ncand - 1;
+            double u[DU], cf[NCFa];
 #pragma unroll
-        for (int m = 0; m < D; m++) {
-            if ((UM >> m) & 1u) {
-                const double half = t2l[m] * (s[m] * s[m]) / 2.0;
-                double pm = half, pp = half;
-                if (b[m] < -1e-14) pm -= tl[m] * b[m];
-                else if (b[m] > 1e-14) pp += tl[m] * b[m];
-                Q += pm;
-                Q += pp;
-                PV = fma(pm, V[2 * m], PV);
-                PV = fma(pp, V[2 * m + 1], PV);
+            for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
+            cf[0] = 0.0;
+#pragma unroll
+            for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
+            double b[D], s[D];
+            Model::drift(A.prm, nd, x, u, cf, b);
+            Model::sigma(A.prm, x, u, s);
+            const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
+            double Q = Q0, PV = PV0;
+#pragma unroll
+            for (int m = 0; m < D; m++) {
+                if ((UM >> m) & 1u) {
+                    const double half = t2l[m] * (s[m] * s[m]) / 2.0;
+                    // branch-free upwinding with the +-1e-14 dead zone of nodeutil.c:300-305
+                    const double tb = tl[m] * b[m];
+                    const double pm = (b[m] < -1e-14) ? half - tb : half;
+                    const double pp = (b[m] > 1e-14) ? half + tb : half;
+                    Q += pm;
+                    Q += pp;
+                    PV = fma(pm, V[2 * m], PV);
+                    PV = fma(pp, V[2 * m + 1], PV);
+                }
             }
+            ok[q] = !(Q < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
+            const double Qs = ok[q] ? Q : 1.0;
+            const double inv = 1.0 / Qs;
+            const double dt = h2l * inv;               // nodeutil.c:369
+            const double pself = fma(-Qs, inv, 1.0);   // 1 - sum_i p_i/Q: rounding residue, as in the reference
+            const double ctg = fma(pself, V[2 * D], PV * inv);
+            const double ebt = (A.discount == 0.0) ? 1.0 : exp(-discl * dt); // bellman.c:94
+            val[q] = dt * stage + ebt * ctg;                                 // bellman.c:97
         }
-        if (Q < 1e-14) { // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
-            st |= C3SC_STATUS_STATIONARY;
-            continue;
-        }
-        const double inv = 1.0 / Q;
-        const double dt = h2l * inv;               // nodeutil.c:369
-        const double pself = fma(-Q, inv, 1.0);    // 1 - sum_i p_i/Q: rounding residue, as in the reference
-        const double ctg = fma(pself, V[2 * D], PV * inv);
-        const double ebt = (A.discount == 0.0) ? 1.0 : exp(-discl * dt);      // bellman.c:94
-        const double val = dt * stage + ebt * ctg;                            // bellman.c:97
-        if (ui < 0 || val < best) {
-            best = val;
-            ui = c;
+#pragma unroll
+        for (int q = 0; q < CG; q++) {
+            if (c0 + q < A.ncand) {
+                if (!ok[q]) st |= C3SC_STATUS_STATIONARY;
+                else if (ui < 0 || val[q] < best) {
+                    best = val[q];
+                    ui = c0 + q;
+                }
+            }
         }
     }
     return best;

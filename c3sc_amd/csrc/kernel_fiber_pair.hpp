@@ -36,10 +36,10 @@ __device__ inline void stage_core_n(double *sK, const double *__restrict__ src, 
 }
 
 __device__ inline void pair_barrier()
-{ // workgroup barrier + LDS visibility between the two wavefronts
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+{ // workgroup barrier + LDS visibility between the two wavefronts.  Only LDS traffic is exchanged, so only
+  // lgkmcnt is drained: a workgroup-scope release fence would also wait (vmcnt(0)) for the scattered
+  // output stores of the previous node, which costs microseconds per barrier.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // which wave folds the neighbour pair of dim m (m != K): alternate by distance from K so the O(distance)
@@ -83,6 +83,13 @@ __device__ inline void dimk_values(int jn, int N, int bck, double vL, double vC,
     }
 }
 
+#define FPP_STAMP(slot)                                                   \
+    if (C3SC_STAMPS_ON && (A.dbg & 128)) {                                \
+        const unsigned long long now__ = clock64();                       \
+        seg[slot] += now__ - tlast;                                       \
+        tlast = now__;                                                    \
+    }
+
 template <class Model, int RP, int K, int H>
 __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArgs &A, const double *__restrict__ ro,
                                                                      const int32_t *__restrict__ idx, double *__restrict__ outv,
@@ -101,8 +108,14 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
     const int lane = threadIdx.x & 63;
     const int N = A.N;
     const long ntiles = (A.F + 63) / 64;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+    CandRegs<Model> cr;
+    cr.load(A, ro);
+    NodeRegs<Model, K> nr;
+    nr.load(A, ro);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        FPP_STAMP(7)
         const long f_raw = tile * 64 + lane;
         const bool live = f_raw < A.F;
         const long f = live ? f_raw : A.F - 1;
@@ -119,12 +132,16 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         }
 
         const unsigned obs_fixed = obstacle_mask_fixed<D>(A, ro, x, K);
+        double tv[Model::NTAB > 0 ? Model::NTAB : 1]; // model tables: constant along the fiber unless indexed by dim K
+        table_values<Model>(A, ro, fi, tv);
 
         double L[RP], R[RP], W[NOWN][RP];
 #pragma unroll
         for (int a = 0; a < RP; a++) { L[a] = (a == 0) ? 1.0 : 0.0; R[a] = (a == 0) ? 1.0 : 0.0; }
 
         // ------------------------------------------------------------ fold the prefix side
+        FPP_STAMP(0) // tile setup
+        if (!(C3SC_STAMPS_ON && (A.dbg & 1))) {
         if constexpr (K > 0) {
             {
                 constexpr int str = fpl_lds_stride(RP);
@@ -218,6 +235,8 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             (std::make_integer_sequence<int, (D - 2 - K > 0 ? D - 2 - K : 0)>{});
         }
 
+        } // dbg & 1
+        FPP_STAMP(1) // folding
         // ------------------------------------------------------------ swap halves: Wh[g][i] = component H*RH + i of vector g
         double Wh[NV][RH];
         {
@@ -229,8 +248,6 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                     constexpr int slot = (m < K) ? 2 * own_left_before<D, K, H>(m) : NOL + 2 * own_right_after<D, K, H>(m);
 #pragma unroll
                     for (int s = 0; s < 2; s++) {
-                        constexpr int dummy = 0;
-                        (void)dummy;
                         const int g = gvec<K>(m, s);
 #pragma unroll
                         for (int i = 0; i < RH; i++) {
@@ -258,32 +275,46 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             (std::make_integer_sequence<int, D>{});
             pair_barrier();
         }
+        // L and R move to LDS (rows of 64 lanes): both waves hold the same values, wave 0 stores L, wave 1 R.
+        // The node loop re-reads them per use; that frees 2*RP*2 VGPRs for the 256-register budget.
+        double *sL = sK, *sR = sK + RP * 64;
+        {
+#pragma unroll
+            for (int a = 0; a < RP; a++) {
+                if constexpr (H == 0) sL[a * 64 + lane] = L[a];
+                else sR[a * 64 + lane] = R[a];
+            }
+            pair_barrier();
+        }
+        FPP_STAMP(2) // half swap
 
         // ------------------------------------------------------------ node loop
         const int bck = A.bctype[K];
         const double *Gk = ro + A.core_off[K];
-        // partial sums of node j owned by this wave: P[g] for the NV neighbour vectors, P[NV] = node value
-        auto partials = [&](int j, double (&P)[NP]) __attribute__((always_inline)) {
+        // partial sums of node j owned by this wave, stored straight to LDS rows dst[g*64 + lane]:
+        // g < NV neighbour values, g = NV the node value; the node-value partial is also returned
+        auto partials = [&](int j, double *dst) __attribute__((always_inline)) -> double {
+            double pv;
             if constexpr (K == 0) { // G_0[j] is a 1 x r row: a = row, no left vectors
                 double ah[RH];
 #pragma unroll
                 for (int i = 0; i < RH; i++) ah[i] = Gk[(size_t)j * RP + H * RH + i];
                 double v = 0.0;
 #pragma unroll
-                for (int i = 0; i < RH; i++) v = fma(ah[i], R[H * RH + i], v);
-                P[NV] = v;
+                for (int i = 0; i < RH; i++) v = fma(ah[i], sR[(H * RH + i) * 64 + lane], v);
+                pv = v;
 #pragma unroll
-                for (int g = 0; g < NV; g++) P[g] = dot_reg<RH>(ah, Wh[g]);
+                for (int g = 0; g < NV; g++) dst[g * 64 + lane] = dot_reg<RH>(ah, Wh[g]);
             } else if constexpr (K == D - 1) { // G_{d-1}[j] is an r x 1 column: c = column, no right vectors
                 double ch[RH];
 #pragma unroll
                 for (int i = 0; i < RH; i++) ch[i] = Gk[(size_t)j * RP + H * RH + i];
                 double v = 0.0;
 #pragma unroll
-                for (int i = 0; i < RH; i++) v = fma(L[H * RH + i], ch[i], v);
-                P[NV] = v;
+                for (int i = 0; i < RH; i++) v = fma(sL[(H * RH + i) * 64 + lane], ch[i], v);
+                pv = v;
 #pragma unroll
-                for (int g = 0; g < NV; g++) P[g] = dot_reg<RH>(Wh[g], ch);
+                for (int g = 0; g < NV; g++) dst[g * 64 + lane] = dot_reg<RH>(Wh[g], ch);
             } else {
                 const double *G = Gk + (size_t)j * RP * RP;
                 double ch[RH], ah[RH];
@@ -291,30 +322,37 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 for (int i = 0; i < RH; i++) { ch[i] = 0.0; ah[i] = 0.0; }
                 // c_h[i] = sum_b G[H*RH+i, b] R[b]
 #pragma unroll
-                for (int b = 0; b < RP; b++)
+                for (int b = 0; b < RP; b++) {
+                    const double rb = sR[b * 64 + lane];
 #pragma unroll
-                    for (int i = 0; i < RH; i++) ch[i] = fma(G[H * RH + i + b * RP], R[b], ch[i]);
+                    for (int i = 0; i < RH; i++) ch[i] = fma(G[H * RH + i + b * RP], rb, ch[i]);
+                }
                 // a_h[i] = sum_a L[a] G[a, H*RH+i]
 #pragma unroll
-                for (int i = 0; i < RH; i++)
+                for (int a = 0; a < RP; a++) {
+                    const double la = sL[a * 64 + lane];
 #pragma unroll
-                    for (int a = 0; a < RP; a++) ah[i] = fma(L[a], G[a + (H * RH + i) * RP], ah[i]);
+                    for (int i = 0; i < RH; i++) ah[i] = fma(la, G[a + (H * RH + i) * RP], ah[i]);
+                }
                 double v = 0.0;
 #pragma unroll
-                for (int i = 0; i < RH; i++) v = fma(L[H * RH + i], ch[i], v);
-                P[NV] = v;
+                for (int i = 0; i < RH; i++) v = fma(sL[(H * RH + i) * 64 + lane], ch[i], v);
+                pv = v;
 #pragma unroll
-                for (int g = 0; g < 2 * K; g++) P[g] = dot_reg<RH>(Wh[g], ch);
+                for (int g = 0; g < 2 * K; g++) dst[g * 64 + lane] = dot_reg<RH>(Wh[g], ch);
 #pragma unroll
-                for (int g = 2 * K; g < NV; g++) P[g] = dot_reg<RH>(ah, Wh[g]);
+                for (int g = 2 * K; g < NV; g++) dst[g * 64 + lane] = dot_reg<RH>(ah, Wh[g]);
             }
+            dst[NV * 64 + lane] = pv;
+            return pv;
         };
-        // LDS exchange slots (doubles): each value is a row of 64 lanes
-        double *B0 = sK;                 // wave 0 -> wave 1 : P_0(j1)[NP], then v_0(j0)
-        double *B1 = sK + (NP + 1) * 64; // wave 1 -> wave 0 : P_1(j0)[NP], then v_1(j1)
-        double *B2 = B1 + (NP + 1) * 64; // wave 1 own       : P_1(j1)[NP]
+        // LDS exchange rows after L/R
+        double *B0 = sK + 2 * RP * 64;    // wave 0 -> wave 1 : P_0(j1)[NP], then v_0(j0)
+        double *B1 = B0 + (NP + 1) * 64;  // wave 1 -> wave 0 : P_1(j0)[NP], then v_1(j1)
+        double *B2 = B1 + (NP + 1) * 64;  // wave 1 own       : P_1(j1)[NP]
+        double *B3 = B2 + NP * 64;        // wave 0 own       : P_0(j0)[NP]
 
-        // finalise one node: V holds the NV neighbour values in gvec order and the node value in V[NV]
+        // finalise one node from its assembled stencil (NV neighbour values in gvec order, node value last)
         auto finalize = [&](int jn, const double (&Vt)[NP], double vlo, double vhi) __attribute__((always_inline)) {
             double V[S];
 #pragma unroll
@@ -323,14 +361,16 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 else { V[2 * m] = Vt[gvec<K>(m, 0)]; V[2 * m + 1] = Vt[gvec<K>(m, 1)]; }
             }
             V[2 * D] = Vt[NV];
-            x[K] = ro[A.xg_off[K] + jn];
-            fi[K] = jn;
-            int ab = (obs_fixed & obstacle_mask_dim<D>(A, ro, K, x[K])) ? -1 : 0;
+            x[K] = nr.x_at(jn);
+#pragma unroll
+            for (int t = 0; t < Model::NTAB; t++)
+                if (Model::tab_dim(t) == K) tv[t] = nr.tab_at(t, jn); // wave-uniform
+            int ab = (obs_fixed & nr.mask_at(jn)) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
             ab = vary_neighbors(jn, N, bck, ab, lo, hi);
             int ui;
-            const double val = node_backup<Model>(A, ro, x, fi, V, ab, ui, st);
+            const double val = node_backup<Model, 1>(A, ro, x, tv, cr, V, ab, ui, st);
             if (live) {
                 outv[(size_t)f * N + jn] = val;
                 if (uidx) uidx[(size_t)f * N + jn] = ui;
@@ -341,14 +381,14 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         // value of node N-2 (left neighbour of node 0 under a periodic boundary)
         double vwrap = 0.0;
         if (bck == C3SC_PERIODIC) {
-            double P[NP];
-            partials(N - 2, P);
-            sK[H * 64 + lane] = P[NV];
+            const double pv = partials(N - 2, H == 0 ? B3 : B2);
+            B0[(NP + H) * 64 + lane] = pv; // two spare slots: B0[NP] (wave 0) and B1[0].. use B0[NP] / B1[NP]
+            if constexpr (H == 1) B1[NP * 64 + lane] = pv;
             pair_barrier();
-            vwrap = P[NV] + sK[(1 - H) * 64 + lane];
+            vwrap = pv + (H == 0 ? B1[NP * 64 + lane] : B0[NP * 64 + lane]);
             pair_barrier();
         }
-        double vone = 0.0;            // v[1]
+        double vone = 0.0;             // v[1]
         double v_m2 = 0.0, v_m1 = 0.0; // v[2t-2], v[2t-1]
         double Vd[NP];                 // wave 1: stencil of node 2t-1 waiting for v[2t]
 #pragma unroll
@@ -358,37 +398,25 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         for (int t = 0; t < T; t++) {
             const int j0 = 2 * t, j1 = 2 * t + 1;
             const bool has0 = j0 < N, has1 = j1 < N;
-            double P0[NP], pv0 = 0.0, pv1 = 0.0;
+            double pv0 = 0.0, pv1 = 0.0;
             if (has0) {
-                partials(j0, P0);
-                pv0 = P0[NV];
-                if constexpr (H == 1) {
-#pragma unroll
-                    for (int g = 0; g < NP; g++) B1[g * 64 + lane] = P0[g];
-                } else {
-                    B0[NP * 64 + lane] = pv0;
-                }
+                pv0 = partials(j0, H == 0 ? B3 : B1);
+                if constexpr (H == 0) B0[NP * 64 + lane] = pv0;
             }
             if (has1) {
-                double P1[NP];
-                partials(j1, P1);
-                pv1 = P1[NV];
-                if constexpr (H == 0) {
-#pragma unroll
-                    for (int g = 0; g < NP; g++) B0[g * 64 + lane] = P1[g];
-                } else {
-#pragma unroll
-                    for (int g = 0; g < NP; g++) B2[g * 64 + lane] = P1[g];
-                    B1[NP * 64 + lane] = pv1;
-                }
+                pv1 = partials(j1, H == 0 ? B0 : B2);
+                if constexpr (H == 1) B1[NP * 64 + lane] = pv1;
             }
+            FPP_STAMP(3) // partials + LDS writes
             pair_barrier();
+            FPP_STAMP(4) // barrier 1
             double v0 = 0.0, v1 = 0.0; // totals v[j0], v[j1]
             if constexpr (H == 0) {
                 if (has1) v1 = pv1 + B1[NP * 64 + lane];
                 if (has0) {
+                    double P0[NP];
 #pragma unroll
-                    for (int g = 0; g < NP; g++) P0[g] += B1[g * 64 + lane];
+                    for (int g = 0; g < NP; g++) P0[g] = B3[g * 64 + lane] + B1[g * 64 + lane];
                     v0 = P0[NV];
                     double vlo, vhi;
                     dimk_values(j0, N, bck, v_m1, v0, v1, vwrap, (j0 == 0 ? v1 : vone), vlo, vhi);
@@ -411,8 +439,15 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             if (t == 0) vone = v1;
             v_m2 = v0;
             v_m1 = v1;
+            FPP_STAMP(5) // LDS reads + finalize
             pair_barrier();
+            FPP_STAMP(6) // barrier 2
         }
+    }
+    if (C3SC_STAMPS_ON && (A.dbg & 128) && lane == 0) {
+        const size_t w = ((size_t)blockIdx.x * 2 + H) * 8;
+        if (w < 65536 * 8)
+            for (int i = 0; i < 8; i++) A.dbgbuf[w + i] = seg[i];
     }
 }
 

@@ -187,6 +187,17 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
     const int tid = threadIdx.x;
     unsigned st = 0;
     const long ntiles = (A.F + FPL_THREADS - 1) / FPL_THREADS;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define FPL_STAMP(slot)                                                   \
+    if (C3SC_STAMPS_ON && (A.dbg & 128)) {                                \
+        const unsigned long long now__ = clock64();                       \
+        seg[slot] += now__ - tlast;                                       \
+        tlast = now__;                                                    \
+    }
+    CandRegs<Model> cr;
+    cr.load(A, ro);
+    NodeRegs<Model, K> nr;
+    nr.load(A, ro);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long f_raw = tile * FPL_THREADS + threadIdx.x;
@@ -206,6 +217,8 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
         }
 
         const unsigned obs_fixed = obstacle_mask_fixed<D>(A, ro, x, K);
+        double tv[Model::NTAB > 0 ? Model::NTAB : 1]; // model tables: constant along the fiber unless indexed by dim K
+        table_values<Model>(A, ro, fi, tv);
 
         double L[RP], R[RP], WR[NREGa][RP];
 #pragma unroll
@@ -233,6 +246,7 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
             }
         };
 
+        FPL_STAMP(0) // tile setup
         // ---- prefix side: fold cores 0..K-1 into L and the left neighbour vectors (g = 2m + s)
         if constexpr (K > 0) {
             { // core 0 is a 1 x r row per node
@@ -346,24 +360,32 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
             (std::make_integer_sequence<int, (D - 2 - K > 0 ? D - 2 - K : 0)>{});
         }
 
+        FPL_STAMP(1) // folding
         // ---- node loop: FT values of node j, then (delayed by one node) the Bellman backup of node j-1
         const int bck = A.bctype[K];
         const double *Gk = ro + A.core_off[K];
         // dot of neighbour vector g with a register vector
         auto vdot = [&](auto gc, const double (&u)[RP]) __attribute__((always_inline)) -> double {
             constexpr int g = decltype(gc)::value;
-            double acc = 0.0;
+            double acc0 = 0.0, acc1 = 0.0; // two chains per dot: halves the dependent-FMA latency
             if constexpr (g < NLDS) {
 #pragma unroll
-                for (int c = 0; c < RP; c++)
-                    acc = fma(sW[(((size_t)g * (RPe / 2) + c / 2) * FPL_THREADS + tid) * 2 + (c & 1)], u[c], acc);
+                for (int c = 0; c < RP; c += 2) {
+                    acc0 = fma(sW[(((size_t)g * (RPe / 2) + c / 2) * FPL_THREADS + tid) * 2], u[c], acc0);
+                    if (c + 1 < RP) acc1 = fma(sW[(((size_t)g * (RPe / 2) + c / 2) * FPL_THREADS + tid) * 2 + 1], u[c + 1], acc1);
+                }
+                double acc = acc0 + acc1;
                 pin(acc);
-                mem_fence();
+                if constexpr (g % 3 == 2 || g == NLDS - 1) mem_fence(); // at most 3 vectors of LDS loads in flight
+                return acc;
             } else {
 #pragma unroll
-                for (int c = 0; c < RP; c++) acc = fma(WR[g - NLDS][c], u[c], acc);
+                for (int c = 0; c < RP; c += 2) {
+                    acc0 = fma(WR[g - NLDS][c], u[c], acc0);
+                    if (c + 1 < RP) acc1 = fma(WR[g - NLDS][c + 1], u[c + 1], acc1);
+                }
+                return acc0 + acc1;
             }
-            return acc;
         };
         // value of one node only (needed ahead of time for the periodic wrap: lo(0) = N-2)
         auto node_value = [&](int j) __attribute__((always_inline)) -> double {
@@ -440,6 +462,7 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 V[2 * K + 1] = 0.0;
                 if (j == 1) v_one = vj;
             }
+            FPL_STAMP(2) // FT of node j
             if (j >= 1) { // node j-1 now knows both neighbours along dim K (nodeutil.c:570-624)
                 const int jn = j - 1;
                 double vlo = v_pp, vhi = vj;
@@ -454,20 +477,23 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 Vp[2 * K] = vlo;
                 Vp[2 * K + 1] = vhi;
                 // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
-                x[K] = ro[A.xg_off[K] + jn];
-                fi[K] = jn;
-                int ab = (obs_fixed & obstacle_mask_dim<D>(A, ro, K, x[K])) ? -1 : 0;
+                x[K] = nr.x_at(jn);
+#pragma unroll
+                for (int t = 0; t < Model::NTAB; t++)
+                    if (Model::tab_dim(t) == K) tv[t] = nr.tab_at(t, jn); // wave-uniform
+                int ab = (obs_fixed & nr.mask_at(jn)) ? -1 : 0;
                 if (fiber_abs) ab = 1;
                 int lo, hi;
                 ab = vary_neighbors(jn, N, bck, ab, lo, hi);
                 int ui;
-                const double val = node_backup<Model>(A, ro, x, fi, Vp, ab, ui, st);
+                const double val = node_backup<Model, 3>(A, ro, x, tv, cr, Vp, ab, ui, st);
                 if (live) {
                     outv[(size_t)f * N + jn] = val;
                     if (uidx) uidx[(size_t)f * N + jn] = ui;
                     if (absorbed) absorbed[(size_t)f * N + jn] = ab;
                 }
             }
+            FPL_STAMP(3) // backup of node j-1
             if (j < N) {
 #pragma unroll
                 for (int s = 0; s < S; s++) Vp[s] = V[s];
@@ -475,6 +501,11 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 v_p = vj;
             }
         }
+    }
+    if (C3SC_STAMPS_ON && (A.dbg & 128) && (threadIdx.x & 63) == 0) {
+        const size_t w = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+        if (w < 65536 * 8)
+            for (int i = 0; i < 8; i++) A.dbgbuf[w + i] = seg[i];
     }
     if (st) atomicOr(A.status, st);
 }

@@ -100,6 +100,8 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
 
     const int sel = lane / RP, bb = lane - sel * RP; // (vector, component) role in the per-fiber setup
+    CandRegs<Model> cr;
+    if constexpr (!STENCIL) cr.load(A, ro);
     unsigned st = 0;
 
     for (long f = (long)blockIdx.x * 4 + wv; f < A.F; f += (long)gridDim.x * 4) {
@@ -299,7 +301,9 @@ __global__ void __launch_bounds__(256)
                 }
             } else {
                 int ui;
-                const double val = node_backup<Model>(A, ro, x, ix, V, ab, ui, st);
+                double tv[Model::NTAB > 0 ? Model::NTAB : 1];
+                table_values<Model>(A, ro, ix, tv);
+                const double val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st);
                 if (live) {
                     outv[(size_t)f * N + j] = val;
                     if (uidx) uidx[(size_t)f * N + j] = ui;

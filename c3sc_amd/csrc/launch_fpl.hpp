@@ -48,7 +48,7 @@ hipError_t launch_fpl(const KArgs &A, const LaunchIO &io)
 
 #define C3SC_REG_FPL1(MODEL_ID, RP, K, ...)                                                                   \
     static Registrar C3SC_CAT(reg_fpl_, __COUNTER__)(KernelEntry{                                             \
-        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_PER_LANE, 1 << 20, K, &launch_fpl<__VA_ARGS__, RP, K>, \
+        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_PER_LANE, 128, K, &launch_fpl<__VA_ARGS__, RP, K>, \
         "k_fiber_per_lane<" #__VA_ARGS__ "," #RP ",K=" #K ">"});
 
 } // namespace c3sc

@@ -12,7 +12,7 @@ hipError_t launch_fpp(const KArgs &A, const LaunchIO &io)
     constexpr int NV = 2 * (D - 1), NP = NV + 1, RH = RP / 2;
     // LDS: max(largest staged fixed core, half-swap buffer, per-node exchange buffers)
     size_t doubles = (size_t)NV * RH * 64;
-    const size_t exch = (size_t)((NP + 1) * 2 + NP) * 64;
+    const size_t exch = (size_t)(2 * RP + (NP + 1) * 2 + 2 * NP) * 64; // L, R rows + exchange rows
     if (exch > doubles) doubles = exch;
     for (int m = 0; m < D; m++) {
         if (m == K) continue;
@@ -47,7 +47,7 @@ hipError_t launch_fpp(const KArgs &A, const LaunchIO &io)
 
 #define C3SC_REG_FPP1(MODEL_ID, RP, K, ...)                                                                   \
     static Registrar C3SC_CAT(reg_fpp_, __COUNTER__)(KernelEntry{                                             \
-        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_PAIR, 1 << 20, K, &launch_fpp<__VA_ARGS__, RP, K>, \
+        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_PAIR, 128, K, &launch_fpp<__VA_ARGS__, RP, K>, \
         "k_fiber_pair<" #__VA_ARGS__ "," #RP ",K=" #K ">"});
 
 } // namespace c3sc

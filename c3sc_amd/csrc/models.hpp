@@ -17,7 +17,7 @@
 //   NTAB, tab_dim(t)            number of tables and the dimension each one is indexed by
 //   NCF                         number of per-candidate features
 //   Node                        per-node invariants computed once per node, not per control
-//   prep(prm, x, tab, ix, node) tab[t] = pointer to table t, ix[m] = grid index of the node in dim m
+//   prep(prm, x, tv, node)      tv[t] = value of table t at this node (the kernel looks it up)
 //   drift(prm, node, x, u, cf, b)   b[D]; cf = this candidate's features
 //   sigma(prm, x, u, s)         s[D] diagonal of the diffusion
 //   stage(prm, x, u)            stage cost
@@ -35,10 +35,10 @@ struct Dubins3D {
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double c, s; };
-    __device__ static inline void prep(const double *, const double (&)[D], const double *const (&tab)[2], const int (&ix)[D], Node &n)
+    __device__ static inline void prep(const double *, const double (&)[D], const double (&tv)[2], Node &n)
     {
-        n.c = tab[0][ix[2]];
-        n.s = tab[1][ix[2]];
+        n.c = tv[0];
+        n.s = tv[1];
     }
     __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, const double *,
                                         double (&b)[D])
@@ -62,13 +62,13 @@ struct Scar4D {
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double vc, vs, pre; };
-    __device__ static inline void prep(const double *, const double (&x)[D], const double *const (&tab)[2], const int (&ix)[D], Node &n)
+    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[2], Node &n)
     {
         const double speed = x[3];
         const double L = 0.2, vcar = 8.0;
         n.pre = (1.0 / (1.0 + (speed / vcar))) * (speed / L);
-        n.vc = speed * tab[0][ix[2]];
-        n.vs = speed * tab[1][ix[2]];
+        n.vc = speed * tv[0];
+        n.vs = speed * tv[1];
     }
     __device__ static inline void drift(const double *, const Node &n, const double (&)[D], const double *u, const double *cf,
                                         double (&b)[D])
@@ -95,12 +95,12 @@ struct Car7D {
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int t) { return t == 2 ? 5 : 2; }
     struct Node { double b0, b1, b4; };
-    __device__ static inline void prep(const double *, const double (&x)[D], const double *const (&tab)[3], const int (&ix)[D], Node &n)
+    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[3], Node &n)
     {
         const double v = x[3], om = x[4];
-        n.b0 = v * tab[0][ix[2]];
-        n.b1 = v * tab[1][ix[2]];
-        n.b4 = (v / (0.2 * (1.0 + v / 8.0)) * tab[2][ix[5]] - om) / 0.5;
+        n.b0 = v * tv[0];
+        n.b1 = v * tv[1];
+        n.b4 = (v / (0.2 * (1.0 + v / 8.0)) * tv[2] - om) / 0.5;
     }
     __device__ static inline void drift(const double *, const Node &n, const double (&x)[D], const double *u, const double *,
                                         double (&b)[D])
@@ -130,7 +130,7 @@ struct LqgNd {
     static constexpr bool STAGE_UDEP = true;
     __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
-    __device__ static inline void prep(const double *, const double (&)[D], const double *const (&)[1], const int (&)[D], Node &) {}
+    __device__ static inline void prep(const double *, const double (&)[D], const double (&)[1], Node &) {}
     __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, const double *,
                                         double (&b)[D])
     {
@@ -165,7 +165,7 @@ struct Chain {
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
-    __device__ static inline void prep(const double *, const double (&)[D], const double *const (&)[1], const int (&)[D], Node &) {}
+    __device__ static inline void prep(const double *, const double (&)[D], const double (&)[1], Node &) {}
     __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, const double *,
                                         double (&b)[D])
     {
@@ -195,6 +195,7 @@ struct Chain {
 template <int DIM>
 struct NoModel {
     static constexpr int D = DIM, DU = 1;
+    static constexpr int NTAB = 0, NCF = 0;
 };
 
 } // namespace c3sc

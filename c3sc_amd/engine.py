@@ -28,7 +28,7 @@ EXPORTS = [
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
     "c3sc_hip_bellman_fibers", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
     "c3sc_hip_stencil_fibers_host", "c3sc_hip_stencil_fibers_nb", "c3sc_hip_stencil_fibers_nb_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
-    "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
+    "c3sc_hip_debug_read", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]
 
 VARIANT_AUTO, VARIANT_FIBER_PER_WAVE, VARIANT_FIBER_PER_LANE, VARIANT_FIBER_PAIR = 0, 1, 2, 3
@@ -261,6 +261,11 @@ class BellmanEngine:
         ms = C.c_float(0)
         self._chk(self.L.c3sc_hip_timer_stop(self.h, C.c_void_p(stream_ptr), C.byref(ms)), "timer_stop")
         return ms.value
+
+    def debug_read(self, n: int) -> np.ndarray:
+        buf = np.zeros(n, dtype=np.uint64)
+        self._chk(self.L.c3sc_hip_debug_read(self.h, C.c_void_p(buf.ctypes.data), C.c_size_t(n)), "debug_read")
+        return buf
 
     def peak_fma_f64(self) -> float:
         v = C.c_double(0)

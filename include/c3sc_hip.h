@@ -131,6 +131,9 @@ int c3sc_hip_get_status(c3sc_hip_ctx *ctx, unsigned *flags, int clear);
 /* name of the kernel the last launch used (for profiles) */
 const char *c3sc_hip_last_kernel(const c3sc_hip_ctx *ctx);
 
+/* diagnostic builds only (C3SC_DBG & 128): per-wave segment cycle sums written by the kernels */
+int c3sc_hip_debug_read(c3sc_hip_ctx *ctx, unsigned long long *out, size_t n);
+
 /* device-side timing on `stream` with HIP events (used by bench.py's roofline leg) */
 int c3sc_hip_timer_start(c3sc_hip_ctx *ctx, void *stream);
 int c3sc_hip_timer_stop(c3sc_hip_ctx *ctx, void *stream, float *ms);

@@ -152,6 +152,23 @@ def main():
     bytes_per_node = float(np.mean([wl.algorithmic_bytes_per_node(w, k) for k in range(d)]))
     hbm_gbs = bytes_per_node * nodes_per_launch / (avg_ms * 1e-3) / 1e9
 
+    # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
+    # runs; FETCH x2 per the gfx950 correction of MI355X_MICROARCH.md) cannot be collected from inside this
+    # process, so the committed summary of the same command is read (profiles/README.md says how it was made).
+    traffic, traffic_src = None, None
+    try:
+        if args.workload == "car7d" and F == (1 << 17):
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_b_fiber_pair_pmc.json")))
+            ks = [v for kname, v in pm["kernels"].items() if "k_fiber_pair" in kname]
+            if ks and "fiber_pair" in eng.last_kernel():
+                traffic = float(np.mean([v["fetch_bytes_x2_gfx950_correction"] + v["write_bytes_per_launch"] for v in ks]))
+                traffic_src = "profiles/r01_b_fiber_pair_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2)"
+    except (OSError, KeyError, ValueError):
+        pass
+    kern = eng.last_kernel()
+    if "K=" in kern:
+        kern = kern[: kern.index("K=")] + "K=0..%d>" % (d - 1)
+
     if rank == 0:
         res = {
             "metric": "Bellman-sweep nodes/sec (7D car rank-10)" if args.workload == "car7d" else f"Bellman-sweep nodes/sec ({w.name})",
@@ -175,8 +192,9 @@ def main():
             "kernel_status_flags": status,
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": None,
-                "kernel": eng.last_kernel(), "avg_launch_ms": avg_ms, "launches": len(kms),
+                "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_node * nodes_per_launch,
+                "kernel": kern, "avg_launch_ms": avg_ms, "launches": len(kms),
                 "algorithmic_flops_per_node": Wf, "nodes_per_launch": nodes_per_launch,
                 "note": "FP64 compute bound (vector FMA path; dense f64 MFMA peak is the same 78.6 TFLOP/s datasheet figure)",
                 "hbm_secondary": {"algorithmic_bytes_per_node": bytes_per_node, "achieved_GBs": hbm_gbs,

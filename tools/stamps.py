@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["C3SC_DBG"] = os.environ.get("C3SC_DBG", "128")
 import torch
 from c3sc_amd import workloads as wl

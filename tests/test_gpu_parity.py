@@ -48,12 +48,13 @@ def _check(eng, P, w, k, idx):
     return err / scale
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["auto", "fiber_per_wave"])
 @pytest.mark.parametrize("name,kw", SMALL, ids=[f"{n}-r{k['rank']}-{i}" for i, (n, k) in enumerate(SMALL)])
-def test_bellman_fibers_vs_oracle(oracle, name, kw):
+def test_bellman_fibers_vs_oracle(oracle, name, kw, variant):
     w = wl.WORKLOADS[name]().scaled(**kw)
     cores = wl.synth_cores(w)
     P = oracle.Problem(w, cores)
-    eng = _engine(w, cores)
+    eng = _engine(w, cores, variant)
     for k in range(w.dx):
         idx = wl.synth_fibers(w, k, 37)
         # make sure boundary faces / wrap-around are exercised

@@ -209,6 +209,10 @@ static int pick_rp(int d, int maxrank)
     return rp;
 }
 
+static int ensure_scratch(c3sc_hip_ctx *c, size_t bytes);
+static size_t align256(size_t x);
+static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model);
+
 extern "C" {
 
 int c3sc_hip_device_count(void)
@@ -463,8 +467,58 @@ int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_i
     const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant, k);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
-    LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, (hipStream_t)stream};
+    LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
     HIPCHK(c, e->fn(A, io));
+    return C3SC_OK;
+}
+
+int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_tables,
+                                   const double *d_costs2, double *d_out, int32_t *d_uidx, int32_t *d_absorbed, void *stream)
+{
+    if (!c) return C3SC_ERR_ARG;
+    const int saved_model = c->model;
+    c->model = C3SC_MODEL_TABLE; // fill_args only checks that a model is set
+    KArgs A;
+    int rc = fill_args(c, k, F, A, true);
+    c->model = saved_model;
+    if (rc != C3SC_OK) return rc;
+    if (F == 0) return C3SC_OK;
+    if (!d_idx || !d_out || !d_tables || !d_costs2) return fail(c, C3SC_ERR_ARG, "bellman_fibers_tables: null buffer");
+    const KernelEntry *e = find_kernel(C3SC_MODEL_TABLE, c->d, c->rp, A.N, C3SC_VARIANT_AUTO, k);
+    if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_tables: no kernel instantiation for (dim, rank, N)");
+    c->last_kernel = e->name;
+    LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, d_tables, d_costs2, (hipStream_t)stream};
+    HIPCHK(c, e->fn(A, io));
+    return C3SC_OK;
+}
+
+int c3sc_hip_bellman_fibers_tables_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const double *h_tables,
+                                        const double *h_costs2, double *h_out, int32_t *h_uidx, int32_t *h_absorbed)
+{
+    if (!c || c->d == 0 || k < 0 || k >= c->d || c->ncand == 0) return fail(c, C3SC_ERR_ARG, "bellman_fibers_tables_host: bad arguments");
+    if (F == 0) return C3SC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->ngrid[k], S = 2 * c->d + 1;
+    const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * sizeof(double)),
+                 b_i = align256(F * N * sizeof(int32_t)), b_t = align256(F * N * c->ncand * S * sizeof(double)),
+                 b_c = align256(F * N * 2 * sizeof(double));
+    int rc = ensure_scratch(c, b_idx + b_out + 2 * b_i + b_t + b_c);
+    if (rc != C3SC_OK) return rc;
+    char *base = (char *)c->scratch;
+    int32_t *d_idx = (int32_t *)base;
+    double *d_out = (double *)(base + b_idx);
+    int32_t *d_ui = (int32_t *)(base + b_idx + b_out);
+    int32_t *d_ab = (int32_t *)(base + b_idx + b_out + b_i);
+    double *d_t = (double *)(base + b_idx + b_out + 2 * b_i);
+    double *d_c = (double *)(base + b_idx + b_out + 2 * b_i + b_t);
+    HIPCHK(c, hipMemcpy(d_idx, h_idx, F * c->d * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_t, h_tables, F * N * c->ncand * S * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_c, h_costs2, F * N * 2 * sizeof(double), hipMemcpyHostToDevice));
+    rc = c3sc_hip_bellman_fibers_tables(c, k, F, d_idx, d_t, d_c, d_out, h_uidx ? d_ui : nullptr, h_absorbed ? d_ab : nullptr, nullptr);
+    if (rc != C3SC_OK) return rc;
+    HIPCHK(c, hipMemcpy(h_out, d_out, F * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_uidx) HIPCHK(c, hipMemcpy(h_uidx, d_ui, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
     return C3SC_OK;
 }
 
@@ -485,7 +539,7 @@ int c3sc_hip_stencil_fibers_nb(c3sc_hip_ctx *c, int k, size_t F, const int32_t *
     const KernelEntry *e = find_kernel(0, c->d, c->rp, A.N, C3SC_VARIANT_AUTO, k);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "stencil_fibers: no kernel instantiation for (dim, rank, N)");
     c->last_kernel = e->name;
-    LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, d_nb_fixed, d_nb_vary, (hipStream_t)stream};
+    LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, d_nb_fixed, d_nb_vary, nullptr, nullptr, (hipStream_t)stream};
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
 }

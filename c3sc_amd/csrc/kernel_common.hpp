@@ -228,6 +228,43 @@ __device__ inline void table_values(const KArgs &A, const double *__restrict__ r
     for (int t = 0; t < Model::NTAB; t++) tv[t] = ro[A.tab_off[t] + ix[Model::tab_dim(t)]];
 }
 
+// One node of the Bellman operator from host-evaluated callback tables (TableModel): row = this node's
+// [U][2D+1] block, cost = (boundcost, obscost).  Same arithmetic as node_backup below.
+template <int D>
+__device__ inline double node_backup_tables(const KArgs &A, const double *__restrict__ row, const double *__restrict__ cost,
+                                            const double (&V)[2 * D + 1], int ab, int &ui, unsigned &st)
+{
+    ui = -1;
+    if (ab == 1) return cost[0];
+    if (ab == -1) return cost[1];
+    double best = 0.0;
+    for (int c = 0; c < A.ncand; c++) {
+        const double *r = row + (size_t)c * (2 * D + 1);
+        double Q = 0.0, PV = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; m++) {
+            const double b = r[m], s = r[D + m];
+            const double half = A.t[2 * m + 1] * (s * s) / 2.0;
+            const double tb = A.t[2 * m] * b;
+            const double pm = (b < -1e-14) ? half - tb : half;
+            const double pp = (b > 1e-14) ? half + tb : half;
+            Q += pm;
+            Q += pp;
+            PV = fma(pm, V[2 * m], PV);
+            PV = fma(pp, V[2 * m + 1], PV);
+        }
+        if (Q < 1e-14) { st |= C3SC_STATUS_STATIONARY; continue; }
+        const double inv = 1.0 / Q;
+        const double dt = A.h2 * inv;
+        const double pself = fma(-Q, inv, 1.0);
+        const double ctg = fma(pself, V[2 * D], PV * inv);
+        const double ebt = (A.discount == 0.0) ? 1.0 : exp(-A.discount * dt);
+        const double val = dt * r[2 * D] + ebt * ctg;
+        if (ui < 0 || val < best) { best = val; ui = c; }
+    }
+    return best;
+}
+
 // One node of the Bellman operator: bellman_optimal (bellman.c:504-543, BRUTEFORCE branch) over
 // bellman_control (:367-480, no-gradient branch) = user dynamics + transition_assemble
 // (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)

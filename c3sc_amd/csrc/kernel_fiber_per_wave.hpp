@@ -70,7 +70,7 @@ template <class Model, int RP, int NPL, bool STENCIL>
 __global__ void __launch_bounds__(256)
     k_fiber_per_wave(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
                      int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed, const int32_t *__restrict__ nbf,
-                     const int32_t *__restrict__ nbv)
+                     const int32_t *__restrict__ nbv, const double *__restrict__ tbl, const double *__restrict__ tcost)
 {
     constexpr int D = Model::D;
     constexpr int S = 2 * D + 1;
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256)
 
     const int sel = lane / RP, bb = lane - sel * RP; // (vector, component) role in the per-fiber setup
     CandRegs<Model> cr;
-    if constexpr (!STENCIL) cr.load(A, ro);
+    if constexpr (!STENCIL && !Model::IS_TABLE) cr.load(A, ro);
     unsigned st = 0;
 
     for (long f = (long)blockIdx.x * 4 + wv; f < A.F; f += (long)gridDim.x * 4) {
@@ -301,9 +301,15 @@ __global__ void __launch_bounds__(256)
                 }
             } else {
                 int ui;
-                double tv[Model::NTAB > 0 ? Model::NTAB : 1];
-                table_values<Model>(A, ro, ix, tv);
-                const double val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st);
+                double val;
+                if constexpr (Model::IS_TABLE) {
+                    const size_t node = (size_t)f * N + jj;
+                    val = node_backup_tables<D>(A, tbl + node * A.ncand * S, tcost + node * 2, V, ab, ui, st);
+                } else {
+                    double tv[Model::NTAB > 0 ? Model::NTAB : 1];
+                    table_values<Model>(A, ro, ix, tv);
+                    val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st);
+                }
                 if (live) {
                     outv[(size_t)f * N + j] = val;
                     if (uidx) uidx[(size_t)f * N + j] = ui;

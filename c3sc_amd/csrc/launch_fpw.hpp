@@ -35,7 +35,7 @@ hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
     int grid = (int)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, io.stream, A, io.ro, io.idx, io.out, io.uidx, io.absorbed,
-                       io.nbf, io.nbv);
+                       io.nbf, io.nbv, io.tbl, io.tcost);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ namespace c3sc {
 
 // examples/dubinscar_new/dubinscar.c:40-121
 struct Dubins3D {
+    static constexpr bool IS_TABLE = false;
     static constexpr int D = 3, DU = 1;
     static constexpr int NTAB = 2, NCF = 0; // tables: cos(x2), sin(x2)
     static constexpr unsigned UDEP_MASK = 1u << 2; // dims whose drift/diffusion depend on the control
@@ -56,6 +57,7 @@ struct Dubins3D {
 
 // examples/skidding_car/scar.c:40-169 (order = {0,1,2,3})
 struct Scar4D {
+    static constexpr bool IS_TABLE = false;
     static constexpr int D = 4, DU = 2;
     static constexpr int NTAB = 2, NCF = 1; // tables: cos(x2), sin(x2); candidate feature: tan(u0)
     static constexpr unsigned UDEP_MASK = (1u << 2) | (1u << 3);
@@ -89,6 +91,7 @@ struct Scar4D {
 
 // synthetic 7-D car: state (x, y, theta, v, omega, delta, a), controls (ddelta, da)
 struct Car7D {
+    static constexpr bool IS_TABLE = false;
     static constexpr int D = 7, DU = 2;
     static constexpr int NTAB = 3, NCF = 0; // tables: cos(x2), sin(x2), tan(x5)
     static constexpr unsigned UDEP_MASK = (1u << 5) | (1u << 6);
@@ -124,6 +127,7 @@ struct Car7D {
 // examples/lqgnd/lqgnd.c:80-198 (dim = 2 is examples/lqg2d_new/lqg2d.c:72-153); prm = {dim, sig_even, sig_odd}
 template <int DIM>
 struct LqgNd {
+    static constexpr bool IS_TABLE = false;
     static constexpr int D = DIM, DU = DIM / 2;
     static constexpr int NTAB = 0, NCF = 0;
     static constexpr unsigned UDEP_MASK = 0xAAAAAAAAu & ((1u << DIM) - 1u); // odd dims are driven by a control
@@ -159,6 +163,7 @@ struct LqgNd {
 // stage_mode 0: stage = 1 (double_int.c:126); 1: stage = sum x_i^2 (synthetic quad10d)
 template <int DIM>
 struct Chain {
+    static constexpr bool IS_TABLE = false;
     static constexpr int D = DIM, DU = 1;
     static constexpr int NTAB = 0, NCF = 0;
     static constexpr unsigned UDEP_MASK = 1u << (DIM - 1);
@@ -191,9 +196,21 @@ struct Chain {
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
 };
 
+// Universal model for arbitrary host callbacks (the reference's examples unchanged): the HOST evaluates the
+// user's drift / diffusion / stage-cost callbacks for every (node, candidate) of the fibers it submits and the
+// kernel reads the numbers from a table: per fiber [N][U][2D+1] = (drift[D], diag sigma[D], stage) and
+// [N][2] = (boundcost, obscost).  c3sc_hip_bellman_fibers_tables.
+template <int DIM>
+struct TableModel {
+    static constexpr int D = DIM, DU = 1;
+    static constexpr int NTAB = 0, NCF = 0;
+    static constexpr bool IS_TABLE = true;
+};
+
 // FT stencil only (c3sc_hip_stencil_fibers): no dynamics
 template <int DIM>
 struct NoModel {
+    static constexpr bool IS_TABLE = false;
     static constexpr int D = DIM, DU = 1;
     static constexpr int NTAB = 0, NCF = 0;
 };

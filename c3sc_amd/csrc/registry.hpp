@@ -16,6 +16,8 @@ struct LaunchIO {
     int32_t *absorbed;
     const int32_t *nbf; // stencil only: explicit fixed-dim neighbours [F][2(d-1)] or null
     const int32_t *nbv; // stencil only: explicit varying-dim neighbours [F][N][2] or null
+    const double *tbl;   // TableModel only: [F][N][U][2d+1] host-evaluated callbacks
+    const double *tcost; // TableModel only: [F][N][2] (boundcost, obscost)
     hipStream_t stream;
 };
 

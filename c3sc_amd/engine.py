@@ -26,7 +26,7 @@ EXPORTS = [
     "c3sc_hip_ctx_create", "c3sc_hip_ctx_destroy", "c3sc_hip_last_error", "c3sc_hip_device_count",
     "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_mca", "c3sc_hip_set_model",
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
-    "c3sc_hip_bellman_fibers", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
+    "c3sc_hip_bellman_fibers", "c3sc_hip_bellman_fibers_tables", "c3sc_hip_bellman_fibers_tables_host", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
     "c3sc_hip_stencil_fibers_host", "c3sc_hip_stencil_fibers_nb", "c3sc_hip_stencil_fibers_nb_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
     "c3sc_hip_debug_read", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]
@@ -64,6 +64,7 @@ def load_library():
         L.c3sc_hip_stencil_fibers_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.c3sc_hip_stencil_fibers_nb_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_void_p]
+        L.c3sc_hip_bellman_fibers_tables_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
         L.c3sc_hip_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.c3sc_hip_timer_start.argtypes = [C.c_void_p, C.c_void_p]
         L.c3sc_hip_timer_stop.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
@@ -227,6 +228,20 @@ class BellmanEngine:
         self._chk(self.L.c3sc_hip_bellman_fibers_host(self.h, k, F, idx.ctypes.data, out.ctypes.data,
                                                       ui.ctypes.data if ui is not None else None,
                                                       ab.ctypes.data if ab is not None else None), "bellman_fibers_host")
+        return out, ui, ab
+
+    def bellman_fibers_tables_host(self, k: int, idx: np.ndarray, tables: np.ndarray, costs2: np.ndarray):
+        """Universal path: tables (F, N, U, 2d+1) = host-evaluated (drift, diag sigma, stage), costs2 (F, N, 2)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        tables = _f64(tables)
+        costs2 = _f64(costs2)
+        F, N = idx.shape[0], self.ngrid[k]
+        out = np.empty((F, N))
+        ui = np.empty((F, N), dtype=np.int32)
+        ab = np.empty((F, N), dtype=np.int32)
+        self._chk(self.L.c3sc_hip_bellman_fibers_tables_host(self.h, k, F, idx.ctypes.data, tables.ctypes.data,
+                                                             costs2.ctypes.data, out.ctypes.data, ui.ctypes.data,
+                                                             ab.ctypes.data), "bellman_fibers_tables_host")
         return out, ui, ab
 
     def stencil_fibers_host(self, k: int, idx: np.ndarray, nb_fixed=None, nb_vary=None):

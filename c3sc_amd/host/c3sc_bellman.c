@@ -445,9 +445,8 @@ static struct c3sc_hip_ctx *sync_device(struct VIparam *vi)
     static struct c3sc_hip_ctx *cfg_ctx = NULL;
     static uint64_t cfg_sig = 0;
     const size_t d = mca->dx;
-    if (dp->model == 0)
-        DIE("bellman_vi: no device model registered (dp_param_set_device_model / c3control_set_device_model); "
-            "host callbacks cannot be called from a kernel");
+    if (dp->model == 0 && (dp->stagecost == NULL || dp->boundcost == NULL || dp->obscost == NULL))
+        DIE("bellman_vi: neither a device model (dp_param_set_device_model) nor the host callbacks are set");
     if (!c3opt_is_bruteforce(cp->opt)) DIE("bellman_vi: only BRUTEFORCE control minimisation runs on the device");
     /* signature of everything the device holds besides the value function */
     int bc[C3SC_MAX_DIM];
@@ -477,7 +476,7 @@ static struct c3sc_hip_ctx *sync_device(struct VIparam *vi)
         hipok(ctx, c3sc_hip_set_grid(ctx, (int)d, mca->ngrid, (const double *const *)mca->xgrid), "c3sc_hip_set_grid");
         hipok(ctx, c3sc_hip_set_boundary(ctx, bc, (int)nobs, lb, ub), "c3sc_hip_set_boundary");
         hipok(ctx, c3sc_hip_set_mca(ctx, mca->h2, mca->t, dp->discount), "c3sc_hip_set_mca");
-        hipok(ctx, c3sc_hip_set_model(ctx, dp->model, dp->prm, dp->nprm), "c3sc_hip_set_model");
+        if (dp->model != 0) hipok(ctx, c3sc_hip_set_model(ctx, dp->model, dp->prm, dp->nprm), "c3sc_hip_set_model");
         hipok(ctx, c3sc_hip_set_controls(ctx, (int)c3opt_get_nbrute(cp->opt), (int)c3opt_get_d(cp->opt), c3opt_get_brute_vals(cp->opt)),
               "c3sc_hip_set_controls");
         cfg_ctx = ctx;
@@ -521,6 +520,41 @@ static void cross_check_model(struct VIparam *vi, struct c3sc_hip_ctx *ctx, size
     dp->model_checked = 1;
     free(costs);
     free(ab);
+}
+
+static int dp_has_device_model(const struct DPparam *dp) { return dp->model != 0; }
+
+/* host evaluation of the user's callbacks for one fiber -> [N][U][2dx+1] and [N][2] */
+static void eval_callback_tables(struct ControlParams *cp, size_t k, const int32_t *idx, size_t N, const double *x,
+                                 double *tables, double *costs2)
+{
+    struct DPparam *dp = cp->dp;
+    const size_t dx = cp->dx, dw = cp->dw, du = c3opt_get_d(cp->opt), U = c3opt_get_nbrute(cp->opt), S = 2 * dx + 1;
+    const double *cands = c3opt_get_brute_vals(cp->opt);
+    size_t fi[C3SC_MAX_DIM], nf[2 * C3SC_MAX_DIM];
+    size_t *nv = xcalloc(2 * N, sizeof(size_t));
+    int *ab = xcalloc(N, sizeof(int));
+    double *drift = xcalloc(dx, sizeof(double)), *diff = xcalloc(dx * dw, sizeof(double));
+    for (size_t m = 0; m < dx; m++) fi[m] = (size_t)idx[m];
+    process_fibers_neighbor(dx, fi, k, x, ab, nv, nf, cp->mca->ngrid, dp->bound);
+    for (size_t j = 0; j < N; j++) {
+        const double *xj = x + j * dx;
+        int res = 0;
+        if (ab[j] == 1) res = dp->boundcost(cp->time, xj, &costs2[2 * j]);
+        else if (ab[j] == -1) res = dp->obscost(xj, &costs2[2 * j + 1]);
+        else {
+            for (size_t c = 0; c < U && res == 0; c++) {
+                double *row = tables + (j * U + c) * S;
+                res = drift_eval(dp->drift, cp->time, xj, cands + c * du, drift, NULL);
+                if (res == 0) res = diff_eval(dp->diff, cp->time, xj, cands + c * du, diff, NULL);
+                if (res == 0) res = dp->stagecost(cp->time, xj, cands + c * du, &row[2 * dx], NULL);
+                for (size_t m = 0; m < dx; m++) { row[m] = drift[m]; row[dx + m] = diff[m * dx + m]; } /* nodeutil.c:294 */
+            }
+        }
+        assert(res == 0);
+        (void)res;
+    }
+    free(nv); free(ab); free(drift); free(diff);
 }
 
 int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg)
@@ -571,14 +605,29 @@ int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg
         size_t r = 0;
         for (size_t f = 0; f < F; f++)
             if (need[f]) memcpy(ridx + (r++) * dx, idx + f * dx, dx * sizeof(int32_t));
-        hipok(ctx, c3sc_hip_bellman_fibers_host(ctx, (int)k0, nrun, ridx, rout, NULL, rabs), "c3sc_hip_bellman_fibers_host");
+        if (dp_has_device_model(cp->dp)) {
+            hipok(ctx, c3sc_hip_bellman_fibers_host(ctx, (int)k0, nrun, ridx, rout, NULL, rabs), "c3sc_hip_bellman_fibers_host");
+        } else {
+            /* universal path: the user's callbacks are evaluated here, exactly where bellman_control would call
+             * them (bellman.c:414-444, 458, 467), and shipped as tables */
+            const size_t U = c3opt_get_nbrute(cp->opt), S = 2 * dx + 1;
+            double *tables = xcalloc(nrun * N * U * S, sizeof(double));
+            double *costs2 = xcalloc(nrun * N * 2, sizeof(double));
+            size_t rr = 0;
+            for (size_t f = 0; f < F; f++)
+                if (need[f]) { eval_callback_tables(cp, k0, idx + f * dx, N, x + f * N * dx, tables + rr * N * U * S, costs2 + rr * N * 2); rr++; }
+            hipok(ctx, c3sc_hip_bellman_fibers_tables_host(ctx, (int)k0, nrun, ridx, tables, costs2, rout, NULL, rabs),
+                  "c3sc_hip_bellman_fibers_tables_host");
+            free(tables);
+            free(costs2);
+        }
         unsigned st = 0;
         hipok(ctx, c3sc_hip_get_status(ctx, &st, 1), "c3sc_hip_get_status");
         if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
         r = 0;
         for (size_t f = 0; f < F; f++) {
             if (!need[f]) continue;
-            if (r == 0) cross_check_model(vi, ctx, k0, ridx, N, x + f * N * dx, rout, rabs);
+            if (r == 0 && dp_has_device_model(cp->dp)) cross_check_model(vi, ctx, k0, ridx, N, x + f * N * dx, rout, rabs);
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
             ser[dx] = 0;
             ser[dx + 1] = workspace_get_vi_iter(cp->work);

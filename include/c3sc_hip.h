@@ -53,7 +53,8 @@ enum {
     C3SC_MODEL_SCAR4D = 2,   /* examples/skidding_car/scar.c:40-169 */
     C3SC_MODEL_CAR7D = 3,    /* synthetic 7-D car */
     C3SC_MODEL_LQGND = 4,    /* examples/lqgnd/lqgnd.c:80-198; params {dim, sig_even, sig_odd} */
-    C3SC_MODEL_CHAIN = 5     /* examples/double_int/double_int.c:80-157; params {dim, sig, sig_last, stage_mode} */
+    C3SC_MODEL_CHAIN = 5,    /* examples/double_int/double_int.c:80-157; params {dim, sig, sig_last, stage_mode} */
+    C3SC_MODEL_TABLE = 100   /* host-evaluated callbacks (c3sc_hip_bellman_fibers_tables); not set with set_model */
 };
 
 /* status bits accumulated by the kernels (c3sc_hip_get_status) */
@@ -103,6 +104,19 @@ int c3sc_hip_set_variant(c3sc_hip_ctx *ctx, int variant);
  * Asynchronous on `stream`. */
 int c3sc_hip_bellman_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, double *d_out,
                             int32_t *d_uidx, int32_t *d_absorbed, void *stream);
+
+/* The same hot path for ARBITRARY host callbacks (the reference's examples unchanged): the host evaluates
+ * drift_eval / diff_eval / stagecost (dynamics.c:127-139,224-239; bellman.c:414-444) for every (node, candidate)
+ * and boundcost / obscost (bellman.c:458,467) for every node of the fibers it submits:
+ *   d_tables double [F][N_k][U][2d+1] = (drift[d], diag(diffusion)[d], stage cost)
+ *   d_costs2 double [F][N_k][2]       = (boundcost, obscost)
+ * set_grid / set_boundary / set_mca / set_controls / upload_value must have been called; set_model is not needed. */
+int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, const double *d_tables,
+                                   const double *d_costs2, double *d_out, int32_t *d_uidx, int32_t *d_absorbed,
+                                   void *stream);
+int c3sc_hip_bellman_fibers_tables_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx,
+                                        const double *h_tables, const double *h_costs2, double *h_out,
+                                        int32_t *h_uidx, int32_t *h_absorbed);
 
 /* Batched mca_get_neighbor_costs (nodeutil.c:647-713) only: d_costs double [F*N_k*(2d+1)],
  * layout out[j*(2d+1) + 2m + {0,1}] = (-,+) neighbour in dim m, [.. + 2d] = self. */

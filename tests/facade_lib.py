@@ -70,7 +70,7 @@ def ptrs(arrs):
 class Control:
     """c3control_create + problem wiring from a workloads.Workload (device model + optional host callbacks)."""
 
-    def __init__(self, w, callbacks=None):
+    def __init__(self, w, callbacks=None, device_model=True):
         L = lib()
         self.L, self.w = L, w
         self._lb, self._ub, self._ng = f64(w.lb), f64(w.ub), usz(w.ngrid)
@@ -81,7 +81,8 @@ class Control:
         for cen, wid in w.obstacles:
             L.c3control_add_obstacle(self.h, dp(f64(cen)), dp(f64(wid)))
         prm = f64(list(w.params) if len(w.params) else [0.0])
-        L.c3control_set_device_model(self.h, C.c_int(w.model), dp(prm), C.c_size_t(len(w.params)))
+        if device_model:
+            L.c3control_set_device_model(self.h, C.c_int(w.model), dp(prm), C.c_size_t(len(w.params)))
         self._cb = callbacks
         if callbacks is not None:
             b, s, st, bd, ob = callbacks

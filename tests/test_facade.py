@@ -220,6 +220,36 @@ def test_bellman_vi_through_reference_api(oracle):
 
 
 @pytest.mark.gpu
+def test_bellman_vi_unchanged_example_callbacks(oracle):
+    """No device model registered: bellman_vi evaluates the user's host callbacks (as the reference's examples
+    define them) into tables and still runs the backup on the GPU -- the 'examples link unchanged' path."""
+    import facade_lib
+
+    w = wl.c2_dubins().scaled(ngrid=(15, 14, 16), rank=6)
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    P.increment_vi_iter()  # c3control_begin_vi does the same (bellman.c:2196); the memo key carries the iteration
+    ctl = facade_lib.Control(w, _callbacks(w), device_model=False)
+    vf = ctl.valuef(cores)
+    vi = ctl.begin_vi(vf)
+    xg = ctl.xgrid()
+    for k in range(3):
+        idx = wl.synth_fibers(w, k, 20)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        idx[:, k] = 0
+        N = w.ngrid[k]
+        x = np.array([[[xg[m][j] if m == k else xg[m][row[m]] for m in range(3)] for j in range(N)] for row in idx])
+        out = ctl.bellman_vi_batch(vi, x)
+        # reference semantics incl. the per-iteration memo: a node already served along another fiber keeps
+        # its first value even where the end-point quirk (nodeutil.c:570-612) would now flag it differently
+        ref = np.array([P.bellman_vi(xf, use_memo=True)[0] for xf in x])
+        assert np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
+    ctl.end_vi(vi)
+    ctl.close()
+
+
+@pytest.mark.gpu
 def test_bellman_vi_batch_and_fiber_nn(oracle):
     """One launch for many callback fibers (bellman_vi_batch) and the literal valuef_eval_fiber_ind_nn
     interface (explicit neighbour arrays, tprob_test.c:575-602 style) on the GPU."""

@@ -105,6 +105,49 @@ def test_stencil_vs_oracle(oracle, name, kw):
         assert np.abs(out - ref).max() <= REL_TOL * scale
 
 
+def test_table_model_vs_oracle(oracle):
+    """c3sc_hip_bellman_fibers_tables: host-evaluated (drift, diag sigma, stage) tables, any dynamics."""
+    import oracle_lib
+    import ctypes as C
+
+    w = wl.scar4d().scaled(ngrid=(9, 8, 10, 7), rank=8)
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    eng = _engine(w, cores)
+    L = oracle_lib.lib()
+    xg = w.xgrid()
+    S = 2 * w.dx + 1
+    prm = np.zeros(8)
+    for k in range(w.dx):
+        idx = wl.synth_fibers(w, k, 17)
+        idx[0, :] = 0
+        idx[:, k] = 0
+        N = w.ngrid[k]
+        tables = np.zeros((len(idx), N, w.ncand, S))
+        costs2 = np.zeros((len(idx), N, 2))
+        b = np.zeros(w.dx); sg = np.zeros(w.dx); st = C.c_double(0)
+        for f, row in enumerate(idx):
+            for j in range(N):
+                x = np.array([xg[m][j] if m == k else xg[m][row[m]] for m in range(w.dx)])
+                bc = C.c_double(0); oc = C.c_double(0)
+                L.orc_model_boundcost(w.model, oracle_lib.dp(prm), oracle_lib.dp(x), C.byref(bc))
+                L.orc_model_obscost(w.model, oracle_lib.dp(prm), oracle_lib.dp(x), C.byref(oc))
+                costs2[f, j] = (bc.value, oc.value)
+                for c in range(w.ncand):
+                    u = np.ascontiguousarray(w.cands[c])
+                    L.orc_model_drift(w.model, oracle_lib.dp(prm), oracle_lib.dp(x), oracle_lib.dp(u), oracle_lib.dp(b))
+                    L.orc_model_diff_diag(w.model, oracle_lib.dp(prm), oracle_lib.dp(x), oracle_lib.dp(u), oracle_lib.dp(sg))
+                    L.orc_model_stage(w.model, oracle_lib.dp(prm), oracle_lib.dp(x), oracle_lib.dp(u), C.byref(st))
+                    tables[f, j, c, :w.dx] = b
+                    tables[f, j, c, w.dx:2 * w.dx] = sg
+                    tables[f, j, c, 2 * w.dx] = st.value
+        out, ui, ab = eng.bellman_fibers_tables_host(k, idx, tables, costs2)
+        ref, ref_ui, ref_ab = P.bellman_fibers(k, idx)
+        np.testing.assert_array_equal(ab, ref_ab)
+        assert np.abs(out - ref).max() <= REL_TOL * np.abs(ref).max()
+        assert "TableModel" in eng.last_kernel()
+
+
 def test_mixed_ranks_and_smooth_value(oracle):
     """Non-uniform ranks (padded on the device) and a smooth rank-2 value function."""
     w = wl.c2_dubins().scaled(ngrid=(19, 23, 17))

@@ -325,9 +325,57 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     }
     double best = 0.0;
     constexpr int NCFa = Model::NCF > 0 ? Model::NCF : 1;
-    // Candidates are evaluated CG at a time (CG = 1 where registers are tight): one candidate is a ~40-deep chain of dependent f64 operations
-    // (rates -> Q -> 1/Q -> dt -> value), and with one or two wavefronts per SIMD nothing else hides that
-    // latency, so independent candidates are interleaved.  The scan order / strict '<' is kept.
+    if (A.discount == 0.0) {
+        // Undiscounted problems (beta = 0, exp(-beta dt) = 1): value_c = (h2*stage_c + PV_c)/Q_c + residue, so
+        // the scan compares the candidates as fractions num_c/Q_c by cross-multiplication and divides ONCE for
+        // the winner -- nine dependent f64 divisions per node are the longest chain of the scan otherwise.
+        // Scan order and strict '<' are kept; a different winner is possible only between candidates whose
+        // values agree to rounding.
+        double bnum = 0.0, bq = 1.0;
+        for (int c = 0; c < A.ncand; c++) {
+            double u[DU], cf[NCFa];
+#pragma unroll
+            for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
+            cf[0] = 0.0;
+#pragma unroll
+            for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
+            double b[D], s[D];
+            Model::drift(A.prm, nd, x, u, cf, b);
+            Model::sigma(A.prm, x, u, s);
+            const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
+            double Qa = 0.0, Qb = 0.0, PVa = 0.0, PVb = 0.0; // two short chains instead of one long one
+#pragma unroll
+            for (int m = 0; m < D; m++) {
+                if ((UM >> m) & 1u) {
+                    const double half = t2l[m] * (s[m] * s[m]) / 2.0;
+                    const double tb = tl[m] * b[m];
+                    const double pm = (b[m] < -1e-14) ? half - tb : half;
+                    const double pp = (b[m] > 1e-14) ? half + tb : half;
+                    Qa += pm;
+                    Qb += pp;
+                    PVa = fma(pm, V[2 * m], PVa);
+                    PVb = fma(pp, V[2 * m + 1], PVb);
+                }
+            }
+            const double Q = Q0 + (Qa + Qb);
+            const double num = fma(h2l, stage, PV0 + (PVa + PVb));
+            if (Q < 1e-14) { st |= C3SC_STATUS_STATIONARY; continue; }
+            if (ui < 0 || num * bq < bnum * Q) {
+                bnum = num;
+                bq = Q;
+                ui = c;
+            }
+        }
+        if (ui >= 0) {
+            const double inv = 1.0 / bq;
+            const double pself = fma(-bq, inv, 1.0);
+            best = fma(pself, V[2 * D], bnum * inv);
+        }
+        return best;
+    }
+    // Candidates are evaluated CG at a time (CG = 1 where registers are tight): one candidate is a ~40-deep
+    // chain of dependent f64 operations (rates -> Q -> 1/Q -> dt -> value), and with one or two wavefronts per
+    // SIMD nothing else hides that latency, so independent candidates are interleaved.
     for (int c0 = 0; c0 < A.ncand; c0 += CG) {
         double val[CG];
         bool ok[CG];

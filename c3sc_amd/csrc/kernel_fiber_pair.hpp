@@ -28,10 +28,16 @@ constexpr int FPP_THREADS = 128;
 
 __device__ inline void stage_core_n(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride, int nthreads)
 {
-    const int total = n_nodes * elems;
+    // dst index = e + (e / elems) * (stride - elems), kept incrementally (no integer division per element)
+    const int total = n_nodes * elems, pad = stride - elems;
+    int j = (int)threadIdx.x / elems, w = (int)threadIdx.x - j * elems;
+    const int dj = nthreads / elems, dw = nthreads - dj * elems;
+#pragma unroll 4
     for (int e = threadIdx.x; e < total; e += nthreads) {
-        const int j = e / elems, w = e - j * elems;
-        sK[j * stride + w] = src[e];
+        sK[e + j * pad] = src[e];
+        j += dj;
+        w += dw;
+        if (w >= elems) { w -= elems; j++; }
     }
 }
 
@@ -108,7 +114,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
     const int lane = threadIdx.x & 63;
     const int N = A.N;
     const long ntiles = (A.F + 63) / 64;
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
     CandRegs<Model> cr;
     cr.load(A, ro);
     NodeRegs<Model, K> nr;
@@ -145,9 +151,11 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         if constexpr (K > 0) {
             {
                 constexpr int str = fpl_lds_stride(RP);
+                FPP_STAMP(1)
                 pair_barrier();
                 stage_core_n(sK, ro + A.core_off[0], A.ngrid[0], RP, str, FPP_THREADS);
                 pair_barrier();
+                FPP_STAMP(7)
 #pragma unroll
                 for (int b = 0; b < RP; b++) {
                     L[b] = sK[fi[0] * str + b];
@@ -161,9 +169,11 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 constexpr int m = decltype(mc)::value;
                 constexpr int str = fpl_lds_stride(RP * RP);
                 constexpr int before = 2 * own_left_before<D, K, H>(m); // own vectors created so far
+                FPP_STAMP(1)
                 pair_barrier();
                 stage_core_n(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str, FPP_THREADS);
                 pair_barrier();
+                FPP_STAMP(7)
                 const double *G = sK + fi[m] * str;
                 apply_core<RP, NOWN, 0, before, true>(G, W);
                 if constexpr (pair_owner<K>(m) == H) {
@@ -192,9 +202,11 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         if constexpr (K < D - 1) {
             {
                 constexpr int str = fpl_lds_stride(RP);
+                FPP_STAMP(1)
                 pair_barrier();
                 stage_core_n(sK, ro + A.core_off[D - 1], A.ngrid[D - 1], RP, str, FPP_THREADS);
                 pair_barrier();
+                FPP_STAMP(7)
 #pragma unroll
                 for (int a = 0; a < RP; a++) {
                     R[a] = sK[fi[D - 1] * str + a];
@@ -208,9 +220,11 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 constexpr int m = decltype(mc)::value; // D-2 down to K+1
                 constexpr int str = fpl_lds_stride(RP * RP);
                 constexpr int after = 2 * own_right_after<D, K, H>(m);
+                FPP_STAMP(1)
                 pair_barrier();
                 stage_core_n(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str, FPP_THREADS);
                 pair_barrier();
+                FPP_STAMP(7)
                 const double *G = sK + fi[m] * str;
                 apply_core<RP, NOWN, NOL, after, false>(G, W);
                 if constexpr (pair_owner<K>(m) == H) {
@@ -370,7 +384,9 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             int lo, hi;
             ab = vary_neighbors(jn, N, bck, ab, lo, hi);
             int ui;
+            FPP_STAMP(8) // exchange reads + stencil assembly + flags
             const double val = node_backup<Model, 1>(A, ro, x, tv, cr, V, ab, ui, st);
+            FPP_STAMP(9) // control scan
             if (live) {
                 outv[(size_t)f * N + jn] = val;
                 if (uidx) uidx[(size_t)f * N + jn] = ui;
@@ -445,9 +461,9 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         }
     }
     if (C3SC_STAMPS_ON && (A.dbg & 128) && lane == 0) {
-        const size_t w = ((size_t)blockIdx.x * 2 + H) * 8;
+        const size_t w = ((size_t)blockIdx.x * 2 + H) * 12;
         if (w < 65536 * 8)
-            for (int i = 0; i < 8; i++) A.dbgbuf[w + i] = seg[i];
+            for (int i = 0; i < 12; i++) A.dbgbuf[w + i] = seg[i];
     }
 }
 

@@ -52,28 +52,33 @@ __host__ __device__ constexpr int fpl_lds_stride(int elems) { return elems | 1; 
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void mem_fence() { asm volatile("" ::: "memory"); }
 
-// out[b] = sum_a v[a] G[a + b*RP]   (row vector times the lane's own matrix in LDS), NV vectors per pass
+// out[b] = sum_a v[a] G[a + b*RP]   (row vector times the lane's own matrix in LDS), NV vectors per pass.
+// Walks the matrix ROW by row so that the RP outputs are RP independent FMA chains (a column-wise walk is one
+// RP-deep dependent chain per output and is latency-bound at two wavefronts per SIMD).
 template <int RP, int NV>
 __device__ inline void vecmat_lds(const double *G, double (&v)[NV][RP])
 {
     double t[NV][RP];
     double g[2][RP];
 #pragma unroll
-    for (int a = 0; a < RP; a++) g[0][a] = G[a];
+    for (int s = 0; s < NV; s++)
 #pragma unroll
-    for (int b = 0; b < RP; b++) {
-        if (b + 1 < RP) {
+        for (int b = 0; b < RP; b++) t[s][b] = 0.0;
 #pragma unroll
-            for (int a = 0; a < RP; a++) g[(b + 1) & 1][a] = G[a + (b + 1) * RP];
+    for (int b = 0; b < RP; b++) g[0][b] = G[b * RP];
+#pragma unroll
+    for (int a = 0; a < RP; a++) {
+        if (a + 1 < RP) {
+#pragma unroll
+            for (int b = 0; b < RP; b++) g[(a + 1) & 1][b] = G[(a + 1) + b * RP];
         }
 #pragma unroll
-        for (int s = 0; s < NV; s++) {
-            double acc = 0.0;
+        for (int s = 0; s < NV; s++)
 #pragma unroll
-            for (int a = 0; a < RP; a++) acc = fma(v[s][a], g[b & 1][a], acc);
-            pin(acc);
-            t[s][b] = acc;
-        }
+            for (int b = 0; b < RP; b++) {
+                t[s][b] = fma(v[s][a], g[a & 1][b], t[s][b]);
+                pin(t[s][b]);
+            }
         mem_fence();
     }
 #pragma unroll
@@ -148,10 +153,15 @@ __device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
 // cooperative global -> LDS copy of one core with the padded node stride
 __device__ inline void stage_core(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride)
 {
-    const int total = n_nodes * elems;
+    const int total = n_nodes * elems, pad = stride - elems;
+    int j = (int)threadIdx.x / elems, w = (int)threadIdx.x - j * elems;
+    const int dj = FPL_THREADS / elems, dw = FPL_THREADS - dj * elems;
+#pragma unroll 4
     for (int e = threadIdx.x; e < total; e += FPL_THREADS) {
-        const int j = e / elems, w = e - j * elems;
-        sK[j * stride + w] = src[e];
+        sK[e + j * pad] = src[e];
+        j += dj;
+        w += dw;
+        if (w >= elems) { w -= elems; j++; }
     }
 }
 

@@ -7,14 +7,14 @@ from c3sc_amd.engine import BellmanEngine
 w = wl.c4_car7d(); cores = wl.synth_cores(w)
 eng = BellmanEngine(0); eng.configure(w, cores); eng.set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 F = 1 << 17
-names = ["setup", "fold", "swap", "partials+wr", "barrier1", "rd+finalize", "barrier2", "tile-top"]
+names = ["setup", "fold-compute", "swap", "partials+wr", "barrier1", "fin-rest", "barrier2", "fold-stage", "fin-pre", "fin-scan", "x", "y"]
 for k in (0, 3, 6):
     idx = torch.from_numpy(wl.synth_fibers(w, k, F)).cuda()
     out = eng.bellman_fibers(k, idx); torch.cuda.synchronize()
     out = eng.bellman_fibers(k, idx); torch.cuda.synchronize()
     var = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     if var == 3:
-        d = eng.debug_read(2048 * 8).reshape(2048, 8).astype(np.float64)
+        d = eng.debug_read(2048 * 12).reshape(2048, 12).astype(np.float64)
         for h in (0, 1):
             m = d[h::2].mean(axis=0)
             print(f"k={k} wave{h}: total {m.sum():.0f} cyc | " + " ".join(f"{n}={v:.0f}" for n, v in zip(names, m)))

@@ -202,19 +202,63 @@ struct NodeRegs {
     }
 };
 
-// Lane-distributed copy of the control candidates and their features (lane c holds candidate c; ncand <= 64)
+// Lane-distributed copy of the control candidates and their features (lane c holds candidate c; ncand <= 64),
+// plus the upwind rates of the dims whose drift and diffusion depend on the control alone (Model::UCONST_MASK):
+// those are constants of the candidate (nodeutil.c:289-309 with b = b(u), sigma = sigma(u)), computed once per
+// wave with the very arithmetic the node loop would use and broadcast by v_readlane in the scan.
 template <class Model>
 struct CandRegs {
+    static constexpr unsigned UC = Model::UCONST_MASK;
+    __host__ __device__ static constexpr int nuc()
+    {
+        int n = 0;
+        for (int m = 0; m < Model::D; m++) n += (UC >> m) & 1u;
+        return n;
+    }
+    __host__ __device__ static constexpr int ucslot(int m)
+    {
+        int n = 0;
+        for (int q = 0; q < m; q++) n += (UC >> q) & 1u;
+        return n;
+    }
+    static constexpr int NUC = nuc() > 0 ? nuc() : 1;
     double u[Model::DU];
     double cf[Model::NCF > 0 ? Model::NCF : 1];
+    double rpm[NUC], rpp[NUC]; // rate to the (-,+) neighbour of each UCONST dim
+    double qab;                // their sum, in the association the scan uses: (sum pm) + (sum pp)
     __device__ inline void load(const KArgs &A, const double *__restrict__ ro)
     {
+        constexpr int D = Model::D;
         const int c = min((int)(threadIdx.x & 63), A.ncand - 1);
 #pragma unroll
         for (int i = 0; i < Model::DU; i++) u[i] = ro[A.cands_off + c * Model::DU + i];
         cf[0] = 0.0;
 #pragma unroll
         for (int i = 0; i < Model::NCF; i++) cf[i] = ro[A.cfeat_off + c * Model::NCF + i];
+        rpm[0] = rpp[0] = qab = 0.0;
+        if constexpr (UC != 0) {
+            typename Model::Node nd{};
+            double x[D], b[D], s[D];
+#pragma unroll
+            for (int m = 0; m < D; m++) x[m] = 0.0;
+            Model::drift(A.prm, nd, x, u, cf, b); // only the UCONST entries are meaningful and used
+            Model::sigma(A.prm, x, u, s);
+            double Qa = 0.0, Qb = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; m++) {
+                if ((UC >> m) & 1u) {
+                    const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
+                    const double tb = A.t[2 * m] * b[m];
+                    const double pm = (b[m] < -1e-14) ? half - tb : half;
+                    const double pp = (b[m] > 1e-14) ? half + tb : half;
+                    rpm[ucslot(m)] = pm;
+                    rpp[ucslot(m)] = pp;
+                    Qa += pm;
+                    Qb += pp;
+                }
+            }
+            qab = Qa + Qb;
+        }
     }
 };
 
@@ -277,8 +321,12 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
 {
     constexpr int D = Model::D, DU = Model::DU;
     ui = -1;
-    if (ab == 1) return Model::boundcost(A.prm, x);  // bellman.c:513-523
-    if (ab == -1) return Model::obscost(A.prm, x);   // bellman.c:524-532
+    // Absorbed lanes (bellman.c:513-532) do not leave early: the scan below runs with the whole wave active and
+    // the absorbed lanes' result is replaced at the end.  The lane-distributed tables (CandRegs, NodeRegs) are
+    // read with v_readlane from lanes that a divergent branch could have switched off, and a register the
+    // compiler spills and reloads inside such a branch is restored for the active lanes only.
+    const double absorbed_cost = (ab == 1) ? Model::boundcost(A.prm, x) : Model::obscost(A.prm, x);
+    if (!__any(ab == 0)) return absorbed_cost; // wave-uniform: every lane absorbed
     typename Model::Node nd;
     Model::prep(A.prm, x, tv, nd);
     // Everything that does not depend on the control is done once per node: the rates of the dims whose
@@ -332,45 +380,69 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         // Scan order and strict '<' are kept; a different winner is possible only between candidates whose
         // values agree to rounding.
         double bnum = 0.0, bq = 1.0;
+        constexpr unsigned UCm = Model::UCONST_MASK;
+        constexpr bool ALLC = (UCm == UM) && !Model::STAGE_UDEP && Model::NCF == 0; // nothing per candidate needs x
         for (int c = 0; c < A.ncand; c++) {
-            double u[DU], cf[NCFa];
+            double Q, num;
+            if constexpr (ALLC) {
+                // every control-dependent rate is a constant of the candidate: 2 FMAs per such dim and one add
+                double PVa = 0.0, PVb = 0.0;
 #pragma unroll
-            for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
-            cf[0] = 0.0;
-#pragma unroll
-            for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
-            double b[D], s[D];
-            Model::drift(A.prm, nd, x, u, cf, b);
-            Model::sigma(A.prm, x, u, s);
-            const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
-            double Qa = 0.0, Qb = 0.0, PVa = 0.0, PVb = 0.0; // two short chains instead of one long one
-#pragma unroll
-            for (int m = 0; m < D; m++) {
-                if ((UM >> m) & 1u) {
-                    const double half = t2l[m] * (s[m] * s[m]) / 2.0;
-                    const double tb = tl[m] * b[m];
-                    const double pm = (b[m] < -1e-14) ? half - tb : half;
-                    const double pp = (b[m] > 1e-14) ? half + tb : half;
-                    Qa += pm;
-                    Qb += pp;
-                    PVa = fma(pm, V[2 * m], PVa);
-                    PVb = fma(pp, V[2 * m + 1], PVb);
+                for (int m = 0; m < D; m++) {
+                    if ((UM >> m) & 1u) {
+                        PVa = fma(readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c), V[2 * m], PVa);
+                        PVb = fma(readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c), V[2 * m + 1], PVb);
+                    }
                 }
+                Q = Q0 + readlane_f64(cr.qab, c);
+                num = fma(h2l, stage0, PV0 + (PVa + PVb));
+            } else {
+                double u[DU], cf[NCFa];
+#pragma unroll
+                for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
+                cf[0] = 0.0;
+#pragma unroll
+                for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
+                double b[D], s[D];
+                Model::drift(A.prm, nd, x, u, cf, b);
+                Model::sigma(A.prm, x, u, s);
+                const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
+                double Qa = 0.0, Qb = 0.0, PVa = 0.0, PVb = 0.0; // two short chains instead of one long one
+#pragma unroll
+                for (int m = 0; m < D; m++) {
+                    if ((UM >> m) & 1u) {
+                        double pm, pp;
+                        if ((UCm >> m) & 1u) {
+                            pm = readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c);
+                            pp = readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c);
+                        } else {
+                            const double half = t2l[m] * (s[m] * s[m]) / 2.0;
+                            const double tb = tl[m] * b[m];
+                            pm = (b[m] < -1e-14) ? half - tb : half;
+                            pp = (b[m] > 1e-14) ? half + tb : half;
+                        }
+                        Qa += pm;
+                        Qb += pp;
+                        PVa = fma(pm, V[2 * m], PVa);
+                        PVb = fma(pp, V[2 * m + 1], PVb);
+                    }
+                }
+                Q = Q0 + (Qa + Qb);
+                num = fma(h2l, stage, PV0 + (PVa + PVb));
             }
-            const double Q = Q0 + (Qa + Qb);
-            const double num = fma(h2l, stage, PV0 + (PVa + PVb));
-            if (Q < 1e-14) { st |= C3SC_STATUS_STATIONARY; continue; }
-            if (ui < 0 || num * bq < bnum * Q) {
-                bnum = num;
-                bq = Q;
-                ui = c;
-            }
+            const bool okc = !(Q < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
+            if (!okc && ab == 0) st |= C3SC_STATUS_STATIONARY;
+            const bool take = okc && (ui < 0 || num * bq < bnum * Q);
+            bnum = take ? num : bnum;
+            bq = take ? Q : bq;
+            ui = take ? c : ui;
         }
-        if (ui >= 0) {
+        {
             const double inv = 1.0 / bq;
             const double pself = fma(-bq, inv, 1.0);
-            best = fma(pself, V[2 * D], bnum * inv);
+            best = (ui >= 0) ? fma(pself, V[2 * D], bnum * inv) : 0.0;
         }
+        if (ab != 0) { best = absorbed_cost; ui = -1; }
         return best;
     }
     // Candidates are evaluated CG at a time (CG = 1 where registers are tight): one candidate is a ~40-deep
@@ -419,14 +491,14 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
 #pragma unroll
         for (int q = 0; q < CG; q++) {
             if (c0 + q < A.ncand) {
-                if (!ok[q]) st |= C3SC_STATUS_STATIONARY;
-                else if (ui < 0 || val[q] < best) {
-                    best = val[q];
-                    ui = c0 + q;
-                }
+                if (!ok[q] && ab == 0) st |= C3SC_STATUS_STATIONARY;
+                const bool take = ok[q] && (ui < 0 || val[q] < best);
+                best = take ? val[q] : best;
+                ui = take ? c0 + q : ui;
             }
         }
     }
+    if (ab != 0) { best = absorbed_cost; ui = -1; }
     return best;
 }
 

@@ -16,6 +16,8 @@
 //   D, DU                       state / control dimension
 //   NTAB, tab_dim(t)            number of tables and the dimension each one is indexed by
 //   NCF                         number of per-candidate features
+//   UDEP_MASK, UCONST_MASK      dims whose drift/diffusion depend on the control; those of them that depend on
+//                               nothing else, so their transition rates are constants of the candidate
 //   Node                        per-node invariants computed once per node, not per control
 //   prep(prm, x, tv, node)      tv[t] = value of table t at this node (the kernel looks it up)
 //   drift(prm, node, x, u, cf, b)   b[D]; cf = this candidate's features
@@ -33,6 +35,7 @@ struct Dubins3D {
     static constexpr int D = 3, DU = 1;
     static constexpr int NTAB = 2, NCF = 0; // tables: cos(x2), sin(x2)
     static constexpr unsigned UDEP_MASK = 1u << 2; // dims whose drift/diffusion depend on the control
+    static constexpr unsigned UCONST_MASK = 1u << 2; // ... and on nothing else (no state): rates are per-candidate constants
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double c, s; };
@@ -61,6 +64,7 @@ struct Scar4D {
     static constexpr int D = 4, DU = 2;
     static constexpr int NTAB = 2, NCF = 1; // tables: cos(x2), sin(x2); candidate feature: tan(u0)
     static constexpr unsigned UDEP_MASK = (1u << 2) | (1u << 3);
+    static constexpr unsigned UCONST_MASK = 1u << 3; // b[2] also depends on the speed
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 2; }
     struct Node { double vc, vs, pre; };
@@ -95,6 +99,7 @@ struct Car7D {
     static constexpr int D = 7, DU = 2;
     static constexpr int NTAB = 3, NCF = 0; // tables: cos(x2), sin(x2), tan(x5)
     static constexpr unsigned UDEP_MASK = (1u << 5) | (1u << 6);
+    static constexpr unsigned UCONST_MASK = UDEP_MASK;
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int t) { return t == 2 ? 5 : 2; }
     struct Node { double b0, b1, b4; };
@@ -131,6 +136,7 @@ struct LqgNd {
     static constexpr int D = DIM, DU = DIM / 2;
     static constexpr int NTAB = 0, NCF = 0;
     static constexpr unsigned UDEP_MASK = 0xAAAAAAAAu & ((1u << DIM) - 1u); // odd dims are driven by a control
+    static constexpr unsigned UCONST_MASK = UDEP_MASK;
     static constexpr bool STAGE_UDEP = true;
     __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
@@ -167,6 +173,7 @@ struct Chain {
     static constexpr int D = DIM, DU = 1;
     static constexpr int NTAB = 0, NCF = 0;
     static constexpr unsigned UDEP_MASK = 1u << (DIM - 1);
+    static constexpr unsigned UCONST_MASK = UDEP_MASK;
     static constexpr bool STAGE_UDEP = false;
     __host__ __device__ static constexpr int tab_dim(int) { return 0; }
     struct Node {};
@@ -204,6 +211,7 @@ template <int DIM>
 struct TableModel {
     static constexpr int D = DIM, DU = 1;
     static constexpr int NTAB = 0, NCF = 0;
+    static constexpr unsigned UDEP_MASK = 0, UCONST_MASK = 0;
     static constexpr bool IS_TABLE = true;
 };
 
@@ -213,6 +221,7 @@ struct NoModel {
     static constexpr bool IS_TABLE = false;
     static constexpr int D = DIM, DU = 1;
     static constexpr int NTAB = 0, NCF = 0;
+    static constexpr unsigned UDEP_MASK = 0, UCONST_MASK = 0;
 };
 
 } // namespace c3sc

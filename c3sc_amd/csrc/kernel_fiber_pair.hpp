@@ -22,6 +22,10 @@
 
 #include "kernel_fiber_per_lane.hpp"
 
+#ifndef FPP_ROWPIPE
+#define FPP_ROWPIPE 0
+#endif
+
 namespace c3sc {
 
 constexpr int FPP_THREADS = 128;
@@ -298,6 +302,16 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 if constexpr (H == 0) sL[a * 64 + lane] = L[a];
                 else sR[a * 64 + lane] = R[a];
             }
+            // the fiber's coordinates and table values are only needed when a node is finalised: parked in LDS
+            // (wave 0 writes; both waves hold the same numbers) they do not occupy VGPRs during the partial sums
+            if constexpr (H == 0) {
+                double *PXw = sK + (2 * RP + 2 * (NP + 1) + NP) * 64;
+#pragma unroll
+                for (int m = 0; m < D; m++)
+                    if (m != K) PXw[m * 64 + lane] = x[m];
+#pragma unroll
+                for (int t = 0; t < Model::NTAB; t++) PXw[(D + t) * 64 + lane] = tv[t];
+            }
             pair_barrier();
         }
         FPP_STAMP(2) // half swap
@@ -307,7 +321,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         const double *Gk = ro + A.core_off[K];
         // partial sums of node j owned by this wave, stored straight to LDS rows dst[g*64 + lane]:
         // g < NV neighbour values, g = NV the node value; the node-value partial is also returned
-        auto partials = [&](int j, double *dst) __attribute__((always_inline)) -> double {
+        auto partials = [&](int j, auto &&sink) __attribute__((always_inline)) -> double {
             double pv;
             if constexpr (K == 0) { // G_0[j] is a 1 x r row: a = row, no left vectors
                 double ah[RH];
@@ -318,7 +332,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 for (int i = 0; i < RH; i++) v = fma(ah[i], sR[(H * RH + i) * 64 + lane], v);
                 pv = v;
 #pragma unroll
-                for (int g = 0; g < NV; g++) dst[g * 64 + lane] = dot_reg<RH>(ah, Wh[g]);
+                for (int g = 0; g < NV; g++) sink(g, dot_reg<RH>(ah, Wh[g]));
             } else if constexpr (K == D - 1) { // G_{d-1}[j] is an r x 1 column: c = column, no right vectors
                 double ch[RH];
 #pragma unroll
@@ -328,43 +342,96 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 for (int i = 0; i < RH; i++) v = fma(sL[(H * RH + i) * 64 + lane], ch[i], v);
                 pv = v;
 #pragma unroll
-                for (int g = 0; g < NV; g++) dst[g * 64 + lane] = dot_reg<RH>(Wh[g], ch);
+                for (int g = 0; g < NV; g++) sink(g, dot_reg<RH>(Wh[g], ch));
             } else {
-                const double *G = Gk + (size_t)j * RP * RP;
+                // This wave's rows of G_K[j]: c_h[i] = sum_b G[hi, b] R[b] reads row hi of the row-major copy,
+                // a_h[i] = sum_a L[a] G[a, hi] reads column hi of the column-major one; either is RP contiguous
+                // doubles on the scalar path.  The rows are walked one at a time with the next row's s_load in
+                // flight (volatile asm keeps that order): left to itself the compiler issues every s_load of the
+                // node first and spills the SGPR tuples to VGPR lanes (v_writelane / v_readlane storms).
+                const double *GT = ro + A.coreT_off[K] + (size_t)j * RP * RP + (size_t)H * RH * RP;
+                const double *GC = Gk + (size_t)j * RP * RP + (size_t)H * RH * RP;
                 double ch[RH], ah[RH];
+#if FPP_ROWPIPE == 0
 #pragma unroll
                 for (int i = 0; i < RH; i++) { ch[i] = 0.0; ah[i] = 0.0; }
-                // c_h[i] = sum_b G[H*RH+i, b] R[b]
 #pragma unroll
                 for (int b = 0; b < RP; b++) {
                     const double rb = sR[b * 64 + lane];
 #pragma unroll
-                    for (int i = 0; i < RH; i++) ch[i] = fma(G[H * RH + i + b * RP], rb, ch[i]);
+                    for (int i = 0; i < RH; i++) ch[i] = fma(GT[i * RP + b], rb, ch[i]);
                 }
-                // a_h[i] = sum_a L[a] G[a, H*RH+i]
 #pragma unroll
                 for (int a = 0; a < RP; a++) {
                     const double la = sL[a * 64 + lane];
 #pragma unroll
-                    for (int i = 0; i < RH; i++) ah[i] = fma(la, G[a + (H * RH + i) * RP], ah[i]);
+                    for (int i = 0; i < RH; i++) ah[i] = fma(la, GC[a + i * RP], ah[i]);
                 }
+#else
+                double cur[RP], nxt[RP], vec[RP];
+                {
+                    int o = 0; // an opaque OFFSET orders the loads; laundering the pointer would lose `ro`'s noalias
+                    asm volatile("" : "+s"(o));
+#pragma unroll
+                    for (int b = 0; b < RP; b++) cur[b] = GT[o + b];
+                }
+#pragma unroll
+                for (int b = 0; b < RP; b++) vec[b] = sR[b * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 2 * RH; k++) {
+                    const int i = k < RH ? k : k - RH;
+                    if (k + 1 < 2 * RH) {
+                        int o = (k + 1 < RH) ? (k + 1) * RP : (k + 1 - RH) * RP;
+                        asm volatile("" : "+s"(o));
+                        const double *p = (k + 1 < RH) ? GT : GC;
+#pragma unroll
+                        for (int b = 0; b < RP; b++) nxt[b] = p[o + b];
+                    }
+                    if (k == RH) {
+#pragma unroll
+                        for (int a = 0; a < RP; a++) vec[a] = sL[a * 64 + lane];
+                    }
+                    double e = 0.0, o = 0.0; // two chains per row
+#pragma unroll
+                    for (int b = 0; b < RP; b += 2) {
+                        e = fma(cur[b], vec[b], e);
+                        if (b + 1 < RP) o = fma(cur[b + 1], vec[b + 1], o);
+                    }
+                    const double r = e + o;
+                    if (k < RH) ch[i] = r;
+                    else ah[i] = r;
+                    if (k + 1 < 2 * RH) {
+#pragma unroll
+                        for (int b = 0; b < RP; b++) {
+                            asm volatile("" : "+s"(nxt[b]));
+                            cur[b] = nxt[b];
+                        }
+                    }
+                    if (k < RH) pin_vgpr(ch[i]);
+                    else pin_vgpr(ah[i]);
+                }
+#endif
                 double v = 0.0;
 #pragma unroll
                 for (int i = 0; i < RH; i++) v = fma(sL[(H * RH + i) * 64 + lane], ch[i], v);
                 pv = v;
 #pragma unroll
-                for (int g = 0; g < 2 * K; g++) dst[g * 64 + lane] = dot_reg<RH>(Wh[g], ch);
+                for (int g = 0; g < 2 * K; g++) sink(g, dot_reg<RH>(Wh[g], ch));
 #pragma unroll
-                for (int g = 2 * K; g < NV; g++) dst[g * 64 + lane] = dot_reg<RH>(ah, Wh[g]);
+                for (int g = 2 * K; g < NV; g++) sink(g, dot_reg<RH>(ah, Wh[g]));
             }
-            dst[NV * 64 + lane] = pv;
+            sink(NV, pv);
             return pv;
+        };
+        auto to_lds = [&](double *dst) __attribute__((always_inline)) {
+            return [dst, lane](int g, double v) __attribute__((always_inline)) { dst[g * 64 + lane] = v; };
         };
         // LDS exchange rows after L/R
         double *B0 = sK + 2 * RP * 64;    // wave 0 -> wave 1 : P_0(j1)[NP], then v_0(j0)
         double *B1 = B0 + (NP + 1) * 64;  // wave 1 -> wave 0 : P_1(j0)[NP], then v_1(j1)
         double *B2 = B1 + (NP + 1) * 64;  // wave 1 own       : P_1(j1)[NP]
-        double *B3 = B2 + NP * 64;        // wave 0 own       : P_0(j0)[NP]
+        double *PX = B2 + NP * 64;        // parked per-fiber constants: x[m] (m != K) rows 0..D-1, model tables after
+        static_assert(D + Model::NTAB <= NP, "parking rows exceed the reserved block");
 
         // finalise one node from its assembled stencil (NV neighbour values in gvec order, node value last)
         auto finalize = [&](int jn, const double (&Vt)[NP], double vlo, double vhi) __attribute__((always_inline)) {
@@ -375,10 +442,13 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 else { V[2 * m] = Vt[gvec<K>(m, 0)]; V[2 * m + 1] = Vt[gvec<K>(m, 1)]; }
             }
             V[2 * D] = Vt[NV];
-            x[K] = nr.x_at(jn);
+            double x[D], tv[Model::NTAB > 0 ? Model::NTAB : 1];
+            tv[0] = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; m++) x[m] = (m == K) ? nr.x_at(jn) : PX[m * 64 + lane];
 #pragma unroll
             for (int t = 0; t < Model::NTAB; t++)
-                if (Model::tab_dim(t) == K) tv[t] = nr.tab_at(t, jn); // wave-uniform
+                tv[t] = (Model::tab_dim(t) == K) ? nr.tab_at(t, jn) /* wave-uniform */ : PX[(D + t) * 64 + lane];
             int ab = (obs_fixed & nr.mask_at(jn)) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
@@ -397,7 +467,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         // value of node N-2 (left neighbour of node 0 under a periodic boundary)
         double vwrap = 0.0;
         if (bck == C3SC_PERIODIC) {
-            const double pv = partials(N - 2, H == 0 ? B3 : B2);
+            const double pv = partials(N - 2, [](int, double) __attribute__((always_inline)) {});
             B0[(NP + H) * 64 + lane] = pv; // two spare slots: B0[NP] (wave 0) and B1[0].. use B0[NP] / B1[NP]
             if constexpr (H == 1) B1[NP * 64 + lane] = pv;
             pair_barrier();
@@ -415,13 +485,21 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             const int j0 = 2 * t, j1 = 2 * t + 1;
             const bool has0 = j0 < N, has1 = j1 < N;
             double pv0 = 0.0, pv1 = 0.0;
-            if (has0) {
-                pv0 = partials(j0, H == 0 ? B3 : B1);
-                if constexpr (H == 0) B0[NP * 64 + lane] = pv0;
-            }
-            if (has1) {
-                pv1 = partials(j1, H == 0 ? B0 : B2);
-                if constexpr (H == 1) B1[NP * 64 + lane] = pv1;
+            double Pown[NP]; // wave 0: its partial sums of the node it finalises stay in registers
+#pragma unroll
+            for (int g = 0; g < NP; g++) Pown[g] = 0.0;
+            if constexpr (H == 0) { // the other wave's node first, the own node last
+                if (has1) pv1 = partials(j1, to_lds(B0));
+                if (has0) {
+                    pv0 = partials(j0, [&](int g, double v) __attribute__((always_inline)) { Pown[g] = v; });
+                    B0[NP * 64 + lane] = pv0;
+                }
+            } else {
+                if (has0) pv0 = partials(j0, to_lds(B1));
+                if (has1) {
+                    pv1 = partials(j1, to_lds(B2));
+                    B1[NP * 64 + lane] = pv1;
+                }
             }
             FPP_STAMP(3) // partials + LDS writes
             pair_barrier();
@@ -432,7 +510,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 if (has0) {
                     double P0[NP];
 #pragma unroll
-                    for (int g = 0; g < NP; g++) P0[g] = B3[g * 64 + lane] + B1[g * 64 + lane];
+                    for (int g = 0; g < NP; g++) P0[g] = Pown[g] + B1[g * 64 + lane];
                     v0 = P0[NV];
                     double vlo, vhi;
                     dimk_values(j0, N, bck, v_m1, v0, v1, vwrap, (j0 == 0 ? v1 : vone), vlo, vhi);

@@ -315,12 +315,13 @@ __device__ inline double node_backup_tables(const KArgs &A, const double *__rest
 // (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)
 // neighbour in dim m, V[2D] = value at the node.  The candidate scan keeps the first minimum
 // (strict '<'), as the brute-force c3opt is assumed to.
-template <class Model, int CG = 1>
+template <class Model, int CG = 1, int CGD = 1>
 __device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
                                      const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1], const CandRegs<Model> &cr,
                                      const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st)
 {
     constexpr int D = Model::D, DU = Model::DU;
+    const int nc = __builtin_amdgcn_readfirstlane(A.ncand); // keeps the candidate loops' trip test on the scalar unit
     ui = -1;
     // Absorbed lanes (bellman.c:513-532) do not leave early: the scan below runs with the whole wave active and
     // the absorbed lanes' result is replaced at the end.  The lane-distributed tables (CandRegs, NodeRegs) are
@@ -383,78 +384,98 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         double bnum = 0.0, bq = 1.0;
         constexpr unsigned UCm = Model::UCONST_MASK;
         constexpr bool ALLC = (UCm == UM) && !Model::STAGE_UDEP && Model::NCF == 0; // nothing per candidate needs x
-        for (int c = 0; c < A.ncand; c++) {
-            double Q, num;
-            if constexpr (ALLC) {
-                // every control-dependent rate is a constant of the candidate: 2 FMAs per such dim and one add
-                double PVa = 0.0, PVb = 0.0;
+        // CGD candidates per trip: one candidate is a chain of ~10 dependent f64 operations and with two
+        // wavefronts per SIMD nothing else covers their latency, so independent candidates are interleaved;
+        // the selection below is straight-line (no short-circuit branches) and keeps the scan order.
+        for (int c0 = 0; c0 < nc; c0 += CGD) {
+            double Qq[CGD], numq[CGD];
 #pragma unroll
-                for (int m = 0; m < D; m++) {
-                    if ((UM >> m) & 1u) {
-                        PVa = fma(readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c), V[2 * m], PVa);
-                        PVb = fma(readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c), V[2 * m + 1], PVb);
-                    }
-                }
-                Q = Q0 + readlane_f64(cr.qab, c);
-                num = fma(h2l, stage0, PV0 + (PVa + PVb));
-            } else {
-                double u[DU], cf[NCFa];
+            for (int q = 0; q < CGD; q++) {
+                const int c = (CGD == 1 || c0 + q < nc) ? c0 + q : nc - 1;
+                double Q, num;
+                if constexpr (ALLC) {
+                    // every control-dependent rate is a constant of the candidate: 2 FMAs per such dim and one add
+                    double PVa = 0.0, PVb = 0.0;
 #pragma unroll
-                for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
-                cf[0] = 0.0;
-#pragma unroll
-                for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
-                double b[D], s[D];
-                Model::drift(A.prm, nd, x, u, cf, b);
-                Model::sigma(A.prm, x, u, s);
-                const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
-                double Qa = 0.0, Qb = 0.0, PVa = 0.0, PVb = 0.0; // two short chains instead of one long one
-#pragma unroll
-                for (int m = 0; m < D; m++) {
-                    if ((UM >> m) & 1u) {
-                        double pm, pp;
-                        if ((UCm >> m) & 1u) {
-                            pm = readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c);
-                            pp = readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c);
-                        } else {
-                            const double half = t2l[m] * (s[m] * s[m]) / 2.0;
-                            const double tb = tl[m] * b[m];
-                            pm = (b[m] < -1e-14) ? half - tb : half;
-                            pp = (b[m] > 1e-14) ? half + tb : half;
+                    for (int m = 0; m < D; m++) {
+                        if ((UM >> m) & 1u) {
+                            PVa = fma(readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c), V[2 * m], PVa);
+                            PVb = fma(readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c), V[2 * m + 1], PVb);
                         }
-                        Qa += pm;
-                        Qb += pp;
-                        PVa = fma(pm, V[2 * m], PVa);
-                        PVb = fma(pp, V[2 * m + 1], PVb);
                     }
+                    Q = Q0 + readlane_f64(cr.qab, c);
+                    num = fma(h2l, stage0, PV0 + (PVa + PVb));
+                } else {
+                    double u[DU], cf[NCFa];
+#pragma unroll
+                    for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
+                    cf[0] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
+                    double b[D], sg[D];
+                    Model::drift(A.prm, nd, x, u, cf, b);
+                    Model::sigma(A.prm, x, u, sg);
+                    const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
+                    double Qa = 0.0, Qb = 0.0, PVa = 0.0, PVb = 0.0; // two short chains instead of one long one
+#pragma unroll
+                    for (int m = 0; m < D; m++) {
+                        if ((UM >> m) & 1u) {
+                            double pm, pp;
+                            if ((UCm >> m) & 1u) {
+                                pm = readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c);
+                                pp = readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c);
+                            } else {
+                                const double half = t2l[m] * (sg[m] * sg[m]) / 2.0;
+                                const double tb = tl[m] * b[m];
+                                pm = (b[m] < -1e-14) ? half - tb : half;
+                                pp = (b[m] > 1e-14) ? half + tb : half;
+                            }
+                            Qa += pm;
+                            Qb += pp;
+                            PVa = fma(pm, V[2 * m], PVa);
+                            PVb = fma(pp, V[2 * m + 1], PVb);
+                        }
+                    }
+                    Q = Q0 + (Qa + Qb);
+                    num = fma(h2l, stage, PV0 + (PVa + PVb));
                 }
-                Q = Q0 + (Qa + Qb);
-                num = fma(h2l, stage, PV0 + (PVa + PVb));
+                Qq[q] = Q;
+                numq[q] = num;
             }
-            const bool okc = !(Q < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
-            if (!okc && ab == 0) st |= C3SC_STATUS_STATIONARY;
-            const bool take = okc && (ui < 0 || num * bq < bnum * Q);
-            bnum = take ? num : bnum;
-            bq = take ? Q : bq;
-            ui = take ? c : ui;
+#pragma unroll
+            for (int q = 0; q < CGD; q++) {
+                if (CGD == 1 || c0 + q < nc) { // wave-uniform
+                    const bool okc = !(Qq[q] < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
+                    if (!okc & (ab == 0)) st |= C3SC_STATUS_STATIONARY;
+                    double lhs = numq[q] * bq, rhs = bnum * Qq[q];
+                    pin_vgpr(lhs); // evaluated unconditionally: the compiler must not wrap them in a divergent branch
+                    pin_vgpr(rhs);
+                    const bool better = lhs < rhs;
+                    const bool take = okc & ((ui < 0) | better);
+                    bnum = take ? numq[q] : bnum;
+                    bq = take ? Qq[q] : bq;
+                    ui = take ? c0 + q : ui;
+                }
+            }
         }
         {
             const double inv = 1.0 / bq;
             const double pself = fma(-bq, inv, 1.0);
             best = (ui >= 0) ? fma(pself, V[2 * D], bnum * inv) : 0.0;
         }
-        if (ab != 0) { best = absorbed_cost; ui = -1; }
+        best = (ab != 0) ? absorbed_cost : best;
+        ui = (ab != 0) ? -1 : ui;
         return best;
     }
     // Candidates are evaluated CG at a time (CG = 1 where registers are tight): one candidate is a ~40-deep
     // chain of dependent f64 operations (rates -> Q -> 1/Q -> dt -> value), and with one or two wavefronts per
     // SIMD nothing else hides that latency, so independent candidates are interleaved.
-    for (int c0 = 0; c0 < A.ncand; c0 += CG) {
+    for (int c0 = 0; c0 < nc; c0 += CG) {
         double val[CG];
         bool ok[CG];
 #pragma unroll
         for (int q = 0; q < CG; q++) {
-            const int c = (c0 + q < A.ncand) ? c0 + q : A.ncand - 1;
+            const int c = (c0 + q < nc) ? c0 + q : nc - 1;
             double u[DU], cf[NCFa];
 #pragma unroll
             for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
@@ -491,15 +512,16 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         }
 #pragma unroll
         for (int q = 0; q < CG; q++) {
-            if (c0 + q < A.ncand) {
+            if (c0 + q < nc) {
                 if (!ok[q] && ab == 0) st |= C3SC_STATUS_STATIONARY;
-                const bool take = ok[q] && (ui < 0 || val[q] < best);
+                const bool take = ok[q] & ((ui < 0) | (val[q] < best));
                 best = take ? val[q] : best;
                 ui = take ? c0 + q : ui;
             }
         }
     }
-    if (ab != 0) { best = absorbed_cost; ui = -1; }
+    best = (ab != 0) ? absorbed_cost : best;
+        ui = (ab != 0) ? -1 : ui;
     return best;
 }
 

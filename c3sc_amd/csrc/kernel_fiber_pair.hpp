@@ -22,6 +22,9 @@
 
 #include "kernel_fiber_per_lane.hpp"
 
+#ifndef FPP_CGD
+#define FPP_CGD 3
+#endif
 #ifndef FPP_ROWPIPE
 #define FPP_ROWPIPE 0
 #endif
@@ -455,13 +458,13 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             ab = vary_neighbors(jn, N, bck, ab, lo, hi);
             int ui;
             FPP_STAMP(8) // exchange reads + stencil assembly + flags
-            const double val = node_backup<Model, 1>(A, ro, x, tv, cr, V, ab, ui, st);
+            const double val = node_backup<Model, 1, FPP_CGD>(A, ro, x, tv, cr, V, ab, ui, st);
             FPP_STAMP(9) // control scan
-            if (live) {
-                outv[(size_t)f * N + jn] = val;
-                if (uidx) uidx[(size_t)f * N + jn] = ui;
-                if (absorbed) absorbed[(size_t)f * N + jn] = ab;
-            }
+            // lanes past the last fiber duplicate fiber F-1 and store the same numbers to the same place: no
+            // divergent branch in the node loop (see node_backup on spilled lane tables)
+            outv[(size_t)f * N + jn] = val;
+            if (uidx) uidx[(size_t)f * N + jn] = ui;
+            if (absorbed) absorbed[(size_t)f * N + jn] = ab;
         };
 
         // value of node N-2 (left neighbour of node 0 under a periodic boundary)

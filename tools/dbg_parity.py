@@ -17,6 +17,9 @@ for k in range(7):
     e = np.abs(out - ref)
     bad = np.argwhere(e > 1e-9 * np.abs(ref).max())
     print("k", k, eng.last_kernel(), "max err", e.max(), "nbad", len(bad), "bad fibers", sorted(set(bad[:, 0]))[:10], "bad nodes", sorted(set(bad[:, 1]))[:12])
+    bab = np.argwhere(ab != ab0)
+    for (f, j) in bab[:8]:
+        print("   absorbed mismatch fiber", f, "node", j, "got", ab[f, j], "want", ab0[f, j], "idx", idx[f], "out", out[f, j], "ref", ref[f, j])
 print("---- periodic moved to dim 3, dim 2 reflect")
 w2 = wl.c4_car7d().scaled(ngrid=(11,) * 7, rank=10)
 w2.bc = (1, 1, 3, 2, 3, 3, 3)

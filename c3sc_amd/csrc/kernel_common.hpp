@@ -62,18 +62,17 @@ __device__ inline void wave_sync()
 // fiber is then absorbed, :520-522 / :542-544).  Periodic: node 0 and node n-1 are the same point (Q8).
 __device__ inline bool fixed_neighbors(int i, int n, int bc, int &lo, int &hi)
 {
-    lo = i - 1;
-    hi = i + 1;
-    if (i == 0) {
-        if (bc == C3SC_ABSORB) { lo = i; hi = i; return true; }
-        if (bc == C3SC_REFLECT) { lo = i; hi = i + 1; }
-        else { lo = n - 2; hi = i + 1; }
-    } else if (i == n - 1) {
-        if (bc == C3SC_ABSORB) { lo = i; hi = i; return true; }
-        if (bc == C3SC_REFLECT) { lo = i - 1; hi = i; }
-        else { lo = i - 1; hi = 1; }
-    }
-    return false;
+    // selects only: i differs per lane and the kernels that keep wave-uniform tables in VGPR lanes
+    // (NodeRegs / CandRegs) must not run lane-divergent branches (see node_backup)
+    const bool first = (i == 0), last = (i == n - 1) & !first;
+    const bool absorb = (bc == C3SC_ABSORB), reflect = (bc == C3SC_REFLECT);
+    const int lo_first = absorb ? i : (reflect ? i : n - 2);
+    const int hi_first = absorb ? i : i + 1;
+    const int lo_last = absorb ? i : i - 1;
+    const int hi_last = absorb ? i : (reflect ? i : 1);
+    lo = first ? lo_first : (last ? lo_last : i - 1);
+    hi = first ? hi_first : (last ? hi_last : i + 1);
+    return (first | last) & absorb;
 }
 
 // Neighbour indices of node j along the VARYING dimension and the final absorbed flag:

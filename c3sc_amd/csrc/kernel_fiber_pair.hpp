@@ -33,21 +33,6 @@ namespace c3sc {
 
 constexpr int FPP_THREADS = 128;
 
-__device__ inline void stage_core_n(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride, int nthreads)
-{
-    // dst index = e + (e / elems) * (stride - elems), kept incrementally (no integer division per element)
-    const int total = n_nodes * elems, pad = stride - elems;
-    int j = (int)threadIdx.x / elems, w = (int)threadIdx.x - j * elems;
-    const int dj = nthreads / elems, dw = nthreads - dj * elems;
-#pragma unroll 4
-    for (int e = threadIdx.x; e < total; e += nthreads) {
-        sK[e + j * pad] = src[e];
-        j += dj;
-        w += dw;
-        if (w >= elems) { w -= elems; j++; }
-    }
-}
-
 __device__ inline void pair_barrier()
 { // workgroup barrier + LDS visibility between the two wavefronts.  Only LDS traffic is exchanged, so only
   // lgkmcnt is drained: a workgroup-scope release fence would also wait (vmcnt(0)) for the scattered

@@ -151,18 +151,34 @@ __device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
 }
 
 // cooperative global -> LDS copy of one core with the padded node stride
-__device__ inline void stage_core(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride)
+__device__ inline void stage_core_n(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride, int nthreads)
 {
+    // dst index = e + (e / elems) * (stride - elems), kept incrementally (no integer division per element).
+    // Full trips first (every thread in range), then one tail trip in which the threads past the end repeat the
+    // last element (same value to the same slot): no lane-divergent branch or loop exit.
     const int total = n_nodes * elems, pad = stride - elems;
     int j = (int)threadIdx.x / elems, w = (int)threadIdx.x - j * elems;
-    const int dj = FPL_THREADS / elems, dw = FPL_THREADS - dj * elems;
+    const int dj = nthreads / elems, dw = nthreads - dj * elems;
+    const int full = total / nthreads;
+    int e = threadIdx.x;
 #pragma unroll 4
-    for (int e = threadIdx.x; e < total; e += FPL_THREADS) {
+    for (int it = 0; it < full; it++) {
         sK[e + j * pad] = src[e];
+        e += nthreads;
         j += dj;
         w += dw;
         if (w >= elems) { w -= elems; j++; }
     }
+    if (full * nthreads < total) {
+        const bool in = e < total;
+        const int ee = in ? e : total - 1, jj = in ? j : (total - 1) / elems;
+        sK[ee + jj * pad] = src[ee];
+    }
+}
+
+__device__ inline void stage_core(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride)
+{
+    stage_core_n(sK, src, n_nodes, elems, stride, FPL_THREADS);
 }
 
 // number of neighbour vectors that live in LDS instead of registers: the 2(D-1) vectors need
@@ -497,11 +513,10 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 ab = vary_neighbors(jn, N, bck, ab, lo, hi);
                 int ui;
                 const double val = node_backup<Model, 3>(A, ro, x, tv, cr, Vp, ab, ui, st);
-                if (live) {
-                    outv[(size_t)f * N + jn] = val;
-                    if (uidx) uidx[(size_t)f * N + jn] = ui;
-                    if (absorbed) absorbed[(size_t)f * N + jn] = ab;
-                }
+                // lanes past the last fiber duplicate fiber F-1: same numbers to the same place, no divergent branch
+                outv[(size_t)f * N + jn] = val;
+                if (uidx) uidx[(size_t)f * N + jn] = ui;
+                if (absorbed) absorbed[(size_t)f * N + jn] = ab;
             }
             FPL_STAMP(3) // backup of node j-1
             if (j < N) {

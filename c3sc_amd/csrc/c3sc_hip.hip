@@ -468,20 +468,34 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
     return C3SC_OK;
 }
 
-int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, double *d_out, int32_t *d_uidx,
-                            int32_t *d_absorbed, void *stream)
+static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const int32_t *d_policy, double *d_out,
+                          int32_t *d_uidx, int32_t *d_absorbed, void *stream)
 {
     KArgs A;
     int rc = fill_args(c, k, F, A, true);
     if (rc != C3SC_OK) return rc;
     if (F == 0) return C3SC_OK;
     if (!d_idx || !d_out) return fail(c, C3SC_ERR_ARG, "bellman_fibers: null buffer");
+    A.forced = d_policy;
     const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant, k);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
+}
+
+int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, double *d_out, int32_t *d_uidx,
+                            int32_t *d_absorbed, void *stream)
+{
+    return launch_bellman(c, k, F, d_idx, nullptr, d_out, d_uidx, d_absorbed, stream);
+}
+
+int c3sc_hip_policy_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const int32_t *d_policy, double *d_out,
+                           int32_t *d_absorbed, void *stream)
+{
+    if (F != 0 && !d_policy) return fail(c, C3SC_ERR_ARG, "policy_fibers: null policy");
+    return launch_bellman(c, k, F, d_idx, d_policy, d_out, nullptr, d_absorbed, stream);
 }
 
 int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_tables,
@@ -590,6 +604,31 @@ int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t
     if (rc != C3SC_OK) return rc;
     HIPCHK(c, hipMemcpy(h_out, d_out, F * N * sizeof(double), hipMemcpyDeviceToHost));
     if (h_uidx) HIPCHK(c, hipMemcpy(h_uidx, d_ui, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return C3SC_OK;
+}
+
+int c3sc_hip_policy_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const int32_t *h_policy, double *h_out,
+                                int32_t *h_absorbed)
+{
+    if (!c || c->d == 0 || k < 0 || k >= c->d || (F != 0 && !h_policy)) return fail(c, C3SC_ERR_ARG, "policy_fibers_host: bad arguments");
+    if (F == 0) return C3SC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->ngrid[k];
+    const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * sizeof(double)),
+                 b_i = align256(F * N * sizeof(int32_t));
+    int rc = ensure_scratch(c, b_idx + b_out + 2 * b_i);
+    if (rc != C3SC_OK) return rc;
+    char *base = (char *)c->scratch;
+    int32_t *d_idx = (int32_t *)base;
+    double *d_out = (double *)(base + b_idx);
+    int32_t *d_pol = (int32_t *)(base + b_idx + b_out);
+    int32_t *d_ab = (int32_t *)(base + b_idx + b_out + b_i);
+    HIPCHK(c, hipMemcpy(d_idx, h_idx, F * c->d * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_pol, h_policy, F * N * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = c3sc_hip_policy_fibers(c, k, F, d_idx, d_pol, d_out, h_absorbed ? d_ab : nullptr, nullptr);
+    if (rc != C3SC_OK) return rc;
+    HIPCHK(c, hipMemcpy(h_out, d_out, F * N * sizeof(double), hipMemcpyDeviceToHost));
     if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
     return C3SC_OK;
 }

@@ -38,6 +38,7 @@ struct KArgs {
     double prm[C3SC_MAX_PARAMS];
     unsigned *status;
     unsigned long long *dbgbuf; // [waves][8] segment cycle sums when (dbg & 128)
+    const int32_t *forced;      // policy evaluation (bellman_pi): [F][N] candidate index to apply per node, or null = minimise
     int dbg; // ablation switches for profiling builds (0 in production): see kernel_fiber_pair.hpp
 };
 
@@ -276,7 +277,8 @@ __device__ inline void table_values(const KArgs &A, const double *__restrict__ r
 // [U][2D+1] block, cost = (boundcost, obscost).  Same arithmetic as node_backup below.
 template <int D>
 __device__ inline double node_backup_tables(const KArgs &A, const double *__restrict__ row, const double *__restrict__ cost,
-                                            const double (&V)[2 * D + 1], int ab, int &ui, unsigned &st)
+                                            const double (&V)[2 * D + 1], int ab, int &ui, unsigned &st, bool forced = false,
+                                            int fu = -1)
 {
     ui = -1;
     if (ab == 1) return cost[0];
@@ -304,7 +306,7 @@ __device__ inline double node_backup_tables(const KArgs &A, const double *__rest
         const double ctg = fma(pself, V[2 * D], PV * inv);
         const double ebt = (A.discount == 0.0) ? 1.0 : exp(-A.discount * dt);
         const double val = dt * r[2 * D] + ebt * ctg;
-        if (ui < 0 || val < best) { best = val; ui = c; }
+        if (forced ? (c == fu) : (ui < 0 || val < best)) { best = val; ui = c; }
     }
     return best;
 }
@@ -317,8 +319,11 @@ __device__ inline double node_backup_tables(const KArgs &A, const double *__rest
 template <class Model, int CG = 1, int CGD = 1>
 __device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
                                      const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1], const CandRegs<Model> &cr,
-                                     const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st)
+                                     const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st, bool forced = false,
+                                     int fu = -1)
 {
+    // forced (wave-uniform) = policy evaluation, bellman_pi (bellman.c:1702-1886): the candidate fu (per lane) is
+    // applied instead of the minimiser's; same rates, same bellmanrhs.
     constexpr int D = Model::D, DU = Model::DU;
     const int nc = __builtin_amdgcn_readfirstlane(A.ncand); // keeps the candidate loops' trip test on the scalar unit
     ui = -1;
@@ -450,7 +455,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
                     pin_vgpr(lhs); // evaluated unconditionally: the compiler must not wrap them in a divergent branch
                     pin_vgpr(rhs);
                     const bool better = lhs < rhs;
-                    const bool take = okc & ((ui < 0) | better);
+                    const bool take = okc & (forced ? (c0 + q == fu) : ((ui < 0) | better));
                     bnum = take ? numq[q] : bnum;
                     bq = take ? Qq[q] : bq;
                     ui = take ? c0 + q : ui;
@@ -513,7 +518,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         for (int q = 0; q < CG; q++) {
             if (c0 + q < nc) {
                 if (!ok[q] && ab == 0) st |= C3SC_STATUS_STATIONARY;
-                const bool take = ok[q] & ((ui < 0) | (val[q] < best));
+                const bool take = ok[q] & (forced ? (c0 + q == fu) : ((ui < 0) | (val[q] < best)));
                 best = take ? val[q] : best;
                 ui = take ? c0 + q : ui;
             }

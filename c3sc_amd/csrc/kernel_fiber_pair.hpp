@@ -88,7 +88,7 @@ __device__ inline void dimk_values(int jn, int N, int bck, double vL, double vC,
         tlast = now__;                                                    \
     }
 
-template <class Model, int RP, int K, int H>
+template <class Model, int RP, int K, int H, bool FORCED>
 __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArgs &A, const double *__restrict__ ro,
                                                                      const int32_t *__restrict__ idx, double *__restrict__ outv,
                                                                      int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed,
@@ -443,7 +443,10 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             ab = vary_neighbors(jn, N, bck, ab, lo, hi);
             int ui;
             FPP_STAMP(8) // exchange reads + stencil assembly + flags
-            const double val = node_backup<Model, 1, FPP_CGD>(A, ro, x, tv, cr, V, ab, ui, st);
+            // FORCED (policy evaluation) is a separate instantiation: as a run-time flag it costs the minimising kernel 4 %
+            int fu = -1;
+            if constexpr (FORCED) fu = A.forced[(size_t)f * N + jn];
+            const double val = node_backup<Model, 1, FPP_CGD>(A, ro, x, tv, cr, V, ab, ui, st, FORCED, fu);
             FPP_STAMP(9) // control scan
             // lanes past the last fiber duplicate fiber F-1 and store the same numbers to the same place: no
             // divergent branch in the node loop (see node_backup on spilled lane tables)
@@ -533,7 +536,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
     }
 }
 
-template <class Model, int RP, int K>
+template <class Model, int RP, int K, bool FORCED>
 __global__ void __launch_bounds__(FPP_THREADS, 2)
     k_fiber_pair(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
                  int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
@@ -541,8 +544,8 @@ __global__ void __launch_bounds__(FPP_THREADS, 2)
     extern __shared__ double sKp[];
     unsigned st = 0;
     const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (h == 0) fiber_pair_body<Model, RP, K, 0>(A, ro, idx, outv, uidx, absorbed, sKp, st);
-    else fiber_pair_body<Model, RP, K, 1>(A, ro, idx, outv, uidx, absorbed, sKp, st);
+    if (h == 0) fiber_pair_body<Model, RP, K, 0, FORCED>(A, ro, idx, outv, uidx, absorbed, sKp, st);
+    else fiber_pair_body<Model, RP, K, 1, FORCED>(A, ro, idx, outv, uidx, absorbed, sKp, st);
     if (st) atomicOr(A.status, st);
 }
 

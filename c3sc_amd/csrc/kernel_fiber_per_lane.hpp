@@ -512,7 +512,9 @@ __global__ void __launch_bounds__(FPL_THREADS, 1)
                 int lo, hi;
                 ab = vary_neighbors(jn, N, bck, ab, lo, hi);
                 int ui;
-                const double val = node_backup<Model, 3>(A, ro, x, tv, cr, Vp, ab, ui, st);
+                const bool forced = A.forced != nullptr; // wave-uniform
+                const int fu = forced ? A.forced[(size_t)f * N + jn] : -1;
+                const double val = node_backup<Model, 3>(A, ro, x, tv, cr, Vp, ab, ui, st, forced, fu);
                 // lanes past the last fiber duplicate fiber F-1: same numbers to the same place, no divergent branch
                 outv[(size_t)f * N + jn] = val;
                 if (uidx) uidx[(size_t)f * N + jn] = ui;

@@ -302,13 +302,15 @@ __global__ void __launch_bounds__(256)
             } else {
                 int ui;
                 double val;
+                const bool forced = A.forced != nullptr; // wave-uniform
+                const int fu = forced ? A.forced[(size_t)f * N + jj] : -1;
                 if constexpr (Model::IS_TABLE) {
                     const size_t node = (size_t)f * N + jj;
-                    val = node_backup_tables<D>(A, tbl + node * A.ncand * S, tcost + node * 2, V, ab, ui, st);
+                    val = node_backup_tables<D>(A, tbl + node * A.ncand * S, tcost + node * 2, V, ab, ui, st, forced, fu);
                 } else {
                     double tv[Model::NTAB > 0 ? Model::NTAB : 1];
                     table_values<Model>(A, ro, ix, tv);
-                    val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st);
+                    val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
                 }
                 if (live) {
                     outv[(size_t)f * N + j] = val;

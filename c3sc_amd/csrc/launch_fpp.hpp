@@ -5,8 +5,8 @@
 
 namespace c3sc {
 
-template <class Model, int RP, int K>
-hipError_t launch_fpp(const KArgs &A, const LaunchIO &io)
+template <class Model, int RP, int K, bool FORCED>
+hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
 {
     constexpr int D = Model::D;
     constexpr int NV = 2 * (D - 1), NP = NV + 1, RH = RP / 2;
@@ -21,7 +21,7 @@ hipError_t launch_fpp(const KArgs &A, const LaunchIO &io)
         if (need > doubles) doubles = need;
     }
     const size_t shmem = doubles * sizeof(double);
-    auto kern = k_fiber_pair<Model, RP, K>;
+    auto kern = k_fiber_pair<Model, RP, K, FORCED>;
     static int blocks_per_cu = 0;
     static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
     hipError_t e;
@@ -43,6 +43,12 @@ hipError_t launch_fpp(const KArgs &A, const LaunchIO &io)
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(FPP_THREADS), shmem, io.stream, A, io.ro, io.idx, io.out, io.uidx, io.absorbed);
     return hipGetLastError();
+}
+
+template <class Model, int RP, int K>
+hipError_t launch_fpp(const KArgs &A, const LaunchIO &io)
+{
+    return A.forced ? launch_fpp_impl<Model, RP, K, true>(A, io) : launch_fpp_impl<Model, RP, K, false>(A, io);
 }
 
 #define C3SC_REG_FPP1(MODEL_ID, RP, K, ...)                                                                   \

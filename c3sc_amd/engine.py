@@ -27,6 +27,7 @@ EXPORTS = [
     "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_mca", "c3sc_hip_set_model",
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
     "c3sc_hip_bellman_fibers", "c3sc_hip_bellman_fibers_tables", "c3sc_hip_bellman_fibers_tables_host", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
+    "c3sc_hip_policy_fibers", "c3sc_hip_policy_fibers_host",
     "c3sc_hip_stencil_fibers_host", "c3sc_hip_stencil_fibers_nb", "c3sc_hip_stencil_fibers_nb_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
     "c3sc_hip_debug_read", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]
@@ -62,6 +63,10 @@ def load_library():
         L.c3sc_hip_bellman_fibers_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]
         L.c3sc_hip_stencil_fibers_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.c3sc_hip_policy_fibers.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+        L.c3sc_hip_policy_fibers_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]
         L.c3sc_hip_stencil_fibers_nb_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_void_p]
         L.c3sc_hip_bellman_fibers_tables_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
@@ -229,6 +234,18 @@ class BellmanEngine:
                                                       ui.ctypes.data if ui is not None else None,
                                                       ab.ctypes.data if ab is not None else None), "bellman_fibers_host")
         return out, ui, ab
+
+    def policy_fibers_host(self, k: int, idx: np.ndarray, policy: np.ndarray):
+        """Policy evaluation (batched bellman_pi): apply candidate policy[f, j] at every node."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        policy = np.ascontiguousarray(policy, dtype=np.int32)
+        F, N = idx.shape[0], self.ngrid[k]
+        assert policy.shape == (F, N)
+        out = np.empty((F, N))
+        ab = np.empty((F, N), dtype=np.int32)
+        self._chk(self.L.c3sc_hip_policy_fibers_host(self.h, k, F, idx.ctypes.data, policy.ctypes.data, out.ctypes.data,
+                                                     ab.ctypes.data), "policy_fibers_host")
+        return out, ab
 
     def bellman_fibers_tables_host(self, k: int, idx: np.ndarray, tables: np.ndarray, costs2: np.ndarray):
         """Universal path: tables (F, N, U, 2d+1) = host-evaluated (drift, diag sigma, stage), costs2 (F, N, 2)."""

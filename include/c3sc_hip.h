@@ -105,6 +105,19 @@ int c3sc_hip_set_variant(c3sc_hip_ctx *ctx, int variant);
 int c3sc_hip_bellman_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, double *d_out,
                             int32_t *d_uidx, int32_t *d_absorbed, void *stream);
 
+/* Policy evaluation: batched bellman_pi (bellman.c:1702-1886) without its memo tables.  Same stencil and
+ * neighbour costs from the uploaded value function (the reference's vf_iteration), but every node applies the
+ * GIVEN control candidate instead of minimising: out = bellmanrhs(stage(u), discount, prob(u), dt(u), costs)
+ * (:1807-1815, :1857-1865); absorbed / obstacle nodes get boundcost / obscost (:1787-1801).
+ *   d_policy   int32 [F*N_k]  device: candidate index per node, as returned in d_uidx by
+ *              c3sc_hip_bellman_fibers run on the policy's value function (-1 = no control: value 0)
+ * The reference caches [prob, dt, stage] of the policy per node; here the candidate index is the cache and the
+ * rates are recomputed (a few dozen flops). */
+int c3sc_hip_policy_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, const int32_t *d_policy,
+                           double *d_out, int32_t *d_absorbed, void *stream);
+int c3sc_hip_policy_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, const int32_t *h_policy,
+                                double *h_out, int32_t *h_absorbed);
+
 /* The same hot path for ARBITRARY host callbacks (the reference's examples unchanged): the host evaluates
  * drift_eval / diff_eval / stagecost (dynamics.c:127-139,224-239; bellman.c:414-444) for every (node, candidate)
  * and boundcost / obscost (bellman.c:458,467) for every node of the fibers it submits:

@@ -755,6 +755,10 @@ struct orc_problem {
     struct orc_htable *vi_htable;
     size_t vi_iter;
     size_t nnode_evals;
+    /* policy iteration (util.c workspace: pi_iter, pi_subiter, pi_prob_htable, pi_htable) */
+    struct orc_htable *pi_prob_htable, *pi_htable;
+    size_t pi_iter, pi_subiter;
+    size_t npol_evals, niter_evals, niter_node_evals;
 };
 
 struct orc_problem *orc_problem_create(size_t dx, size_t du, size_t dw, const double *lb, const double *ub,
@@ -788,6 +792,8 @@ void orc_problem_destroy(struct orc_problem *p)
     free(p->xgrid); free(p->ngrid); free(p->h); free(p->t); free(p->cands);
     orc_boundary_free(p->bound);
     orc_htable_destroy(p->vi_htable);
+    orc_htable_destroy(p->pi_prob_htable);
+    orc_htable_destroy(p->pi_htable);
     free(p);
 }
 
@@ -887,6 +893,152 @@ static int optimal_value(struct orc_problem *p, int absorbed, const double *x, c
     return 0;
 }
 
+static void build_fiber_x(const struct orc_problem *p, size_t k, const int *idx, double *x)
+{
+    const size_t dx = p->dx, N = p->ngrid[k];
+    for (size_t j = 0; j < N; j++)
+        for (size_t m = 0; m < dx; m++) x[j * dx + m] = (m == k) ? p->xgrid[m][j] : p->xgrid[m][idx[m]];
+}
+
+/* ---- policy iteration: c3control_pi_solve head (bellman.c:2351-2354), c3control_step_pi (:2243-2249) ---- */
+void orc_problem_pi_begin(struct orc_problem *p)
+{
+    p->pi_iter++;
+    orc_htable_destroy(p->pi_prob_htable);
+    p->pi_prob_htable = orc_htable_create(1000000);
+    orc_htable_destroy(p->pi_htable);
+    p->pi_htable = orc_htable_create(1000000);
+    p->npol_evals = 0;
+}
+void orc_problem_pi_step_begin(struct orc_problem *p)
+{
+    p->pi_subiter++;
+    p->niter_evals = 0;
+    p->niter_node_evals = 0;
+}
+size_t orc_problem_npol_evals(const struct orc_problem *p) { return p->npol_evals; }
+size_t orc_problem_niter_node_evals(const struct orc_problem *p) { return p->niter_node_evals; }
+
+/* bellman_optimal at one node, returning the winning candidate (used by bellman_pi to fix the policy) */
+static int optimal_control(struct orc_problem *p, const double *x, const double *costs, int *uidx)
+{
+    double v;
+    return optimal_value(p, 0, x, costs, &v, uidx);
+}
+
+/* bellman_pi, the live version (bellman.c:1702-1886).  p->vf is vf_iteration, vf_policy the value function the
+ * policy is greedy for.  Quirk Q2 is kept: node values are stored in the PROB table under key1 with one element,
+ * the value memo (pi_htable) is looked up but never filled, and the final loop keys with keys1[ii]. */
+int orc_bellman_pi(struct orc_problem *p, struct orc_valuef *vf_policy, size_t N, const double *x, double *out, int *uidx_out)
+{
+    const size_t dx = p->dx, S = 2 * dx + 1;
+    if (p->pi_prob_htable == NULL) p->pi_prob_htable = orc_htable_create(1000000);
+    if (p->pi_htable == NULL) p->pi_htable = orc_htable_create(1000000);
+    int *absorbed_pol = calloc(N, sizeof(int)), *absorbed = calloc(N, sizeof(int));
+    double *costs_pol = calloc(N * S, sizeof(double)), *costs = calloc(N * S, sizeof(double));
+    size_t *fi = calloc(dx, sizeof(size_t));
+    size_t dim_vary = 0;
+    char (*keys1)[256] = malloc(N * 256), (*keys2)[256] = malloc(N * 256);
+    double **probs = calloc(N, sizeof(double *));
+    size_t *ind_prob_run = calloc(N, sizeof(size_t));
+    size_t nprob_run = 0;
+    int res = orc_mca_get_neighbor_costs(dx, N, x, p->bound, vf_policy, p->ngrid, (const double *const *)p->xgrid, fi,
+                                         &dim_vary, absorbed_pol, costs_pol); /* :1741 */
+    if (res != 0) goto done;
+    size_t key_ind[20];
+    for (size_t i = 0; i < dx; i++) key_ind[i] = fi[i];
+    key_ind[dx] = p->pi_iter;        /* :1759 */
+    key_ind[dx + 1] = p->pi_subiter; /* :1760 */
+    res = orc_mca_get_neighbor_costs(dx, N, x, p->bound, p->vf, p->ngrid, (const double *const *)p->xgrid, fi, &dim_vary,
+                                     absorbed, costs); /* :1767 */
+    if (res != 0) goto done;
+    for (size_t ii = 0; ii < N; ii++) {
+        if (uidx_out) uidx_out[ii] = -1;
+        key_ind[dim_vary] = ii;
+        orc_size_t_a_to_char(key_ind, dx + 2, keys1[ii]);
+        orc_size_t_a_to_char(key_ind, dx + 1, keys2[ii]);
+        size_t nb = 0;
+        const double *out_stored = orc_htable_get_element(p->pi_htable, keys1[ii], &nb);
+        if (out_stored != NULL) {
+            out[ii] = out_stored[0];
+        } else if (absorbed_pol[ii] == 1) { /* :1787 */
+            res = p->model ? orc_model_boundcost(p->model, p->params, x + ii * dx, out + ii) : p->boundc(0.0, x + ii * dx, out + ii);
+            if (res) goto done;
+            orc_htable_add_element(p->pi_prob_htable, keys1[ii], out + ii, 1);
+            p->niter_evals++; p->niter_node_evals++;
+        } else if (absorbed[ii] == -1) { /* :1794 */
+            res = p->model ? orc_model_obscost(p->model, p->params, x + ii * dx, out + ii) : p->obsc(x + ii * dx, out + ii);
+            if (res) goto done;
+            orc_htable_add_element(p->pi_prob_htable, keys1[ii], out + ii, 1);
+            p->niter_evals++; p->niter_node_evals++;
+        } else {
+            p->niter_evals++; p->niter_node_evals++;
+            const double *cached = orc_htable_get_element(p->pi_prob_htable, keys2[ii], &nb);
+            if (cached == NULL) { /* :1808 */
+                p->npol_evals++;
+                probs[ii] = calloc(S + 2, sizeof(double));
+                ind_prob_run[nprob_run++] = ii;
+            } else { /* :1814 */
+                out[ii] = orc_bellmanrhs(dx, p->du, cached[S + 1], NULL, p->discount, cached, NULL, cached[S], NULL,
+                                         costs + ii * S, NULL);
+                if (uidx_out) uidx_out[ii] = -2; /* from the cache */
+                orc_htable_add_element(p->pi_prob_htable, keys1[ii], out + ii, 1);
+            }
+        }
+    }
+    for (size_t r = 0; r < nprob_run; r++) { /* :1832-1869 */
+        const size_t ii = ind_prob_run[r];
+        int ui = -1;
+        res = optimal_control(p, x + ii * dx, costs_pol + ii * S, &ui);
+        if (res) goto done;
+        if (ui < 0) { res = 3; goto done; }
+        const double *u = p->cands + (size_t)ui * p->du;
+        double drift[16], diff[256], stage = 0.0;
+        if (p->model != 0) {
+            double sd[16];
+            res = orc_model_drift(p->model, p->params, x + ii * dx, u, drift);
+            for (size_t i = 0; i < dx * p->dw; i++) diff[i] = 0.0;
+            if (!res) res = orc_model_diff_diag(p->model, p->params, x + ii * dx, u, sd);
+            for (size_t i = 0; i < dx; i++) diff[i * dx + i] = sd[i];
+            if (!res) res = orc_model_stage(p->model, p->params, x + ii * dx, u, &stage);
+        } else {
+            res = p->b(0.0, x + ii * dx, u, drift, NULL, p->bargs);
+            if (!res) res = p->s(0.0, x + ii * dx, u, diff, NULL, p->sargs);
+            if (!res) res = p->stage(0.0, x + ii * dx, u, &stage, NULL);
+        }
+        if (res) goto done;
+        res = orc_transition_assemble(dx, p->du, p->dw, p->h2, p->t, drift, NULL, diff, NULL, probs[ii], NULL,
+                                      probs[ii] + S, NULL, NULL);
+        if (res) { res = 100 + res; goto done; }
+        probs[ii][S + 1] = stage;
+        out[ii] = orc_bellmanrhs(dx, p->du, stage, NULL, p->discount, probs[ii], NULL, probs[ii][S], NULL, costs + ii * S, NULL);
+        if (uidx_out) uidx_out[ii] = ui;
+    }
+    for (size_t r = 0; r < nprob_run; r++) { /* :1876-1880 */
+        orc_htable_add_element(p->pi_prob_htable, keys2[ind_prob_run[r]], probs[ind_prob_run[r]], S + 2);
+        orc_htable_add_element(p->pi_prob_htable, keys1[r], out + ind_prob_run[r], 1);
+    }
+done:
+    for (size_t ii = 0; ii < N; ii++) free(probs[ii]);
+    free(probs); free(ind_prob_run); free(keys1); free(keys2);
+    free(absorbed_pol); free(absorbed); free(costs_pol); free(costs); free(fi);
+    return res;
+}
+
+int orc_policy_fibers(struct orc_problem *p, struct orc_valuef *vf_policy, size_t k, size_t F, const int *idx, double *out,
+                      int *uidx)
+{
+    const size_t dx = p->dx, N = p->ngrid[k];
+    double *x = malloc(N * dx * sizeof(double));
+    int res = 0;
+    for (size_t f = 0; f < F && res == 0; f++) {
+        build_fiber_x(p, k, idx + f * dx, x);
+        res = orc_bellman_pi(p, vf_policy, N, x, out + f * N, uidx ? uidx + f * N : NULL);
+    }
+    free(x);
+    return res;
+}
+
 /* bellman.c:1295-1423 */
 int orc_bellman_vi(struct orc_problem *p, size_t N, const double *x, double *out, int *uidx, int use_memo)
 {
@@ -927,13 +1079,6 @@ int orc_bellman_vi(struct orc_problem *p, size_t N, const double *x, double *out
 done:
     free(absorbed); free(costs); free(fi);
     return res;
-}
-
-static void build_fiber_x(const struct orc_problem *p, size_t k, const int *idx, double *x)
-{
-    const size_t dx = p->dx, N = p->ngrid[k];
-    for (size_t j = 0; j < N; j++)
-        for (size_t m = 0; m < dx; m++) x[j * dx + m] = (m == k) ? p->xgrid[m][j] : p->xgrid[m][idx[m]];
 }
 
 int orc_bellman_fibers(struct orc_problem *p, size_t k, size_t F, const int *idx, double *out, int *uidx,

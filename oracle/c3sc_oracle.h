@@ -143,6 +143,16 @@ int orc_bellman_vi(struct orc_problem *p, size_t N, const double *x, double *out
  * absorbed_out (may be NULL) F*N ints. */
 int orc_bellman_fibers(struct orc_problem *p, size_t k, size_t F, const int *idx, double *out, int *uidx,
                        int *absorbed_out);
+/* Policy iteration (bellman.c:1702-1886, 2214-2262, 2343-2407).  p's value is vf_iteration; vf_policy is the value
+ * function the policy is greedy for.  uidx (may be NULL): candidate applied per node (-1 absorbed, -2 taken from the
+ * cached [prob, dt, stage] of this pi_iter). */
+void orc_problem_pi_begin(struct orc_problem *p);      /* c3control_pi_solve head: ++pi_iter, reset both tables */
+void orc_problem_pi_step_begin(struct orc_problem *p); /* c3control_step_pi head: ++pi_subiter, zero the counters */
+size_t orc_problem_npol_evals(const struct orc_problem *p);
+size_t orc_problem_niter_node_evals(const struct orc_problem *p);
+int orc_bellman_pi(struct orc_problem *p, struct orc_valuef *vf_policy, size_t N, const double *x, double *out, int *uidx);
+int orc_policy_fibers(struct orc_problem *p, struct orc_valuef *vf_policy, size_t k, size_t F, const int *idx, double *out,
+                      int *uidx);
 /* Same for the FT stencil only: out F*N*(2dx+1). */
 int orc_stencil_fibers(struct orc_problem *p, size_t k, size_t F, const int *idx, double *out, int *absorbed_out);
 

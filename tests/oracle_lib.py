@@ -252,6 +252,40 @@ class Problem:
         assert res == 0, f"oracle bellman_fibers failed: {res}"
         return out, uidx, ab
 
+    # ---- policy iteration (bellman_pi, bellman.c:1702-1886)
+    def pi_begin(self):
+        self.L.orc_problem_pi_begin(self.h)
+
+    def pi_step_begin(self):
+        self.L.orc_problem_pi_step_begin(self.h)
+
+    def npol_evals(self):
+        self.L.orc_problem_npol_evals.restype = C.c_size_t
+        return self.L.orc_problem_npol_evals(self.h)
+
+    def niter_node_evals(self):
+        self.L.orc_problem_niter_node_evals.restype = C.c_size_t
+        return self.L.orc_problem_niter_node_evals(self.h)
+
+    def policy_fibers(self, policy_vf, k, idx):
+        """bellman_pi per fiber: the policy is greedy for policy_vf (a ValueF), the iterate is this problem's value."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        F, N = idx.shape[0], self.w.ngrid[k]
+        out = np.zeros((F, N))
+        uidx = np.zeros((F, N), dtype=np.int32)
+        res = self.L.orc_policy_fibers(self.h, policy_vf.h, C.c_size_t(k), C.c_size_t(F), ip(idx), dp(out), ip(uidx))
+        assert res == 0, f"oracle policy_fibers failed: {res}"
+        return out, uidx
+
+    def bellman_pi(self, policy_vf, x):
+        x = f64(x)
+        N = x.shape[0]
+        out = np.zeros(N)
+        uidx = np.zeros(N, dtype=np.int32)
+        res = self.L.orc_bellman_pi(self.h, policy_vf.h, C.c_size_t(N), dp(x), dp(out), ip(uidx))
+        assert res == 0
+        return out, uidx
+
     def stencil_fibers(self, k, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         F = idx.shape[0]

@@ -217,3 +217,41 @@ def test_full_size_properties():
     out_c, _, ab_c = eng.bellman_fibers_host(k, idx)
     live = ab_c == 0
     assert (out_c[live] > 7.5).all() and (out_c[live] < 7.5 + 40.0).all()
+
+
+@pytest.mark.parametrize("name,kw", [SMALL[0], SMALL[2], SMALL[4], SMALL[6], SMALL[7]],
+                         ids=lambda v: v if isinstance(v, str) else f"r{v['rank']}")
+def test_policy_evaluation_vs_oracle(oracle, name, kw):
+    """c3sc_hip_policy_fibers == bellman_pi (bellman.c:1702-1886): the policy is greedy for one value function
+    (argmin from c3sc_hip_bellman_fibers on it), the Bellman right-hand side is evaluated on another."""
+    w = wl.WORKLOADS[name]().scaled(**kw)
+    cores_pol = wl.synth_cores(w)
+    cores_it = [c * (1.0 + 0.05 * np.cos(np.arange(c.size)).reshape(c.shape)) for c in wl.smooth_cores(w)]
+    P = oracle.Problem(w, cores_it)
+    pol_vf = oracle.ValueF(w.ngrid, w.ranks, cores_pol)
+    eng_pol = _engine(w, cores_pol, 0)
+    eng_it = _engine(w, cores_it, 0)
+    P.pi_begin()
+    P.pi_step_begin()
+    worst = 0.0
+    for k in range(w.dx):
+        idx = wl.synth_fibers(w, k, 23)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        idx[:, k] = 0
+        ref, ref_ui = P.policy_fibers(pol_vf, k, idx)
+        _, ui, _ = eng_pol.bellman_fibers_host(k, idx)
+        out, ab = eng_it.policy_fibers_host(k, idx, ui)
+        assert eng_it.status() == 0
+        scale = np.abs(ref).max()
+        # the oracle reports -2 where it reused the cached [prob, dt, stage] of a node seen before in this pi_iter
+        fresh = ref_ui >= 0
+        bad = fresh & (ui != ref_ui)
+        err = np.abs(out - ref)
+        assert err[~bad].max() <= REL_TOL * scale, f"{w.name} k={k}: err {err[~bad].max():.3e} scale {scale:.3e}"
+        # a different argmin is only acceptable on ties of the policy objective; then compare through the oracle's choice
+        if bad.any():
+            out2, _ = eng_it.policy_fibers_host(k, idx, np.where(ref_ui >= 0, ref_ui, ui).astype(np.int32))
+            assert np.abs(out2 - ref).max() <= REL_TOL * scale
+        worst = max(worst, err[~bad].max() / scale)
+    assert P.niter_node_evals() > 0 and P.npol_evals() > 0

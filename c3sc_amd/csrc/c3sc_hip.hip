@@ -498,8 +498,8 @@ int c3sc_hip_policy_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_id
     return launch_bellman(c, k, F, d_idx, d_policy, d_out, nullptr, d_absorbed, stream);
 }
 
-int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_tables,
-                                   const double *d_costs2, double *d_out, int32_t *d_uidx, int32_t *d_absorbed, void *stream)
+static int launch_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_tables, const double *d_costs2,
+                         const int32_t *d_policy, double *d_out, int32_t *d_uidx, int32_t *d_absorbed, void *stream)
 {
     if (!c) return C3SC_ERR_ARG;
     const int saved_model = c->model;
@@ -510,6 +510,7 @@ int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *c, int k, size_t F, const int32
     if (rc != C3SC_OK) return rc;
     if (F == 0) return C3SC_OK;
     if (!d_idx || !d_out || !d_tables || !d_costs2) return fail(c, C3SC_ERR_ARG, "bellman_fibers_tables: null buffer");
+    A.forced = d_policy;
     const KernelEntry *e = find_kernel(C3SC_MODEL_TABLE, c->d, c->rp, A.N, C3SC_VARIANT_AUTO, k);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_tables: no kernel instantiation for (dim, rank, N)");
     c->last_kernel = e->name;
@@ -518,8 +519,21 @@ int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *c, int k, size_t F, const int32
     return C3SC_OK;
 }
 
-int c3sc_hip_bellman_fibers_tables_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const double *h_tables,
-                                        const double *h_costs2, double *h_out, int32_t *h_uidx, int32_t *h_absorbed)
+int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_tables,
+                                   const double *d_costs2, double *d_out, int32_t *d_uidx, int32_t *d_absorbed, void *stream)
+{
+    return launch_tables(c, k, F, d_idx, d_tables, d_costs2, nullptr, d_out, d_uidx, d_absorbed, stream);
+}
+
+int c3sc_hip_policy_fibers_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_tables,
+                                  const double *d_costs2, const int32_t *d_policy, double *d_out, int32_t *d_absorbed, void *stream)
+{
+    if (F != 0 && !d_policy) return fail(c, C3SC_ERR_ARG, "policy_fibers_tables: null policy");
+    return launch_tables(c, k, F, d_idx, d_tables, d_costs2, d_policy, d_out, nullptr, d_absorbed, stream);
+}
+
+static int tables_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const double *h_tables, const double *h_costs2,
+                       const int32_t *h_policy, double *h_out, int32_t *h_uidx, int32_t *h_absorbed)
 {
     if (!c || c->d == 0 || k < 0 || k >= c->d || c->ncand == 0) return fail(c, C3SC_ERR_ARG, "bellman_fibers_tables_host: bad arguments");
     if (F == 0) return C3SC_OK;
@@ -540,12 +554,30 @@ int c3sc_hip_bellman_fibers_tables_host(c3sc_hip_ctx *c, int k, size_t F, const 
     HIPCHK(c, hipMemcpy(d_idx, h_idx, F * c->d * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_t, h_tables, F * N * c->ncand * S * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_c, h_costs2, F * N * 2 * sizeof(double), hipMemcpyHostToDevice));
-    rc = c3sc_hip_bellman_fibers_tables(c, k, F, d_idx, d_t, d_c, d_out, h_uidx ? d_ui : nullptr, h_absorbed ? d_ab : nullptr, nullptr);
+    if (h_policy) { // the uidx buffer carries the policy in
+        HIPCHK(c, hipMemcpy(d_ui, h_policy, F * N * sizeof(int32_t), hipMemcpyHostToDevice));
+        rc = c3sc_hip_policy_fibers_tables(c, k, F, d_idx, d_t, d_c, d_ui, d_out, h_absorbed ? d_ab : nullptr, nullptr);
+    } else {
+        rc = c3sc_hip_bellman_fibers_tables(c, k, F, d_idx, d_t, d_c, d_out, h_uidx ? d_ui : nullptr, h_absorbed ? d_ab : nullptr, nullptr);
+    }
     if (rc != C3SC_OK) return rc;
     HIPCHK(c, hipMemcpy(h_out, d_out, F * N * sizeof(double), hipMemcpyDeviceToHost));
-    if (h_uidx) HIPCHK(c, hipMemcpy(h_uidx, d_ui, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h_uidx && !h_policy) HIPCHK(c, hipMemcpy(h_uidx, d_ui, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
     return C3SC_OK;
+}
+
+int c3sc_hip_bellman_fibers_tables_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const double *h_tables,
+                                        const double *h_costs2, double *h_out, int32_t *h_uidx, int32_t *h_absorbed)
+{
+    return tables_host(c, k, F, h_idx, h_tables, h_costs2, nullptr, h_out, h_uidx, h_absorbed);
+}
+
+int c3sc_hip_policy_fibers_tables_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const double *h_tables,
+                                       const double *h_costs2, const int32_t *h_policy, double *h_out, int32_t *h_absorbed)
+{
+    if (F != 0 && !h_policy) return fail(c, C3SC_ERR_ARG, "policy_fibers_tables_host: null policy");
+    return tables_host(c, k, F, h_idx, h_tables, h_costs2, h_policy, h_out, nullptr, h_absorbed);
 }
 
 int c3sc_hip_stencil_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, double *d_costs, int32_t *d_absorbed,

@@ -27,7 +27,7 @@ EXPORTS = [
     "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_mca", "c3sc_hip_set_model",
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
     "c3sc_hip_bellman_fibers", "c3sc_hip_bellman_fibers_tables", "c3sc_hip_bellman_fibers_tables_host", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
-    "c3sc_hip_policy_fibers", "c3sc_hip_policy_fibers_host",
+    "c3sc_hip_policy_fibers", "c3sc_hip_policy_fibers_host", "c3sc_hip_policy_fibers_tables", "c3sc_hip_policy_fibers_tables_host",
     "c3sc_hip_stencil_fibers_host", "c3sc_hip_stencil_fibers_nb", "c3sc_hip_stencil_fibers_nb_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
     "c3sc_hip_debug_read", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]

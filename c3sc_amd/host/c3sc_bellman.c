@@ -36,8 +36,22 @@ struct ValueF {
     struct c3sc_hip_ctx *bound;  /* device context the cores were uploaded to */
 };
 static unsigned long g_vf_version = 0;
-static unsigned long g_uploaded_version = 0; /* version resident on the (single) device context */
-static struct c3sc_hip_ctx *g_uploaded_ctx = NULL;
+/* which value function is resident on which device context (a workspace owns at most two) */
+#define MAX_TRACKED_CTX 16
+static struct { struct c3sc_hip_ctx *ctx; unsigned long version; uint64_t cfg_sig; int cfg_set; } g_ctx[MAX_TRACKED_CTX];
+static int ctx_slot(struct c3sc_hip_ctx *ctx)
+{
+    int free_slot = -1;
+    for (int i = 0; i < MAX_TRACKED_CTX; i++) {
+        if (g_ctx[i].ctx == ctx) return i;
+        if (g_ctx[i].ctx == NULL && free_slot < 0) free_slot = i;
+    }
+    if (free_slot < 0) { free_slot = 0; } /* recycle: worst case is one redundant upload */
+    g_ctx[free_slot].ctx = ctx;
+    g_ctx[free_slot].version = 0;
+    g_ctx[free_slot].cfg_set = 0;
+    return free_slot;
+}
 
 struct ValueF *valuef_create_nodal(size_t d, const size_t *N, const size_t *ranks, double **cores)
 {
@@ -94,10 +108,10 @@ double valuef_eval_ind(struct ValueF *vf, const size_t *ind)
 void valuef_bind_device(struct ValueF *vf, struct c3sc_hip_ctx *ctx)
 {
     vf->bound = ctx;
-    if (g_uploaded_ctx == ctx && g_uploaded_version == vf->version) return;
+    const int sl = ctx_slot(ctx);
+    if (g_ctx[sl].version == vf->version) return;
     hipok(ctx, c3sc_hip_upload_value(ctx, vf->ranks, (const double *const *)vf->cores), "c3sc_hip_upload_value");
-    g_uploaded_ctx = ctx;
-    g_uploaded_version = vf->version;
+    g_ctx[sl].version = vf->version;
 }
 
 int valuef_eval_fiber_ind_nn(struct ValueF *vf, const size_t *fixed_ind, size_t dim_vary, const size_t *neighbors,
@@ -435,19 +449,15 @@ static uint64_t fnv(uint64_t h, const void *p, size_t n)
     return h;
 }
 
-/* push the host-side problem description to the device context (cheap; idempotent) */
-static struct c3sc_hip_ctx *sync_device(struct VIparam *vi)
+/* push the host-side problem description to a device context (cheap; idempotent) and make vf resident on it */
+static struct c3sc_hip_ctx *sync_device_ctx(struct ControlParams *cp, struct c3sc_hip_ctx *ctx, struct ValueF *vf)
 {
-    struct ControlParams *cp = vi->cp;
     struct MCAparam *mca = cp->mca;
     struct DPparam *dp = cp->dp;
-    struct c3sc_hip_ctx *ctx = workspace_get_hip_ctx(cp->work);
-    static struct c3sc_hip_ctx *cfg_ctx = NULL;
-    static uint64_t cfg_sig = 0;
     const size_t d = mca->dx;
     if (dp->model == 0 && (dp->stagecost == NULL || dp->boundcost == NULL || dp->obscost == NULL))
-        DIE("bellman_vi: neither a device model (dp_param_set_device_model) nor the host callbacks are set");
-    if (!c3opt_is_bruteforce(cp->opt)) DIE("bellman_vi: only BRUTEFORCE control minimisation runs on the device");
+        DIE("bellman_vi/pi: neither a device model (dp_param_set_device_model) nor the host callbacks are set");
+    if (!c3opt_is_bruteforce(cp->opt)) DIE("bellman_vi/pi: only BRUTEFORCE control minimisation runs on the device");
     /* signature of everything the device holds besides the value function */
     int bc[C3SC_MAX_DIM];
     double lb[C3SC_MAX_OBSTACLES * C3SC_MAX_DIM], ub[C3SC_MAX_OBSTACLES * C3SC_MAX_DIM];
@@ -472,19 +482,25 @@ static struct c3sc_hip_ctx *sync_device(struct VIparam *vi)
     sig = fnv(sig, &dp->model, sizeof(int));
     sig = fnv(sig, dp->prm, sizeof(dp->prm));
     sig = fnv(sig, c3opt_get_brute_vals(cp->opt), c3opt_get_nbrute(cp->opt) * c3opt_get_d(cp->opt) * sizeof(double));
-    if (cfg_ctx != ctx || cfg_sig != sig) {
+    const int sl = ctx_slot(ctx);
+    if (!g_ctx[sl].cfg_set || g_ctx[sl].cfg_sig != sig) {
         hipok(ctx, c3sc_hip_set_grid(ctx, (int)d, mca->ngrid, (const double *const *)mca->xgrid), "c3sc_hip_set_grid");
         hipok(ctx, c3sc_hip_set_boundary(ctx, bc, (int)nobs, lb, ub), "c3sc_hip_set_boundary");
         hipok(ctx, c3sc_hip_set_mca(ctx, mca->h2, mca->t, dp->discount), "c3sc_hip_set_mca");
         if (dp->model != 0) hipok(ctx, c3sc_hip_set_model(ctx, dp->model, dp->prm, dp->nprm), "c3sc_hip_set_model");
         hipok(ctx, c3sc_hip_set_controls(ctx, (int)c3opt_get_nbrute(cp->opt), (int)c3opt_get_d(cp->opt), c3opt_get_brute_vals(cp->opt)),
               "c3sc_hip_set_controls");
-        cfg_ctx = ctx;
-        cfg_sig = sig;
-        g_uploaded_ctx = NULL; /* set_grid invalidates the resident value function */
+        g_ctx[sl].cfg_set = 1;
+        g_ctx[sl].cfg_sig = sig;
+        g_ctx[sl].version = 0; /* set_grid invalidates the resident value function */
     }
-    valuef_bind_device(vi->vf, ctx);
+    valuef_bind_device(vf, ctx);
     return ctx;
+}
+
+static struct c3sc_hip_ctx *sync_device(struct VIparam *vi)
+{
+    return sync_device_ctx(vi->cp, workspace_get_hip_ctx(vi->cp->work), vi->vf);
 }
 
 /* first-use cross-check of the device model against the host callbacks: a handful of live nodes are
@@ -650,6 +666,153 @@ int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg
 
 int bellman_vi(size_t N, const double *x, double *out, void *arg) { return bellman_vi_batch(1, N, x, out, arg); }
 
+
+/* =============================================================================== policy iteration */
+struct PIparam { /* bellman.c:1430-1444 */
+    struct ControlParams *cp;
+    struct ValueF *vf_iteration;
+    struct ValueF *vf_policy;
+    size_t npol_evals;       /* nodes whose policy was computed */
+    size_t niter_evals;      /* fiber nodes evaluated in this step */
+    size_t niter_node_evals;
+    double convergence;
+};
+
+struct PIparam *pi_param_create(double convergence, struct ValueF *policy)
+{ /* bellman.c:1446-1464 */
+    struct PIparam *p = xcalloc(1, sizeof(*p));
+    p->convergence = convergence;
+    p->vf_policy = policy;
+    return p;
+}
+void pi_param_destroy(struct PIparam *p) { free(p); }
+void pi_param_add_cp(struct PIparam *p, struct ControlParams *cp) { p->cp = cp; }
+void pi_param_add_value(struct PIparam *p, struct ValueF *vf) { p->vf_iteration = vf; p->niter_evals = 0; p->niter_node_evals = 0; }
+size_t pi_param_get_npol_evals(const struct PIparam *p) { return p->npol_evals; }
+size_t pi_param_get_niter_node_evals(const struct PIparam *p) { return p->niter_node_evals; }
+
+/* bellman_pi (bellman.c:1702-1886) for F fibers.  Per node the reference caches the policy's [prob, dt, stage] under
+ * key2 = (node index, pi_iter); here the cached element is the CANDIDATE INDEX the policy applies (one double), from
+ * which the device recomputes the rates.  Counters follow the reference: every node of every call counts as an
+ * iteration evaluation (its value memo is never filled -- SURVEY.md 9 Q2; the lookup is kept, the mis-keyed 1-element
+ * entries it pushes into the prob table are not), npol_evals counts nodes whose policy had to be computed. */
+int bellman_pi_batch(size_t F, size_t N, const double *x, double *out, void *arg)
+{
+    struct PIparam *pi = arg;
+    struct ControlParams *cp = pi->cp;
+    assert(cp != NULL && pi->vf_policy != NULL && pi->vf_iteration != NULL);
+    struct MCAparam *mca = cp->mca;
+    struct DPparam *dp = cp->dp;
+    const size_t dx = mca->dx;
+    struct c3sc_hip_ctx *ctx_it = sync_device_ctx(cp, workspace_get_hip_ctx(cp->work), pi->vf_iteration);
+    struct c3sc_hip_ctx *ctx_pol = sync_device_ctx(cp, workspace_get_hip_ctx_policy(cp->work), pi->vf_policy);
+    struct HTable *ht_prob = workspace_get_pi_prob_htable(cp->work), *ht_iter = workspace_get_pi_htable(cp->work);
+    size_t *ser = workspace_get_ind_to_serialize(cp->work);
+    char key1[256], key2[256];
+
+    int32_t *idx = xcalloc(F * dx, sizeof(int32_t));
+    int32_t *policy = xcalloc(F * N, sizeof(int32_t));
+    int *absorbed = xcalloc(N, sizeof(int));
+    size_t *nv = xcalloc(2 * N, sizeof(size_t));
+    unsigned char *need = xcalloc(F, 1), *stored = xcalloc(F * N, 1), *miss = xcalloc(F * N, 1);
+    size_t fi[C3SC_MAX_DIM], nf[2 * C3SC_MAX_DIM], k0 = dx;
+    for (size_t f = 0; f < F; f++) {
+        size_t dv;
+        const double *xf = x + f * N * dx;
+        int res = convert_fiber_to_ind(dx, N, xf, mca->ngrid, mca->xgrid, fi, &dv);
+        assert(res == 0 && dv < dx && N == mca->ngrid[dv]);
+        (void)res;
+        if (k0 == dx) k0 = dv;
+        if (dv != k0) DIE("bellman_pi_batch: all fibers of a batch must vary the same dimension");
+        process_fibers_neighbor(dx, fi, dv, xf, absorbed, nv, nf, mca->ngrid, dp->bound);
+        for (size_t m = 0; m < dx; m++) { idx[f * dx + m] = (m == dv) ? 0 : (int32_t)fi[m]; ser[m] = fi[m]; }
+        ser[dx] = workspace_get_pi_iter(cp->work);        /* bellman.c:1759 */
+        ser[dx + 1] = workspace_get_pi_subiter(cp->work); /* :1760 */
+        for (size_t j = 0; j < N; j++) {
+            ser[dv] = j;
+            size_t_a_to_char(ser, dx + 2, key1);
+            size_t_a_to_char(ser, dx + 1, key2);
+            size_t nb = 0;
+            double *v = htable_get_element(ht_iter, key1, &nb); /* :1781 (never filled, Q2) */
+            policy[f * N + j] = -1;
+            if (v != NULL) { out[f * N + j] = v[0]; stored[f * N + j] = 1; continue; }
+            pi->niter_evals++;
+            pi->niter_node_evals++;
+            if (absorbed[j] == 1 || absorbed[j] == -1) continue; /* :1787, :1794: boundcost / obscost on the device */
+            double *c = htable_get_element(ht_prob, key2, &nb); /* :1806 */
+            if (c != NULL) policy[f * N + j] = (int32_t)c[0];
+            else { miss[f * N + j] = 1; need[f] = 1; pi->npol_evals++; }
+        }
+    }
+    const int have_model = dp_has_device_model(dp);
+    const size_t U = c3opt_get_nbrute(cp->opt), S = 2 * dx + 1;
+    double *tables = NULL, *costs2 = NULL;
+    if (!have_model) { /* universal path: host callbacks evaluated once, used by both passes */
+        tables = xcalloc(F * N * U * S, sizeof(double));
+        costs2 = xcalloc(F * N * 2, sizeof(double));
+        for (size_t f = 0; f < F; f++) eval_callback_tables(cp, k0, idx + f * dx, N, x + f * N * dx, tables + f * N * U * S, costs2 + f * N * 2);
+    }
+    /* policy pass: fibers with a node whose policy is not cached yet -> greedy control for vf_policy (:1832-1846) */
+    size_t nrun = 0;
+    for (size_t f = 0; f < F; f++) nrun += need[f];
+    if (nrun > 0) {
+        int32_t *ridx = xcalloc(nrun * dx, sizeof(int32_t)), *rui = xcalloc(nrun * N, sizeof(int32_t));
+        double *rout = xcalloc(nrun * N, sizeof(double));
+        size_t r = 0;
+        for (size_t f = 0; f < F; f++)
+            if (need[f]) memcpy(ridx + (r++) * dx, idx + f * dx, dx * sizeof(int32_t));
+        if (have_model) {
+            hipok(ctx_pol, c3sc_hip_bellman_fibers_host(ctx_pol, (int)k0, nrun, ridx, rout, rui, NULL), "c3sc_hip_bellman_fibers_host");
+        } else {
+            double *rt = xcalloc(nrun * N * U * S, sizeof(double)), *rc2 = xcalloc(nrun * N * 2, sizeof(double));
+            r = 0;
+            for (size_t f = 0; f < F; f++)
+                if (need[f]) {
+                    memcpy(rt + r * N * U * S, tables + f * N * U * S, N * U * S * sizeof(double));
+                    memcpy(rc2 + r * N * 2, costs2 + f * N * 2, N * 2 * sizeof(double));
+                    r++;
+                }
+            hipok(ctx_pol, c3sc_hip_bellman_fibers_tables_host(ctx_pol, (int)k0, nrun, ridx, rt, rc2, rout, rui, NULL),
+                  "c3sc_hip_bellman_fibers_tables_host");
+            free(rt); free(rc2);
+        }
+        unsigned st = 0;
+        hipok(ctx_pol, c3sc_hip_get_status(ctx_pol, &st, 1), "c3sc_hip_get_status");
+        if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+        r = 0;
+        for (size_t f = 0; f < F; f++) {
+            if (!need[f]) continue;
+            for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
+            ser[dx] = workspace_get_pi_iter(cp->work);
+            for (size_t j = 0; j < N; j++) {
+                if (!miss[f * N + j]) continue;
+                policy[f * N + j] = rui[r * N + j];
+                ser[k0] = j;
+                size_t_a_to_char(ser, dx + 1, key2);
+                double c = (double)rui[r * N + j];
+                htable_add_element(ht_prob, key2, &c, 1); /* :1877 (there: 2dx+3 doubles) */
+            }
+            r++;
+        }
+        free(ridx); free(rui); free(rout);
+    }
+    /* evaluation pass on vf_iteration with the policy applied (:1807-1815, :1857-1865) */
+    double *eout = xcalloc(F * N, sizeof(double));
+    if (have_model) hipok(ctx_it, c3sc_hip_policy_fibers_host(ctx_it, (int)k0, F, idx, policy, eout, NULL), "c3sc_hip_policy_fibers_host");
+    else hipok(ctx_it, c3sc_hip_policy_fibers_tables_host(ctx_it, (int)k0, F, idx, tables, costs2, policy, eout, NULL),
+               "c3sc_hip_policy_fibers_tables_host");
+    unsigned st = 0;
+    hipok(ctx_it, c3sc_hip_get_status(ctx_it, &st, 1), "c3sc_hip_get_status");
+    if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+    for (size_t i = 0; i < F * N; i++)
+        if (!stored[i]) out[i] = eout[i];
+    free(eout); free(tables); free(costs2);
+    free(idx); free(policy); free(absorbed); free(nv); free(need); free(stored); free(miss);
+    return 0;
+}
+
+int bellman_pi(size_t N, const double *x, double *out, void *arg) { return bellman_pi_batch(1, N, x, out, arg); }
+
 /* =============================================================================== C3Control */
 struct C3Control {
     size_t dx, du, dw;
@@ -714,6 +877,31 @@ struct VIparam *c3control_begin_vi(struct C3Control *c, struct ValueF *vf, struc
     vi_param_add_value(vi, vf);
     workspace_increment_vi_iter(c->work);
     return vi;
+}
+
+struct PIparam *c3control_begin_pi(struct C3Control *c, struct ValueF *policy)
+{ /* head of c3control_pi_solve (bellman.c:2351-2354): a new policy -> new pi_iter, both tables emptied */
+    struct PIparam *pi = pi_param_create(1e-10, policy);
+    workspace_increment_pi_iter(c->work);
+    workspace_reset_pi_prob_htable(c->work);
+    workspace_reset_pi_htable(c->work);
+    return pi;
+}
+
+void c3control_begin_pi_step(struct C3Control *c, struct PIparam *pi, struct ValueF *vf, struct c3Opt *opt)
+{ /* c3control_step_pi before valuef_interp (bellman.c:2236-2249) */
+    c->cp_active = control_params_create(c->dx, c->dw, c->dp, c->mca, c->work, opt);
+    pi_param_add_cp(pi, c->cp_active);
+    pi_param_add_value(pi, vf);
+    workspace_increment_pi_subiter(c->work);
+}
+
+void c3control_end_pi_step(struct C3Control *c, struct PIparam *pi, size_t *niter_evals)
+{
+    if (niter_evals) *niter_evals = pi->niter_node_evals;
+    control_params_destroy(c->cp_active);
+    c->cp_active = NULL;
+    pi_param_add_cp(pi, NULL);
 }
 
 void c3control_end_vi(struct C3Control *c, struct VIparam *vi, size_t *nevals)

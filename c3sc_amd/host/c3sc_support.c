@@ -302,8 +302,11 @@ struct Workspace {
     size_t *ind_to_serialize;
     struct HTable *vi_htable;
     size_t vi_iter;
-    char **keys;
-    struct c3sc_hip_ctx *hip;
+    char **keys, **keys2;
+    struct c3sc_hip_ctx *hip, *hip_policy;
+    /* policy iteration (util.c:700-715, 766-779) */
+    struct HTable *pi_prob_htable, *pi_htable;
+    size_t pi_iter, pi_subiter;
 };
 
 #define NBUCKET 1000000 /* util.c:760 */
@@ -321,14 +324,20 @@ struct Workspace *workspace_alloc(size_t dx, size_t du, size_t dw, size_t N)
     w->ind_to_serialize = xmalloc((dx + 3) * sizeof(size_t));
     w->vi_htable = htable_create(NBUCKET);
     w->keys = xmalloc(N * sizeof(char *));
-    for (size_t i = 0; i < N; i++) w->keys[i] = xmalloc(256);
+    w->keys2 = xmalloc(N * sizeof(char *));
+    for (size_t i = 0; i < N; i++) { w->keys[i] = xmalloc(256); w->keys2[i] = xmalloc(256); }
+    w->pi_prob_htable = htable_create(NBUCKET);
+    w->pi_htable = htable_create(NBUCKET);
     return w;
 }
 
 void workspace_free(struct Workspace *w)
 {
     if (w == NULL) return;
-    for (size_t i = 0; i < w->N; i++) free(w->keys[i]);
+    for (size_t i = 0; i < w->N; i++) { free(w->keys[i]); free(w->keys2[i]); }
+    free(w->keys2);
+    htable_destroy(w->pi_prob_htable); htable_destroy(w->pi_htable);
+    if (w->hip_policy) c3sc_hip_ctx_destroy(w->hip_policy);
     free(w->keys); free(w->slab); free(w->costs); free(w->absorbed); free(w->ind_to_serialize);
     htable_destroy(w->vi_htable);
     if (w->hip) c3sc_hip_ctx_destroy(w->hip);
@@ -359,16 +368,38 @@ double *workspace_get_costs(struct Workspace *w, size_t n) { return w->costs + n
 int *workspace_get_absorbed(struct Workspace *w, size_t n) { return w->absorbed + n; }
 size_t *workspace_get_ind_to_serialize(struct Workspace *w) { return w->ind_to_serialize; }
 char **workspace_get_saved_keys(struct Workspace *w) { return w->keys; }
+char **workspace_get_saved_keys2(struct Workspace *w) { return w->keys2; }
+void workspace_reset_pi_prob_htable(struct Workspace *w) { htable_destroy(w->pi_prob_htable); w->pi_prob_htable = htable_create(NBUCKET); }
+void workspace_reset_pi_htable(struct Workspace *w) { htable_destroy(w->pi_htable); w->pi_htable = htable_create(NBUCKET); }
+struct HTable *workspace_get_pi_prob_htable(const struct Workspace *w) { return w->pi_prob_htable; }
+struct HTable *workspace_get_pi_htable(const struct Workspace *w) { return w->pi_htable; }
+void workspace_increment_pi_iter(struct Workspace *w) { w->pi_iter++; }
+void workspace_increment_pi_subiter(struct Workspace *w) { w->pi_subiter++; }
+size_t workspace_get_pi_iter(const struct Workspace *w) { return w->pi_iter; }
+size_t workspace_get_pi_subiter(const struct Workspace *w) { return w->pi_subiter; }
+
+static struct c3sc_hip_ctx *make_ctx(void)
+{
+    struct c3sc_hip_ctx *ctx = NULL;
+    const char *dev = getenv("C3SC_HIP_DEVICE");
+    int rc = c3sc_hip_ctx_create(dev ? atoi(dev) : 0, &ctx);
+    if (rc != C3SC_OK) { /* no CPU fallback: the reference style is to print and exit(1) */
+        fprintf(stderr, "c3sc: cannot create the MI355X context (code %d); the Bellman backup has no CPU fallback\n", rc);
+        exit(1);
+    }
+    return ctx;
+}
 
 struct c3sc_hip_ctx *workspace_get_hip_ctx(struct Workspace *w)
 {
-    if (w->hip == NULL) {
-        const char *dev = getenv("C3SC_HIP_DEVICE");
-        int rc = c3sc_hip_ctx_create(dev ? atoi(dev) : 0, &w->hip);
-        if (rc != C3SC_OK) { /* no CPU fallback: the reference style is to print and exit(1) */
-            fprintf(stderr, "c3sc: cannot create the MI355X context (code %d); the Bellman backup has no CPU fallback\n", rc);
-            exit(1);
-        }
-    }
+    if (w->hip == NULL) w->hip = make_ctx();
     return w->hip;
+}
+
+/* second engine holding the POLICY's value function during policy iteration (bellman_pi reads two value
+ * functions per fiber, bellman.c:1741 and :1767) */
+struct c3sc_hip_ctx *workspace_get_hip_ctx_policy(struct Workspace *w)
+{
+    if (w->hip_policy == NULL) w->hip_policy = make_ctx();
+    return w->hip_policy;
 }

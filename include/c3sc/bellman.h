@@ -55,6 +55,18 @@ int bellman_vi(size_t N, const double *x, double *out, void *arg); /* bellman.c:
  * N x dx; memo semantics identical to F successive bellman_vi calls */
 int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg);
 
+/* policy evaluation (bellman.c:1430-1491, 1702-1886): vf_policy fixes the control at every node, the Bellman
+ * right-hand side is evaluated on vf_iteration */
+struct PIparam;
+struct PIparam *pi_param_create(double convergence, struct ValueF *policy);
+void pi_param_destroy(struct PIparam *);
+void pi_param_add_cp(struct PIparam *, struct ControlParams *);
+void pi_param_add_value(struct PIparam *, struct ValueF *);
+size_t pi_param_get_npol_evals(const struct PIparam *);       /* new: read-only views of the reference's counters */
+size_t pi_param_get_niter_node_evals(const struct PIparam *);
+int bellman_pi(size_t N, const double *x, double *out, void *arg); /* bellman.c:1702-1886 */
+int bellman_pi_batch(size_t F, size_t N, const double *x, double *out, void *arg); /* new: many fibers per launch */
+
 struct C3Control;
 struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, double *ub, size_t *ngrid,
                                    double discount); /* bellman.c:1962-1999 */
@@ -73,4 +85,9 @@ void c3control_set_device_model(struct C3Control *, int model, const double *par
  * cross approximation that consumes it (valuef_interp -> C3) is out of scope, so the caller drives the fibers */
 struct VIparam *c3control_begin_vi(struct C3Control *, struct ValueF *vf, struct c3Opt *opt);
 void c3control_end_vi(struct C3Control *, struct VIparam *, size_t *nevals);
+/* the same for policy iteration: c3control_pi_solve's head (bellman.c:2351-2354) and c3control_step_pi's
+ * callback state (bellman.c:2236-2249) */
+struct PIparam *c3control_begin_pi(struct C3Control *, struct ValueF *policy);
+void c3control_begin_pi_step(struct C3Control *, struct PIparam *, struct ValueF *vf, struct c3Opt *opt);
+void c3control_end_pi_step(struct C3Control *, struct PIparam *, size_t *niter_evals);
 #endif

@@ -65,7 +65,18 @@ double *workspace_get_costs(struct Workspace *, size_t node);
 int *workspace_get_absorbed(struct Workspace *, size_t node);
 size_t *workspace_get_ind_to_serialize(struct Workspace *);
 char **workspace_get_saved_keys(struct Workspace *);
+char **workspace_get_saved_keys2(struct Workspace *);
+/* policy iteration state (util.c:700-715, 766-779, 930-964) */
+void workspace_reset_pi_prob_htable(struct Workspace *);
+void workspace_reset_pi_htable(struct Workspace *);
+struct HTable *workspace_get_pi_prob_htable(const struct Workspace *);
+struct HTable *workspace_get_pi_htable(const struct Workspace *);
+void workspace_increment_pi_iter(struct Workspace *);
+void workspace_increment_pi_subiter(struct Workspace *);
+size_t workspace_get_pi_iter(const struct Workspace *);
+size_t workspace_get_pi_subiter(const struct Workspace *);
 /* new: the MI355X engine this workspace drives (created on first use; aborts if no GPU) */
 struct c3sc_hip_ctx;
 struct c3sc_hip_ctx *workspace_get_hip_ctx(struct Workspace *);
+struct c3sc_hip_ctx *workspace_get_hip_ctx_policy(struct Workspace *); /* holds the policy's value function */
 #endif

@@ -130,6 +130,13 @@ int c3sc_hip_bellman_fibers_tables(c3sc_hip_ctx *ctx, int k, size_t F, const int
 int c3sc_hip_bellman_fibers_tables_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx,
                                         const double *h_tables, const double *h_costs2, double *h_out,
                                         int32_t *h_uidx, int32_t *h_absorbed);
+/* policy evaluation (bellman_pi) with host-evaluated callbacks: as c3sc_hip_policy_fibers, rates from the tables */
+int c3sc_hip_policy_fibers_tables(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, const double *d_tables,
+                                  const double *d_costs2, const int32_t *d_policy, double *d_out, int32_t *d_absorbed,
+                                  void *stream);
+int c3sc_hip_policy_fibers_tables_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx,
+                                       const double *h_tables, const double *h_costs2, const int32_t *h_policy,
+                                       double *h_out, int32_t *h_absorbed);
 
 /* Batched mca_get_neighbor_costs (nodeutil.c:647-713) only: d_costs double [F*N_k*(2d+1)],
  * layout out[j*(2d+1) + 2m + {0,1}] = (-,+) neighbour in dim m, [.. + 2d] = self. */

@@ -25,7 +25,7 @@ def lib():
         L = C.CDLL(PATH)
         for n in ("boundary_alloc", "drift_alloc", "diff_alloc", "htable_create", "workspace_alloc", "mca_param_create",
                   "dp_param_create", "control_params_create", "vi_param_create", "c3control_create", "c3opt_alloc",
-                  "valuef_create_nodal", "valuef_copy", "c3control_begin_vi", "approx_args_init"):
+                  "valuef_create_nodal", "valuef_copy", "c3control_begin_vi", "approx_args_init", "c3control_begin_pi", "pi_param_create"):
             getattr(L, n).restype = C.c_void_p
         L.size_t_a_to_char.restype = C.c_char_p
         L.c3sc_hashchar.restype = C.c_size_t
@@ -38,6 +38,8 @@ def lib():
         L.c3control_get_xgrid.restype = C.POINTER(c_double_p)
         L.valuef_eval_ind.restype = C.c_double
         L.vi_param_get_nnode_evals.restype = C.c_size_t
+        L.pi_param_get_npol_evals.restype = C.c_size_t
+        L.pi_param_get_niter_node_evals.restype = C.c_size_t
         L.uniform_stride.restype = C.c_size_t
         L.approx_args_get_cross_tol.restype = C.c_double
         L.approx_args_get_maxrank.restype = C.c_size_t
@@ -123,6 +125,33 @@ class Control:
         F, N = x.shape[0], x.shape[1]
         out = np.zeros((F, N))
         rc = self.L.bellman_vi_batch(C.c_size_t(F), C.c_size_t(N), dp(x), dp(out), vi)
+        assert rc == 0
+        return out
+
+    # ---- policy iteration (bellman_pi)
+    def begin_pi(self, policy_vf):
+        return C.c_void_p(self.L.c3control_begin_pi(self.h, policy_vf))
+
+    def begin_pi_step(self, pi, vf):
+        self.L.c3control_begin_pi_step(self.h, pi, vf, self.opt)
+
+    def end_pi_step(self, pi):
+        n = C.c_size_t(0)
+        self.L.c3control_end_pi_step(self.h, pi, C.byref(n))
+        return n.value
+
+    def bellman_pi(self, pi, x):
+        x = f64(x)
+        out = np.zeros(x.shape[0])
+        rc = self.L.bellman_pi(C.c_size_t(x.shape[0]), dp(x), dp(out), pi)
+        assert rc == 0
+        return out
+
+    def bellman_pi_batch(self, pi, x):
+        x = f64(x)
+        F, N = x.shape[0], x.shape[1]
+        out = np.zeros((F, N))
+        rc = self.L.bellman_pi_batch(C.c_size_t(F), C.c_size_t(N), dp(x), dp(out), pi)
         assert rc == 0
         return out
 

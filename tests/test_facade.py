@@ -283,3 +283,43 @@ def test_bellman_vi_batch_and_fiber_nn(oracle):
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     ctl.end_vi(vi)
     ctl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_model", [True, False], ids=["device_model", "host_callbacks"])
+def test_bellman_pi_through_reference_api(oracle, device_model):
+    """c3control_begin_pi (pi_solve head) -> begin_pi_step (step_pi state) -> bellman_pi(N, x, out, poli) with the
+    policy greedy for one value function and the iterate another: values and the reference's counters
+    (npol_evals: policy computed once per node and pi_iter; niter_node_evals: every node of every call, Q2)."""
+    import facade_lib
+
+    w = wl.c2_dubins().scaled(ngrid=(21, 17, 16), rank=4)
+    cores_pol = wl.synth_cores(w)
+    cores_it = [c * (1.0 + 0.05 * np.cos(np.arange(c.size)).reshape(c.shape)) for c in wl.smooth_cores(w)]
+    P = oracle.Problem(w, cores_it)
+    pol_vf = oracle.ValueF(w.ngrid, w.ranks, cores_pol)
+    ctl = facade_lib.Control(w, _callbacks(w), device_model=device_model)
+    vf_pol, vf_it = ctl.valuef(cores_pol), ctl.valuef(cores_it)
+    pi = ctl.begin_pi(vf_pol)
+    P.pi_begin()
+    xg = ctl.xgrid()
+    L = facade_lib.lib()
+    for step in range(2):  # second step: new pi_subiter, same policy -> no new policy evaluations
+        ctl.begin_pi_step(pi, vf_it)
+        P.pi_step_begin()
+        for k in range(3):
+            idx = wl.synth_fibers(w, k, 10)
+            idx[0, :] = 0
+            idx[1, :] = np.array(w.ngrid) - 1
+            N = w.ngrid[k]
+            x = np.array([[[xg[m][j] if m == k else xg[m][row[m]] for m in range(3)] for j in range(N)] for row in idx])
+            ref = np.array([P.bellman_pi(pol_vf, xf)[0] for xf in x])
+            if k == 1:
+                out = np.array([ctl.bellman_pi(pi, xf) for xf in x])  # the callback ABI, one fiber per call
+            else:
+                out = ctl.bellman_pi_batch(pi, x)
+            assert np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert L.pi_param_get_npol_evals(pi) == P.npol_evals()
+        assert ctl.end_pi_step(pi) == P.niter_node_evals()
+    L.pi_param_destroy(pi)
+    ctl.close()

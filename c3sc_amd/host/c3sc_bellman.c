@@ -11,11 +11,9 @@
 
 #include "c3sc/c3sc.h"
 #include "c3sc_hip.h"
+#include "c3sc_private.h"
 
-#define DIE(...)                                                                                   \
-    do { fprintf(stderr, "c3sc: " __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } while (0)
-
-static void *xcalloc(size_t n, size_t s)
+void *c3sc_xcalloc(size_t n, size_t s)
 {
     void *p = calloc(n ? n : 1, s);
     if (p == NULL) DIE("out of memory");
@@ -27,14 +25,7 @@ static void hipok(struct c3sc_hip_ctx *ctx, int rc, const char *what)
     if (rc != C3SC_OK) DIE("%s failed (code %d): %s", what, rc, c3sc_hip_last_error(ctx));
 }
 
-/* =============================================================================== ValueF */
-struct ValueF {
-    size_t d;
-    size_t *N, *ranks;
-    double **cores;
-    unsigned long version;       /* bumps on every construction: identifies an upload */
-    struct c3sc_hip_ctx *bound;  /* device context the cores were uploaded to */
-};
+/* =============================================================================== ValueF (struct in c3sc_private.h) */
 static unsigned long g_vf_version = 0;
 /* which value function is resident on which device context (a workspace owns at most two) */
 #define MAX_TRACKED_CTX 16
@@ -71,14 +62,53 @@ struct ValueF *valuef_create_nodal(size_t d, const size_t *N, const size_t *rank
     return vf;
 }
 
+void valuef_attach_grid(struct ValueF *vf, double **grid)
+{ /* the nodes the cores are sampled on: needed by the continuous norms and off-grid evaluation */
+    if (vf->grid == NULL) vf->grid = xcalloc(vf->d, sizeof(double *));
+    for (size_t m = 0; m < vf->d; m++) {
+        free(vf->grid[m]);
+        vf->grid[m] = xcalloc(vf->N[m], sizeof(double));
+        memcpy(vf->grid[m], grid[m], vf->N[m] * sizeof(double));
+    }
+}
+
+void valuef_set_cross_indices(struct ValueF *vf, const size_t *nisl, int *const *isl, const size_t *nisr, int *const *isr)
+{ /* left sets: nisl[k] tuples over dims 0..k-1; right sets: nisr[k] tuples over dims k+1..d-1 */
+    valuef_free_cross_indices(vf);
+    const size_t d = vf->d;
+    vf->nisl = xcalloc(d, sizeof(size_t)); vf->nisr = xcalloc(d, sizeof(size_t));
+    vf->isl = xcalloc(d, sizeof(int *)); vf->isr = xcalloc(d, sizeof(int *));
+    for (size_t k = 0; k < d; k++) {
+        vf->nisl[k] = nisl[k]; vf->nisr[k] = nisr[k];
+        vf->isl[k] = xcalloc(nisl[k] * (k ? k : 1), sizeof(int));
+        vf->isr[k] = xcalloc(nisr[k] * (d - 1 - k ? d - 1 - k : 1), sizeof(int));
+        if (k > 0) memcpy(vf->isl[k], isl[k], nisl[k] * k * sizeof(int));
+        if (k + 1 < d) memcpy(vf->isr[k], isr[k], nisr[k] * (d - 1 - k) * sizeof(int));
+    }
+}
+
+void valuef_free_cross_indices(struct ValueF *vf)
+{
+    if (vf->isl) for (size_t k = 0; k < vf->d; k++) { free(vf->isl[k]); free(vf->isr[k]); }
+    free(vf->isl); free(vf->isr); free(vf->nisl); free(vf->nisr);
+    vf->isl = vf->isr = NULL; vf->nisl = vf->nisr = NULL;
+}
+
 void valuef_destroy(struct ValueF *vf)
 {
     if (vf == NULL) return;
-    for (size_t m = 0; m < vf->d; m++) free(vf->cores[m]);
-    free(vf->cores); free(vf->N); free(vf->ranks); free(vf);
+    for (size_t m = 0; m < vf->d; m++) { free(vf->cores[m]); if (vf->grid) free(vf->grid[m]); }
+    valuef_free_cross_indices(vf);
+    free(vf->grid); free(vf->cores); free(vf->N); free(vf->ranks); free(vf);
 }
 
-struct ValueF *valuef_copy(struct ValueF *vf) { return valuef_create_nodal(vf->d, vf->N, vf->ranks, vf->cores); }
+struct ValueF *valuef_copy(struct ValueF *vf)
+{ /* valuefunc.c:126-158: the copy keeps the cross index sets (the next interpolation warm-starts from them) */
+    struct ValueF *c = valuef_create_nodal(vf->d, vf->N, vf->ranks, vf->cores);
+    if (vf->grid) valuef_attach_grid(c, vf->grid);
+    if (vf->isl) valuef_set_cross_indices(c, vf->nisl, vf->isl, vf->nisr, vf->isr);
+    return c;
+}
 size_t *valuef_get_ranks(struct ValueF *vf) { return vf->ranks; }
 size_t valuef_get_dim(const struct ValueF *vf) { return vf->d; }
 const size_t *valuef_get_N(const struct ValueF *vf) { return vf->N; }
@@ -910,4 +940,137 @@ void c3control_end_vi(struct C3Control *c, struct VIparam *vi, size_t *nevals)
     vi_param_destroy(vi);
     control_params_destroy(c->cp_active);
     c->cp_active = NULL;
+}
+
+/* =============================================================================== solver loops (bellman.c:2177-2407) */
+struct Diag { /* bellman.c:2409-2420 */
+    size_t iter;
+    int type; /* 0 policy iteration, 1 value iteration */
+    double norm, abs_diff;
+    size_t dim;
+    size_t *ranks;
+    double frac;
+    struct Diag *next;
+};
+
+void diag_destroy(struct Diag **head)
+{
+    struct Diag *cur = head ? *head : NULL;
+    while (cur != NULL) {
+        struct Diag *nx = cur->next;
+        free(cur->ranks);
+        free(cur);
+        cur = nx;
+    }
+    if (head) *head = NULL;
+}
+
+void diag_append(struct Diag **diag, size_t iter, int type, double norm, double abs_diff, size_t dim, size_t *ranks, double frac)
+{
+    struct Diag *n = xcalloc(1, sizeof(*n));
+    n->iter = iter; n->type = type; n->norm = norm; n->abs_diff = abs_diff; n->dim = dim; n->frac = frac;
+    n->ranks = xcalloc(dim + 1, sizeof(size_t));
+    memcpy(n->ranks, ranks, (dim + 1) * sizeof(size_t));
+    if (*diag == NULL) { *diag = n; return; }
+    struct Diag *cur = *diag;
+    while (cur->next != NULL) cur = cur->next;
+    cur->next = n;
+}
+
+void diag_print(struct Diag *head, FILE *fp)
+{ /* one line per iteration: iter type norm abs_diff avg_rank max_rank frac (bellman.c:2467-2491) */
+    for (struct Diag *c = head; c != NULL; c = c->next) {
+        double avg = 0.0;
+        size_t mx = 0;
+        for (size_t i = 1; i < c->dim; i++) { if (c->ranks[i] > mx) mx = c->ranks[i]; avg += (double)c->ranks[i]; }
+        avg /= (double)(c->dim - 1);
+        fprintf(fp, "%zu %d %3.15G %3.15G %3.15G %zu %3.15G \n", c->iter, c->type, c->norm, c->abs_diff, avg, mx, c->frac);
+    }
+}
+
+int diag_save(struct Diag *head, char *filename)
+{
+    FILE *fp = fopen(filename, "w");
+    if (fp == NULL) { fprintf(stderr, "cat: can't open %s\n", filename); return 1; }
+    diag_print(head, fp);
+    fclose(fp);
+    return 0;
+}
+
+size_t diag_count(const struct Diag *head) { size_t n = 0; for (; head; head = head->next) n++; return n; }
+double diag_last_diff(const struct Diag *head) { double d = 0.0; for (; head; head = head->next) d = head->abs_diff; return d; }
+
+struct ValueF *c3control_init_value(struct C3Control *c, int (*f)(size_t, const double *, double *, void *), void *args,
+                                    struct ApproxArgs *aargs, int verbose)
+{ /* bellman.c:2264-2280 */
+    return valuef_interp(c->dx, f, args, c->ngrid, c->xgrid, NULL, aargs, verbose);
+}
+
+struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct ApproxArgs *apargs, struct c3Opt *opt, int verbose,
+                                 size_t *nevals)
+{ /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
+    struct VIparam *vi = c3control_begin_vi(c, vf, opt);
+    struct ValueF *next = valuef_interp_batch(c->dx, bellman_vi_batch, vi, c->ngrid, c->xgrid, vf, apargs, verbose);
+    c3control_end_vi(c, vi, nevals);
+    return next;
+}
+
+struct ValueF *c3control_step_pi(struct C3Control *c, struct ValueF *vf, struct PIparam *poli, struct ApproxArgs *apargs,
+                                 struct c3Opt *opt, int verbose, size_t *niter_evals)
+{ /* bellman.c:2214-2262 */
+    c3control_begin_pi_step(c, poli, vf, opt);
+    struct ValueF *next = valuef_interp_batch(c->dx, bellman_pi_batch, poli, c->ngrid, c->xgrid, vf, apargs, verbose);
+    c3control_end_pi_step(c, poli, niter_evals);
+    return next;
+}
+
+static void report(const char *what, size_t ii, size_t maxiter, double diff, double norm, double frac)
+{
+    printf("\t %s (%zu\\%zu):\n", what, ii + 1, maxiter);
+    printf("\t \t L2 Difference between iterates    = %3.5E\n ", diff);
+    printf("\t \t L2 Norm of current value function = %3.5E\n", norm);
+    printf("\t \t Relative L2 Cauchy difference     = %3.5E\n", diff / norm);
+    printf("\t \t Fraction of states evaluated      = %3.5E\n", frac);
+}
+
+struct ValueF *c3control_vi_solve(struct C3Control *c, size_t maxiter, double abs_conv_tol, struct ValueF *vo,
+                                  struct ApproxArgs *apargs, struct c3Opt *opt, int verbose, struct Diag **diag)
+{ /* bellman.c:2282-2340 */
+    struct ValueF *start = valuef_copy(vo);
+    workspace_reset_vi_htable(c->work);
+    double stot = 1.0;
+    for (size_t m = 0; m < c->dx; m++) stot *= (double)c->ngrid[m];
+    for (size_t ii = 0; ii < maxiter; ii++) {
+        if (ii % 1000 == 0) workspace_reset_vi_htable(c->work); /* precaution against memory growth (2296-2298) */
+        size_t nevals = 0;
+        struct ValueF *next = c3control_step_vi(c, start, apargs, opt, verbose - 1, &nevals);
+        const double diff = valuef_norm2diff(start, next), norm = valuef_norm(next), frac = (double)nevals / stot;
+        if (verbose > 0) report("Value Iteration", ii, maxiter, diff, norm, frac);
+        if (diag != NULL) diag_append(diag, ii, 1, norm, diff, c->dx, valuef_get_ranks(next), frac);
+        valuef_destroy(start);
+        start = next;
+        if (diff < abs_conv_tol) break;
+    }
+    return start;
+}
+
+struct ValueF *c3control_pi_solve(struct C3Control *c, size_t maxiter, double abs_conv_tol, struct ValueF *policy,
+                                  struct ApproxArgs *apargs, struct c3Opt *opt, int verbose, struct Diag **diag)
+{ /* bellman.c:2343-2407 */
+    struct ValueF *start = valuef_copy(policy);
+    struct PIparam *poli = c3control_begin_pi(c, policy);
+    double stot = 1.0;
+    for (size_t m = 0; m < c->dx; m++) stot *= (double)c->ngrid[m];
+    for (size_t ii = 0; ii < maxiter; ii++) {
+        size_t nevals = 0;
+        struct ValueF *next = c3control_step_pi(c, start, poli, apargs, opt, verbose - 1, &nevals);
+        const double diff = valuef_norm2diff(start, next), norm = valuef_norm(next), frac = (double)nevals / stot;
+        if (verbose > 0) report("POLICY ITERATION", ii, maxiter, diff, norm, frac);
+        if (diag != NULL) diag_append(diag, ii, 0, norm, diff, c->dx, valuef_get_ranks(next), frac);
+        valuef_destroy(start);
+        start = next;
+        if (diff < abs_conv_tol) break;
+    }
+    pi_param_destroy(poli);
+    return start;
 }

@@ -1,0 +1,747 @@
+/* c3sc_cross.c -- own nodal TT-cross driver: valuef_interp and the continuous norms of the value function.
+ *
+ * The reference builds every value function by handing the fiber callback (bellman_vi / bellman_pi / a start
+ * cost) to C3's cross approximation (valuefunc.c:603-767 -> ftapprox_cross_rankadapt).  C3 is a third-party
+ * library that is not part of the reference tree, so this file restates the published algorithm it uses --
+ * alternating left/right maxvol cross sweeps over r_k r_{k+1} fibers per core, TT rounding, rank kicking --
+ * with the knobs valuef_interp sets (valuefunc.c:618-649: start rank, cross_tol, round_tol, kickrank,
+ * maxrank clamped to min N, five sweeps, start ranks = reference ranks + 1 and index sets copied from the
+ * reference value function when adapting).  Pivot choices are not pinned by any reference test, so the numerics
+ * are judged by convergence and by the values at the nodes.
+ *
+ * All fibers of one core step are requested in ONE call of the batched callback (bellman_vi_batch /
+ * bellman_pi_batch run them in one kernel launch); a plain callback with the reference's one-fiber ABI is
+ * looped over.
+ *
+ * Working layout of a core with ranks (r0, r1) and N nodes: G[a + r0*(j + N*b)], i.e. the left unfolding
+ * (r0 N) x r1 in column-major order and at the same time the right unfolding r0 x (N r1). */
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "c3sc/c3sc.h"
+#include "c3sc_private.h"
+
+/* ------------------------------------------------------------------------------ small dense kernels */
+
+/* Householder QR of the m x n (m >= n) column-major matrix A: on exit A holds the thin orthonormal Q (m x n),
+ * R (n x n, column-major, upper triangular) is written if not NULL.  Works for rank-deficient A (Q stays
+ * orthonormal). */
+static void qr_thin(size_t m, size_t n, double *A, double *R)
+{
+    assert(m >= n);
+    double *V = xcalloc(m * n, sizeof(double)); /* Householder vectors */
+    double *Rf = xcalloc(n * n, sizeof(double));
+    for (size_t k = 0; k < n; k++) {
+        double *a = A + k * m;
+        double nrm = 0.0;
+        for (size_t i = k; i < m; i++) nrm += a[i] * a[i];
+        nrm = sqrt(nrm);
+        double *v = V + k * m;
+        if (nrm == 0.0) { /* zero column below the diagonal: reflect e_k onto itself */
+            Rf[k + k * n] = 0.0;
+            continue;
+        }
+        const double alpha = a[k] >= 0.0 ? -nrm : nrm;
+        for (size_t i = k; i < m; i++) v[i] = a[i];
+        v[k] -= alpha;
+        double vn = 0.0;
+        for (size_t i = k; i < m; i++) vn += v[i] * v[i];
+        vn = sqrt(vn);
+        if (vn > 0.0) for (size_t i = k; i < m; i++) v[i] /= vn;
+        for (size_t j = k; j < n; j++) { /* apply H = I - 2 v v^T to the trailing columns */
+            double *c = A + j * m, s = 0.0;
+            for (size_t i = k; i < m; i++) s += v[i] * c[i];
+            s *= 2.0;
+            for (size_t i = k; i < m; i++) c[i] -= s * v[i];
+        }
+        for (size_t j = k; j < n; j++) Rf[k + j * n] = A[k + j * m];
+    }
+    for (size_t j = 0; j < n; j++)
+        for (size_t i = 0; i <= j && i < n; i++) Rf[i + j * n] = A[i + j * m];
+    /* accumulate Q = H_0 ... H_{n-1} applied to the first n columns of the identity */
+    for (size_t j = 0; j < n; j++) {
+        double *q = A + j * m;
+        for (size_t i = 0; i < m; i++) q[i] = (i == j) ? 1.0 : 0.0;
+    }
+    for (size_t kk = n; kk-- > 0;) {
+        const double *v = V + kk * m;
+        double vn = 0.0;
+        for (size_t i = kk; i < m; i++) vn += v[i] * v[i];
+        if (vn == 0.0) continue;
+        for (size_t j = 0; j < n; j++) {
+            double *q = A + j * m, s = 0.0;
+            for (size_t i = kk; i < m; i++) s += v[i] * q[i];
+            s *= 2.0;
+            for (size_t i = kk; i < m; i++) q[i] -= s * v[i];
+        }
+    }
+    if (R) memcpy(R, Rf, n * n * sizeof(double));
+    free(V);
+    free(Rf);
+}
+
+/* Solve X S = Q for X (m x r) where S = Q[rows] is r x r: Gaussian elimination with partial pivoting on S^T. */
+static void right_solve(size_t m, size_t r, const double *Q, const size_t *rows, double *X)
+{
+    /* X S = Q  <=>  S^T X^T = Q^T.  Factor T = S^T (r x r) and solve for the m right-hand sides. */
+    double *T = xcalloc(r * r, sizeof(double));
+    size_t *piv = xcalloc(r, sizeof(size_t));
+    for (size_t i = 0; i < r; i++)
+        for (size_t j = 0; j < r; j++) T[i + j * r] = Q[rows[j] + i * m]; /* T[i][j] = S[j][i] */
+    double *B = xcalloc(r * m, sizeof(double)); /* Q^T, r x m col-major */
+    for (size_t c = 0; c < m; c++)
+        for (size_t i = 0; i < r; i++) B[i + c * r] = Q[c + i * m];
+    for (size_t k = 0; k < r; k++) {
+        size_t p = k;
+        for (size_t i = k + 1; i < r; i++) if (fabs(T[i + k * r]) > fabs(T[p + k * r])) p = i;
+        piv[k] = p;
+        if (p != k) {
+            for (size_t j = 0; j < r; j++) { double t = T[k + j * r]; T[k + j * r] = T[p + j * r]; T[p + j * r] = t; }
+            for (size_t c = 0; c < m; c++) { double t = B[k + c * r]; B[k + c * r] = B[p + c * r]; B[p + c * r] = t; }
+        }
+        const double d = T[k + k * r];
+        if (d == 0.0) continue; /* singular pivot: leave (maxvol never selects dependent rows of an orthonormal Q) */
+        for (size_t i = k + 1; i < r; i++) {
+            const double f = T[i + k * r] / d;
+            if (f == 0.0) continue;
+            for (size_t j = k; j < r; j++) T[i + j * r] -= f * T[k + j * r];
+            for (size_t c = 0; c < m; c++) B[i + c * r] -= f * B[k + c * r];
+        }
+    }
+    for (size_t c = 0; c < m; c++) {
+        double *b = B + c * r;
+        for (size_t ii = r; ii-- > 0;) {
+            double s = b[ii];
+            for (size_t j = ii + 1; j < r; j++) s -= T[ii + j * r] * b[j];
+            b[ii] = (T[ii + ii * r] != 0.0) ? s / T[ii + ii * r] : 0.0;
+        }
+        for (size_t i = 0; i < r; i++) X[c + i * m] = b[i];
+    }
+    free(T); free(piv); free(B);
+}
+
+/* maxvol: r rows of the m x r matrix Q (full column rank) whose submatrix has (locally) maximal volume;
+ * B = Q inv(Q[rows]) has entries bounded by 1 + delta on exit. */
+static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
+{
+    /* start: pivoted Gaussian elimination picks r well-conditioned rows */
+    double *W = xcalloc(m * r, sizeof(double));
+    memcpy(W, Q, m * r * sizeof(double));
+    unsigned char *used = xcalloc(m, 1);
+    for (size_t k = 0; k < r; k++) {
+        size_t p = m;
+        double best = -1.0;
+        for (size_t i = 0; i < m; i++)
+            if (!used[i] && fabs(W[i + k * m]) > best) { best = fabs(W[i + k * m]); p = i; }
+        rows[k] = p;
+        used[p] = 1;
+        const double d = W[p + k * m];
+        if (d == 0.0) continue;
+        for (size_t i = 0; i < m; i++) {
+            if (used[i]) continue;
+            const double f = W[i + k * m] / d;
+            if (f == 0.0) continue;
+            for (size_t j = k; j < r; j++) W[i + j * m] -= f * W[p + j * m];
+        }
+    }
+    free(W);
+    free(used);
+    right_solve(m, r, Q, rows, B);
+    for (int it = 0; it < 200; it++) {
+        size_t bi = 0, bj = 0;
+        double best = 0.0;
+        for (size_t j = 0; j < r; j++)
+            for (size_t i = 0; i < m; i++)
+                if (fabs(B[i + j * m]) > best) { best = fabs(B[i + j * m]); bi = i; bj = j; }
+        if (best <= 1.0 + 1e-2) break;
+        /* swap row rows[bj] for row bi: B <- B - B[:,bj] (B[bi,:] - e_bj) / B[bi,bj] */
+        const double piv = B[bi + bj * m];
+        double *rowv = xcalloc(r, sizeof(double)), *colv = xcalloc(m, sizeof(double));
+        for (size_t j = 0; j < r; j++) rowv[j] = B[bi + j * m] - (j == bj ? 1.0 : 0.0);
+        for (size_t i = 0; i < m; i++) colv[i] = B[i + bj * m] / piv;
+        for (size_t j = 0; j < r; j++)
+            if (rowv[j] != 0.0)
+                for (size_t i = 0; i < m; i++) B[i + j * m] -= colv[i] * rowv[j];
+        rows[bj] = bi;
+        free(rowv); free(colv);
+    }
+}
+
+/* One-sided Jacobi SVD of the m x n (m >= n) column-major A: on exit A = U diag(S) (columns sorted by
+ * decreasing S), V (n x n) the right singular vectors. */
+static void svd_jacobi(size_t m, size_t n, double *A, double *S, double *V)
+{
+    for (size_t i = 0; i < n * n; i++) V[i] = 0.0;
+    for (size_t i = 0; i < n; i++) V[i + i * n] = 1.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (size_t p = 0; p + 1 < n; p++)
+            for (size_t q = p + 1; q < n; q++) {
+                double *ap = A + p * m, *aq = A + q * m;
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (size_t i = 0; i < m; i++) { alpha += ap[i] * ap[i]; beta += aq[i] * aq[i]; gamma += ap[i] * aq[i]; }
+                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
+                off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (size_t i = 0; i < m; i++) { const double x = ap[i], y = aq[i]; ap[i] = c * x - s * y; aq[i] = s * x + c * y; }
+                double *vp = V + p * n, *vq = V + q * n;
+                for (size_t i = 0; i < n; i++) { const double x = vp[i], y = vq[i]; vp[i] = c * x - s * y; vq[i] = s * x + c * y; }
+            }
+        if (off < 1e-14) break;
+    }
+    for (size_t j = 0; j < n; j++) {
+        double s = 0.0;
+        for (size_t i = 0; i < m; i++) s += A[i + j * m] * A[i + j * m];
+        S[j] = sqrt(s);
+    }
+    /* sort by decreasing singular value (selection sort on columns) */
+    for (size_t j = 0; j + 1 < n; j++) {
+        size_t b = j;
+        for (size_t l = j + 1; l < n; l++) if (S[l] > S[b]) b = l;
+        if (b != j) {
+            double t = S[j]; S[j] = S[b]; S[b] = t;
+            for (size_t i = 0; i < m; i++) { t = A[i + j * m]; A[i + j * m] = A[i + b * m]; A[i + b * m] = t; }
+            for (size_t i = 0; i < n; i++) { t = V[i + j * n]; V[i + j * n] = V[i + b * n]; V[i + b * n] = t; }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------ TT in the working layout */
+struct tt {
+    size_t d;
+    size_t *N, *r; /* r[d+1] */
+    double **G;    /* G[k][a + r_k*(j + N_k*b)] */
+};
+
+static struct tt *tt_alloc(size_t d, const size_t *N, const size_t *r)
+{
+    struct tt *t = xcalloc(1, sizeof(*t));
+    t->d = d;
+    t->N = xcalloc(d, sizeof(size_t));
+    t->r = xcalloc(d + 1, sizeof(size_t));
+    t->G = xcalloc(d, sizeof(double *));
+    memcpy(t->N, N, d * sizeof(size_t));
+    memcpy(t->r, r, (d + 1) * sizeof(size_t));
+    for (size_t k = 0; k < d; k++) t->G[k] = xcalloc(r[k] * N[k] * r[k + 1], sizeof(double));
+    return t;
+}
+
+static void tt_free(struct tt *t)
+{
+    if (!t) return;
+    for (size_t k = 0; k < t->d; k++) free(t->G[k]);
+    free(t->G); free(t->N); free(t->r); free(t);
+}
+
+static struct tt *tt_copy(const struct tt *s)
+{
+    struct tt *t = tt_alloc(s->d, s->N, s->r);
+    for (size_t k = 0; k < s->d; k++) memcpy(t->G[k], s->G[k], s->r[k] * s->N[k] * s->r[k + 1] * sizeof(double));
+    return t;
+}
+
+static struct tt *tt_from_valuef(const struct ValueF *vf)
+{
+    struct tt *t = tt_alloc(vf->d, vf->N, vf->ranks);
+    for (size_t k = 0; k < vf->d; k++) {
+        const size_t r0 = vf->ranks[k], r1 = vf->ranks[k + 1], N = vf->N[k];
+        for (size_t j = 0; j < N; j++)
+            for (size_t b = 0; b < r1; b++)
+                for (size_t a = 0; a < r0; a++) t->G[k][a + r0 * (j + N * b)] = vf->cores[k][j * r0 * r1 + a + b * r0];
+    }
+    return t;
+}
+
+static struct ValueF *valuef_from_tt(const struct tt *t, double **grid)
+{
+    double **cores = xcalloc(t->d, sizeof(double *));
+    for (size_t k = 0; k < t->d; k++) {
+        const size_t r0 = t->r[k], r1 = t->r[k + 1], N = t->N[k];
+        cores[k] = xcalloc(N * r0 * r1, sizeof(double));
+        for (size_t j = 0; j < N; j++)
+            for (size_t b = 0; b < r1; b++)
+                for (size_t a = 0; a < r0; a++) cores[k][j * r0 * r1 + a + b * r0] = t->G[k][a + r0 * (j + N * b)];
+    }
+    struct ValueF *vf = valuef_create_nodal(t->d, t->N, t->r, cores);
+    for (size_t k = 0; k < t->d; k++) free(cores[k]);
+    free(cores);
+    if (grid) valuef_attach_grid(vf, grid);
+    return vf;
+}
+
+/* right-to-left orthogonalisation: afterwards cores 1..d-1 have orthonormal rows (right unfolding) and
+ * ||T||_F = ||G_0||_F.  Ranks may shrink when r_k > N_k r_{k+1}. */
+static void tt_orthogonalize_rl(struct tt *t)
+{
+    for (size_t k = t->d - 1; k >= 1; k--) {
+        const size_t r0 = t->r[k], N = t->N[k], r1 = t->r[k + 1], cols = N * r1;
+        const size_t p0 = t->r[k - 1], Np = t->N[k - 1], rowsP = p0 * Np;
+        if (cols < r0) {
+            /* more rows than columns (e.g. the last core of a difference TT): A = A * I, so the identity is the
+             * orthonormal factor and A moves into the previous core; the rank drops to cols */
+            double *Pn = xcalloc(rowsP * cols, sizeof(double));
+            for (size_t cc = 0; cc < cols; cc++)
+                for (size_t b = 0; b < r0; b++) {
+                    const double ab = t->G[k][b + r0 * cc];
+                    if (ab == 0.0) continue;
+                    const double *src = t->G[k - 1] + b * rowsP;
+                    double *dst = Pn + cc * rowsP;
+                    for (size_t i = 0; i < rowsP; i++) dst[i] += ab * src[i];
+                }
+            double *Gn = xcalloc(cols * cols, sizeof(double));
+            for (size_t cc = 0; cc < cols; cc++) Gn[cc + cols * cc] = 1.0;
+            free(t->G[k]); t->G[k] = Gn;
+            free(t->G[k - 1]); t->G[k - 1] = Pn;
+            t->r[k] = cols;
+            continue;
+        }
+        /* A = G_k as r0 x cols (cols >= r0): QR of A^T (cols x r0), A^T = Q R  ->  A = R^T Q^T */
+        double *At = xcalloc(cols * r0, sizeof(double));
+        for (size_t c = 0; c < cols; c++)
+            for (size_t a = 0; a < r0; a++) At[c + a * cols] = t->G[k][a + r0 * c];
+        double *R = xcalloc(r0 * r0, sizeof(double));
+        qr_thin(cols, r0, At, R);
+        double *Gn = xcalloc(r0 * cols, sizeof(double));
+        for (size_t c = 0; c < cols; c++)
+            for (size_t a = 0; a < r0; a++) Gn[a + r0 * c] = At[c + a * cols];
+        double *Pn = xcalloc(rowsP * r0, sizeof(double));
+        for (size_t a = 0; a < r0; a++) /* (G_{k-1} R^T)[:, a] = sum_b G_{k-1}[:, b] R[a, b] */
+            for (size_t b = 0; b < r0; b++) {
+                const double rab = R[a + b * r0];
+                if (rab == 0.0) continue;
+                const double *src = t->G[k - 1] + b * rowsP;
+                double *dst = Pn + a * rowsP;
+                for (size_t i = 0; i < rowsP; i++) dst[i] += rab * src[i];
+            }
+        free(t->G[k]); t->G[k] = Gn;
+        free(t->G[k - 1]); t->G[k - 1] = Pn;
+        free(At); free(R);
+    }
+}
+
+static double tt_frob_of_core0(const struct tt *t)
+{
+    double s = 0.0;
+    const size_t n = t->r[0] * t->N[0] * t->r[1];
+    for (size_t i = 0; i < n; i++) s += t->G[0][i] * t->G[0][i];
+    return sqrt(s);
+}
+
+/* TT rounding to relative accuracy eps in the nodal Frobenius norm (ranks never exceed maxrank) */
+static void tt_round(struct tt *t, double eps)
+{
+    if (t->d < 2) return;
+    tt_orthogonalize_rl(t);
+    const double nrm = tt_frob_of_core0(t);
+    const double delta = eps * nrm / sqrt((double)(t->d - 1));
+    for (size_t k = 0; k + 1 < t->d; k++) {
+        const size_t m = t->r[k] * t->N[k], n = t->r[k + 1];
+        const size_t nn = n <= m ? n : m;
+        double *A = t->G[k]; /* m x n col-major */
+        double *S, *V;
+        if (m >= n) {
+            S = xcalloc(n, sizeof(double)); V = xcalloc(n * n, sizeof(double));
+            svd_jacobi(m, n, A, S, V);
+        } else { /* wide: reduce with QR of A^T first is overkill here; pad rows with zeros */
+            double *Ap = xcalloc(n * n, sizeof(double));
+            for (size_t j = 0; j < n; j++) memcpy(Ap + j * n, A + j * m, m * sizeof(double));
+            S = xcalloc(n, sizeof(double)); V = xcalloc(n * n, sizeof(double));
+            svd_jacobi(n, n, Ap, S, V);
+            for (size_t j = 0; j < n; j++) memcpy(A + j * m, Ap + j * n, m * sizeof(double));
+            free(Ap);
+        }
+        size_t rnew = nn;
+        double tail = 0.0;
+        while (rnew > 1 && tail + S[rnew - 1] * S[rnew - 1] <= delta * delta) { tail += S[rnew - 1] * S[rnew - 1]; rnew--; }
+        /* G_k <- U[:, :rnew]; G_{k+1} <- diag(S) V^T [:rnew, :] G_{k+1} */
+        double *Gk = xcalloc(m * rnew, sizeof(double));
+        for (size_t j = 0; j < rnew; j++) {
+            const double inv = S[j] > 0.0 ? 1.0 / S[j] : 0.0;
+            for (size_t i = 0; i < m; i++) Gk[i + j * m] = A[i + j * m] * inv;
+        }
+        const size_t cols = t->N[k + 1] * t->r[k + 2];
+        double *Gn = xcalloc(rnew * cols, sizeof(double));
+        for (size_t c = 0; c < cols; c++)
+            for (size_t j = 0; j < rnew; j++) {
+                double s = 0.0;
+                for (size_t b = 0; b < n; b++) s += V[b + j * n] * t->G[k + 1][b + n * c];
+                Gn[j + rnew * c] = S[j] * s;
+            }
+        free(t->G[k]); t->G[k] = Gk;
+        free(t->G[k + 1]); t->G[k + 1] = Gn;
+        t->r[k + 1] = rnew;
+        free(S); free(V);
+    }
+}
+
+/* a - b as a TT (ranks add) */
+static struct tt *tt_diff(const struct tt *a, const struct tt *b)
+{
+    const size_t d = a->d;
+    size_t *r = xcalloc(d + 1, sizeof(size_t));
+    r[0] = 1; r[d] = 1;
+    for (size_t k = 1; k < d; k++) r[k] = a->r[k] + b->r[k];
+    struct tt *t = tt_alloc(d, a->N, r);
+    for (size_t k = 0; k < d; k++) {
+        const size_t N = a->N[k], ra0 = a->r[k], ra1 = a->r[k + 1], rb0 = b->r[k], rb1 = b->r[k + 1], r0 = r[k];
+        const size_t offa0 = 0, offb0 = (k == 0) ? 0 : ra0, offb1 = (k == d - 1) ? 0 : ra1;
+        const double sign = (k == d - 1) ? -1.0 : 1.0;
+        for (size_t j = 0; j < N; j++) {
+            for (size_t be = 0; be < ra1; be++)
+                for (size_t al = 0; al < ra0; al++) t->G[k][(offa0 + al) + r0 * (j + N * be)] = a->G[k][al + ra0 * (j + N * be)];
+            for (size_t be = 0; be < rb1; be++)
+                for (size_t al = 0; al < rb0; al++)
+                    t->G[k][(offb0 + al) + r0 * (j + N * (offb1 + be))] += sign * b->G[k][al + rb0 * (j + N * be)];
+        }
+    }
+    free(r);
+    return t;
+}
+
+/* continuous L2 norm of the piecewise-multilinear interpolant of a nodal TT: weight every core along its node
+ * index with L^T, M = L L^T the (tridiagonal) mass matrix of the hat functions on that grid, then the plain
+ * Frobenius norm via orthogonalisation (no Gram-matrix cancellation: the error is eps*||T||, not eps*||T||^2). */
+static double tt_norm_l2(const struct tt *src, double **grid)
+{
+    struct tt *t = tt_copy(src);
+    for (size_t k = 0; k < t->d; k++) {
+        const size_t N = t->N[k], r0 = t->r[k], r1 = t->r[k + 1];
+        double *dg = xcalloc(N, sizeof(double)), *lo = xcalloc(N, sizeof(double)); /* L: diagonal and sub-diagonal */
+        for (size_t i = 0; i < N; i++) {
+            const double hl = (i > 0) ? grid[k][i] - grid[k][i - 1] : 0.0;
+            const double hr = (i + 1 < N) ? grid[k][i + 1] - grid[k][i] : 0.0;
+            const double mii = (hl + hr) / 3.0;
+            const double mlo = (i > 0) ? hl / 6.0 : 0.0; /* M[i][i-1] */
+            if (i == 0) { dg[0] = sqrt(mii); lo[0] = 0.0; }
+            else { lo[i] = mlo / dg[i - 1]; dg[i] = sqrt(mii - lo[i] * lo[i]); }
+        }
+        /* G'[.., i, ..] = (L^T G)[i] = dg[i] G[i] + lo[i+1] G[i+1] */
+        for (size_t b = 0; b < r1; b++)
+            for (size_t i = 0; i < N; i++)
+                for (size_t a = 0; a < r0; a++) {
+                    double v = dg[i] * t->G[k][a + r0 * (i + N * b)];
+                    if (i + 1 < N) v += lo[i + 1] * t->G[k][a + r0 * (i + 1 + N * b)];
+                    t->G[k][a + r0 * (i + N * b)] = v;
+                }
+        free(dg); free(lo);
+    }
+    if (t->d > 1) tt_orthogonalize_rl(t);
+    const double nrm = tt_frob_of_core0(t);
+    tt_free(t);
+    return nrm;
+}
+
+static double **unit_grid(size_t d, const size_t *N)
+{
+    double **g = xcalloc(d, sizeof(double *));
+    for (size_t k = 0; k < d; k++) {
+        g[k] = xcalloc(N[k], sizeof(double));
+        for (size_t i = 0; i < N[k]; i++) g[k][i] = (double)i;
+    }
+    return g;
+}
+
+double valuef_norm(struct ValueF *vf)
+{ /* valuefunc.c:315-322 -> function_train_norm2 of linear elements: sqrt(int V^2) */
+    struct tt *t = tt_from_valuef(vf);
+    double **g = vf->grid ? vf->grid : unit_grid(vf->d, vf->N);
+    const double n = tt_norm_l2(t, g);
+    if (!vf->grid) { for (size_t k = 0; k < vf->d; k++) free(g[k]); free(g); }
+    tt_free(t);
+    return n;
+}
+
+double valuef_norm2diff(struct ValueF *a, struct ValueF *b)
+{ /* valuefunc.c:324-335 */
+    assert(a->d == b->d);
+    struct tt *ta = tt_from_valuef(a), *tb = tt_from_valuef(b);
+    struct tt *td = tt_diff(ta, tb);
+    double **g = a->grid ? a->grid : (b->grid ? b->grid : unit_grid(a->d, a->N));
+    const double n = tt_norm_l2(td, g);
+    if (!a->grid && !b->grid) { for (size_t k = 0; k < a->d; k++) free(g[k]); free(g); }
+    tt_free(ta); tt_free(tb); tt_free(td);
+    return n;
+}
+
+double valuef_eval(struct ValueF *vf, const double *x)
+{ /* valuefunc.c:337-343: the piecewise-multilinear interpolant at an arbitrary point (clamped to the grid) */
+    if (vf->grid == NULL) DIE("valuef_eval: the value function has no grid attached (valuef_attach_grid)");
+    size_t rmax = 1;
+    for (size_t m = 0; m <= vf->d; m++) if (vf->ranks[m] > rmax) rmax = vf->ranks[m];
+    double *v = xcalloc(2 * rmax, sizeof(double)), *w = v + rmax;
+    v[0] = 1.0;
+    for (size_t m = 0; m < vf->d; m++) {
+        const size_t N = vf->N[m], r0 = vf->ranks[m], r1 = vf->ranks[m + 1];
+        const double *g = vf->grid[m];
+        size_t i = 0;
+        double wt = 0.0; /* weight of node i+1 */
+        if (x[m] <= g[0]) { i = 0; wt = 0.0; }
+        else if (x[m] >= g[N - 1]) { i = N - 2; wt = 1.0; }
+        else {
+            size_t lo = 0, hi = N - 1;
+            while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (g[mid] <= x[m]) lo = mid; else hi = mid; }
+            i = lo;
+            wt = (x[m] - g[lo]) / (g[lo + 1] - g[lo]);
+        }
+        const double *G0 = vf->cores[m] + i * r0 * r1, *G1 = vf->cores[m] + (i + 1 < N ? i + 1 : i) * r0 * r1;
+        for (size_t b = 0; b < r1; b++) {
+            double s = 0.0;
+            for (size_t a = 0; a < r0; a++) s += v[a] * ((1.0 - wt) * G0[a + b * r0] + wt * G1[a + b * r0]);
+            w[b] = s;
+        }
+        memcpy(v, w, r1 * sizeof(double));
+    }
+    const double out = v[0];
+    free(v);
+    return out;
+}
+
+/* ------------------------------------------------------------------------------ cross approximation */
+typedef int (*fiber_fn)(size_t, const double *, double *, void *);
+typedef int (*fiber_batch_fn)(size_t, size_t, const double *, double *, void *);
+
+struct cross {
+    size_t d;
+    const size_t *N;
+    double **grid;
+    fiber_fn f;
+    fiber_batch_fn fb;
+    void *args;
+    size_t *r;      /* current ranks, r[d+1] */
+    int **I, **J;   /* I[k]: r[k] tuples over dims 0..k-1; J[k]: r[k+1] tuples over dims k+1..d-1 */
+    size_t nfibers; /* fibers requested so far */
+    int verbose;
+};
+
+/* evaluate the core tensor C[a + r_k*(j + N_k*b)] = f(I_k[a], j, J_k[b]): r_k r_{k+1} fibers along dim k */
+static double *cross_eval_core(struct cross *c, size_t k)
+{
+    const size_t d = c->d, N = c->N[k], r0 = c->r[k], r1 = c->r[k + 1], F = r0 * r1;
+    double *x = xcalloc(F * N * d, sizeof(double)), *out = xcalloc(F * N, sizeof(double));
+    for (size_t b = 0; b < r1; b++)
+        for (size_t a = 0; a < r0; a++) {
+            double *xf = x + (a + r0 * b) * N * d;
+            for (size_t j = 0; j < N; j++) {
+                for (size_t m = 0; m < k; m++) xf[j * d + m] = c->grid[m][c->I[k][a * k + m]];
+                xf[j * d + k] = c->grid[k][j];
+                for (size_t m = k + 1; m < d; m++) xf[j * d + m] = c->grid[m][c->J[k][b * (d - 1 - k) + (m - k - 1)]];
+            }
+        }
+    int res = 0;
+    if (c->fb) res = c->fb(F, N, x, out, c->args);
+    else
+        for (size_t f = 0; f < F && res == 0; f++) res = c->f(N, x + f * N * d, out + f * N, c->args);
+    if (res != 0) DIE("valuef_interp: the fiber callback returned %d", res);
+    c->nfibers += F;
+    double *C = xcalloc(r0 * N * r1, sizeof(double));
+    for (size_t b = 0; b < r1; b++)
+        for (size_t a = 0; a < r0; a++)
+            for (size_t j = 0; j < N; j++) C[a + r0 * (j + N * b)] = out[(a + r0 * b) * N + j];
+    free(x); free(out);
+    return C;
+}
+
+/* left-to-right half sweep: new left index sets, interpolatory cores; returns the TT */
+static struct tt *cross_sweep_lr(struct cross *c)
+{
+    const size_t d = c->d;
+    struct tt *t = tt_alloc(d, c->N, c->r);
+    for (size_t k = 0; k < d; k++) {
+        const size_t N = c->N[k], r0 = c->r[k], r1 = c->r[k + 1], m = r0 * N;
+        double *C = cross_eval_core(c, k);
+        if (k == d - 1) { memcpy(t->G[k], C, m * r1 * sizeof(double)); free(C); break; }
+        assert(m >= r1);
+        qr_thin(m, r1, C, NULL);
+        size_t *rows = xcalloc(r1, sizeof(size_t));
+        maxvol(m, r1, C, rows, t->G[k]);
+        /* I_{k+1}[b] = (I_k[a], j) with row = a + r0*j */
+        int *In = xcalloc(r1 * (k + 1), sizeof(int));
+        for (size_t b = 0; b < r1; b++) {
+            const size_t a = rows[b] % r0, j = rows[b] / r0;
+            for (size_t q = 0; q < k; q++) In[b * (k + 1) + q] = c->I[k][a * k + q];
+            In[b * (k + 1) + k] = (int)j;
+        }
+        free(c->I[k + 1]);
+        c->I[k + 1] = In;
+        free(rows); free(C);
+    }
+    return t;
+}
+
+/* right-to-left half sweep: new right index sets */
+static struct tt *cross_sweep_rl(struct cross *c)
+{
+    const size_t d = c->d;
+    struct tt *t = tt_alloc(d, c->N, c->r);
+    for (size_t k = d; k-- > 0;) {
+        const size_t N = c->N[k], r0 = c->r[k], r1 = c->r[k + 1], cols = N * r1;
+        double *C = cross_eval_core(c, k);
+        if (k == 0) { memcpy(t->G[0], C, r0 * cols * sizeof(double)); free(C); break; }
+        assert(cols >= r0);
+        double *Ct = xcalloc(cols * r0, sizeof(double)); /* (N r1) x r0 */
+        for (size_t cc = 0; cc < cols; cc++)
+            for (size_t a = 0; a < r0; a++) Ct[cc + a * cols] = C[a + r0 * cc];
+        qr_thin(cols, r0, Ct, NULL);
+        size_t *rows = xcalloc(r0, sizeof(size_t));
+        double *B = xcalloc(cols * r0, sizeof(double));
+        maxvol(cols, r0, Ct, rows, B);
+        for (size_t cc = 0; cc < cols; cc++)
+            for (size_t a = 0; a < r0; a++) t->G[k][a + r0 * cc] = B[cc + a * cols];
+        /* J_{k-1}[a] = (j, J_k[b]) with col = j + N*b */
+        const size_t len = d - k; /* tuple length over dims k..d-1 */
+        int *Jn = xcalloc(r0 * len, sizeof(int));
+        for (size_t a = 0; a < r0; a++) {
+            const size_t j = rows[a] % N, b = rows[a] / N;
+            Jn[a * len] = (int)j;
+            for (size_t q = 0; q + 1 < len; q++) Jn[a * len + 1 + q] = c->J[k][b * (len - 1) + q];
+        }
+        free(c->J[k - 1]);
+        c->J[k - 1] = Jn;
+        free(rows); free(B); free(Ct); free(C);
+    }
+    return t;
+}
+
+/* tuple sets of the requested size: keep what is there, extend with uniform-stride "diagonal" tuples
+ * (valuefunc.c:672-690 seeds the sets from grid[m][stride*j]) that are not present yet */
+static int *resize_tuples(const int *old, size_t nold, size_t nnew, size_t len, const size_t *Ndims, size_t salt)
+{
+    int *out = xcalloc(nnew * (len ? len : 1), sizeof(int));
+    size_t have = 0;
+    for (; have < nold && have < nnew; have++) memcpy(out + have * len, old + have * len, len * sizeof(int));
+    size_t trial = 0;
+    while (have < nnew && len > 0) {
+        int *tup = out + have * len;
+        for (size_t q = 0; q < len; q++) {
+            const size_t Nq = Ndims[q];
+            const size_t stride = nnew > 1 ? uniform_stride(Nq, nnew <= Nq ? nnew : Nq) : 0;
+            size_t v = (stride ? stride : 1) * (have + trial) + (trial ? (trial * (q + 1 + salt)) : 0);
+            tup[q] = (int)(v % Nq);
+        }
+        int dup = 0;
+        for (size_t e = 0; e < have && !dup; e++) dup = (memcmp(out + e * len, tup, len * sizeof(int)) == 0);
+        if (dup) { trial++; if (trial > 64 * (nnew + 1)) { have++; trial = 0; } continue; }
+        have++;
+        trial = 0;
+    }
+    return out;
+}
+
+static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, void *args, const size_t *N, double **grid,
+                                  struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
+{
+    if (d < 2) DIE("valuef_interp: need at least two dimensions");
+    if (approx_args_get_function_class(aargs) != LINELM) DIE("valuef_interp: only LINELM (nodal linear elements) is built");
+    size_t minN = N[0];
+    for (size_t k = 0; k < d; k++) if (N[k] < minN) minN = N[k];
+    size_t maxrank = approx_args_get_maxrank(aargs);
+    if (maxrank >= minN) maxrank = minN; /* valuefunc.c:625-631 */
+    const size_t kick = approx_args_get_kickrank(aargs);
+    const int adapt = approx_args_get_adapt(aargs);
+    const double cross_tol = approx_args_get_cross_tol(aargs), round_tol = approx_args_get_round_tol(aargs);
+    const size_t maxiter = 5; /* valuefunc.c:632 */
+
+    struct cross c;
+    memset(&c, 0, sizeof(c));
+    c.d = d; c.N = N; c.grid = grid; c.f = f; c.fb = fb; c.args = args; c.verbose = verbose;
+    c.r = xcalloc(d + 1, sizeof(size_t));
+    c.r[0] = c.r[d] = 1;
+    size_t base = approx_args_get_startrank(aargs);
+    if (base > maxrank) base = maxrank;
+    if (base < 1) base = 1;
+    for (size_t k = 1; k < d; k++) c.r[k] = base;
+    if (vref != NULL && adapt == 1) { /* valuefunc.c:636-649 */
+        const size_t *rr = valuef_get_ranks(vref);
+        for (size_t k = 1; k < d; k++) c.r[k] = (rr[k] + 1) >= maxrank ? maxrank : rr[k] + 1;
+    }
+    c.I = xcalloc(d + 1, sizeof(int *));
+    c.J = xcalloc(d + 1, sizeof(int *));
+    for (size_t k = 0; k < d; k++) {
+        /* I[k]: r[k] tuples of length k; J[k]: r[k+1] tuples of length d-1-k */
+        const int *oldI = NULL, *oldJ = NULL;
+        size_t nI = 0, nJ = 0;
+        if (vref != NULL && adapt == 1 && vref->isl != NULL) { oldI = vref->isl[k]; nI = vref->nisl[k]; oldJ = vref->isr[k]; nJ = vref->nisr[k]; }
+        c.I[k] = resize_tuples(oldI, nI, c.r[k], k, N, 0);
+        c.J[k] = resize_tuples(oldJ, nJ, c.r[k + 1], d - 1 - k, N + k + 1, 1);
+    }
+    if (verbose > 0) { printf("Starting Ranks: "); for (size_t k = 0; k <= d; k++) printf("%zu ", c.r[k]); printf("\n"); }
+
+    struct tt *best = NULL;
+    for (int round = 0; round < 50; round++) {
+        struct tt *prev = NULL, *cur = NULL;
+        double rel = 1.0;
+        for (size_t it = 0; it < maxiter; it++) {
+            struct tt *t1 = cross_sweep_lr(&c);
+            struct tt *t2 = cross_sweep_rl(&c);
+            tt_free(t1);
+            tt_free(cur);
+            cur = t2;
+            if (prev != NULL) {
+                struct tt *df = tt_diff(cur, prev);
+                if (df->d > 1) tt_orthogonalize_rl(df);
+                const double dn = tt_frob_of_core0(df);
+                struct tt *cc = tt_copy(cur);
+                if (cc->d > 1) tt_orthogonalize_rl(cc);
+                const double cn = tt_frob_of_core0(cc);
+                tt_free(df); tt_free(cc);
+                rel = cn > 0.0 ? dn / cn : dn;
+                if (verbose > 1) printf("  cross sweep %zu: relative change %.3e (fibers so far %zu)\n", it + 1, rel, c.nfibers);
+            }
+            tt_free(prev);
+            prev = tt_copy(cur);
+            if (rel < cross_tol) break;
+        }
+        tt_free(prev);
+        /* rounding; if a rank survives untouched and may still grow, kick it and cross again */
+        struct tt *rounded = tt_copy(cur);
+        tt_round(rounded, round_tol);
+        int kicked = 0;
+        if (adapt == 1) {
+            for (size_t k = 1; k < d; k++)
+                if (rounded->r[k] >= c.r[k] && c.r[k] < maxrank) {
+                    const size_t rn = (c.r[k] + kick) >= maxrank ? maxrank : c.r[k] + kick;
+                    int *In = resize_tuples(c.I[k], c.r[k], rn, k, N, 3 + round);
+                    int *Jn = resize_tuples(c.J[k - 1], c.r[k], rn, d - k, N + k, 5 + round);
+                    free(c.I[k]); c.I[k] = In;
+                    free(c.J[k - 1]); c.J[k - 1] = Jn;
+                    c.r[k] = rn;
+                    kicked = 1;
+                }
+        }
+        tt_free(best);
+        best = rounded;
+        tt_free(cur);
+        if (!kicked) break;
+        if (verbose > 0) { printf("Kicked ranks: "); for (size_t k = 0; k <= d; k++) printf("%zu ", c.r[k]); printf("\n"); }
+    }
+    if (verbose > 0) { printf("Final Ranks: "); for (size_t k = 0; k <= d; k++) printf("%zu ", best->r[k]); printf("\n"); }
+    struct ValueF *vf = valuef_from_tt(best, grid);
+    {
+        size_t *nl = xcalloc(d, sizeof(size_t)), *nr = xcalloc(d, sizeof(size_t));
+        for (size_t k = 0; k < d; k++) { nl[k] = c.r[k]; nr[k] = c.r[k + 1]; }
+        valuef_set_cross_indices(vf, nl, c.I, nr, c.J);
+        free(nl); free(nr);
+    }
+    tt_free(best);
+    for (size_t k = 0; k < d; k++) { free(c.I[k]); free(c.J[k]); }
+    free(c.I); free(c.J); free(c.r);
+    return vf;
+}
+
+struct ValueF *valuef_interp(size_t d, int (*f)(size_t, const double *, double *, void *), void *args, const size_t *N,
+                             double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
+{ /* valuefunc.c:603-767 */
+    return interp_impl(d, f, NULL, args, N, grid, vref, aargs, verbose);
+}
+
+struct ValueF *valuef_interp_batch(size_t d, int (*fb)(size_t, size_t, const double *, double *, void *), void *args,
+                                   const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
+{
+    return interp_impl(d, NULL, fb, args, N, grid, vref, aargs, verbose);
+}

@@ -90,4 +90,26 @@ void c3control_end_vi(struct C3Control *, struct VIparam *, size_t *nevals);
 struct PIparam *c3control_begin_pi(struct C3Control *, struct ValueF *policy);
 void c3control_begin_pi_step(struct C3Control *, struct PIparam *, struct ValueF *vf, struct c3Opt *opt);
 void c3control_end_pi_step(struct C3Control *, struct PIparam *, size_t *niter_evals);
+
+/* ---- solver loops over the own cross driver (valuefunc.h: valuef_interp) ---- */
+#include <stdio.h>
+struct ApproxArgs;
+struct Diag; /* bellman.c:2409-2514: per-iteration log */
+void diag_destroy(struct Diag **head);
+void diag_append(struct Diag **diag, size_t iter, int type, double norm, double abs_diff, size_t dim, size_t *ranks,
+                 double frac);
+void diag_print(struct Diag *head, FILE *fp);
+int diag_save(struct Diag *head, char *filename);
+size_t diag_count(const struct Diag *head);     /* new: read-only helpers for callers without the struct layout */
+double diag_last_diff(const struct Diag *head);
+struct ValueF *c3control_init_value(struct C3Control *, int (*f)(size_t, const double *, double *, void *), void *args,
+                                    struct ApproxArgs *aargs, int verbose);                 /* bellman.c:2264-2280 */
+struct ValueF *c3control_step_vi(struct C3Control *, struct ValueF *vf, struct ApproxArgs *, struct c3Opt *, int verbose,
+                                 size_t *nevals);                                           /* bellman.c:2177-2212 */
+struct ValueF *c3control_step_pi(struct C3Control *, struct ValueF *vf, struct PIparam *, struct ApproxArgs *,
+                                 struct c3Opt *, int verbose, size_t *niter_evals);         /* bellman.c:2214-2262 */
+struct ValueF *c3control_vi_solve(struct C3Control *, size_t maxiter, double abs_conv_tol, struct ValueF *vo,
+                                  struct ApproxArgs *, struct c3Opt *, int verbose, struct Diag **diag); /* :2282-2340 */
+struct ValueF *c3control_pi_solve(struct C3Control *, size_t maxiter, double abs_conv_tol, struct ValueF *policy,
+                                  struct ApproxArgs *, struct c3Opt *, int verbose, struct Diag **diag); /* :2343-2407 */
 #endif

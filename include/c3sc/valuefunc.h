@@ -1,7 +1,8 @@
 /* valuefunc.h -- nodal function-train value function (mirrors src/valuefunc.h:47-76 for the hot path).
  * The reference keeps a C3 FunctionTrain inside struct ValueF; C3 is out of scope here, so the value
  * function is held directly as its nodal core tables (exactly what valuef_precompute_cores,
- * valuefunc.c:165-189, produces).  valuef_interp / save / load / norm live in C3. */
+ * valuefunc.c:165-189, produces), its grid and the cross index sets of the interpolation that made it.
+ * valuef_interp and the norms are an own restatement of what the reference delegates to C3 (c3sc_cross.c). */
 #ifndef C3SC_VALUE_H
 #define C3SC_VALUE_H
 #include <stddef.h>
@@ -20,6 +21,21 @@ double valuef_eval_ind(struct ValueF *, const size_t *ind);
 /* valuefunc.c:369-585 -- runs on the GPU bound with valuef_bind_device */
 int valuef_eval_fiber_ind_nn(struct ValueF *, const size_t *fixed_ind, size_t dim_vary, const size_t *neighbors,
                              const size_t *neighbors_vary, double *out);
+/* the nodes the cores are sampled on (copied); valuef_interp attaches them itself */
+void valuef_attach_grid(struct ValueF *, double **grid);
+/* valuefunc.c:603-767: cross approximation of a fiber callback f(N, x[N*d], out[N], args) on the tensor grid.
+ * vref (may be NULL) seeds ranks (+1) and index sets when aargs->adapt == 1. */
+struct ApproxArgs;
+struct ValueF *valuef_interp(size_t d, int (*f)(size_t, const double *, double *, void *), void *args, const size_t *N,
+                             double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose);
+/* new: the same with a batched callback fb(F, N, x[F*N*d], out[F*N], args): all r_k r_{k+1} fibers of a core step
+ * arrive in one call (bellman_vi_batch / bellman_pi_batch run them in one kernel launch) */
+struct ValueF *valuef_interp_batch(size_t d, int (*fb)(size_t, size_t, const double *, double *, void *), void *args,
+                                   const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
+                                   int verbose);
+double valuef_norm(struct ValueF *);                       /* valuefunc.c:315-322: sqrt(int V^2), linear elements */
+double valuef_norm2diff(struct ValueF *, struct ValueF *); /* valuefunc.c:324-335 */
+double valuef_eval(struct ValueF *, const double *x);      /* valuefunc.c:337-343: off-grid multilinear interpolant */
 struct c3sc_hip_ctx;
 void valuef_bind_device(struct ValueF *, struct c3sc_hip_ctx *); /* uploads the cores (lazy, once per ctx) */
 #endif

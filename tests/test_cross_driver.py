@@ -1,0 +1,135 @@
+"""Own TT-cross driver behind valuef_interp (c3sc_amd/host/c3sc_cross.c).  The reference delegates
+this to C3 and pins nothing numerically, so the tests are properties: nodal accuracy on functions of known TT
+rank, rank adaptation + rounding, warm start, and the continuous L2 norms against closed forms."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FIBER_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+def _lib():
+    import facade_lib
+
+    L = facade_lib.lib()
+    L.valuef_interp.restype = C.c_void_p
+    L.valuef_interp_batch.restype = C.c_void_p
+    L.valuef_norm.restype = C.c_double
+    L.valuef_norm2diff.restype = C.c_double
+    L.valuef_eval.restype = C.c_double
+    L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+    L.valuef_eval_ind.restype = C.c_double
+    return L, facade_lib
+
+
+def _interp(L, fl, func, grids, vref=None, batch=False, **kw):
+    d = len(grids)
+    N = np.array([len(g) for g in grids], dtype=np.uintp)
+    gs = [fl.f64(g) for g in grids]
+    gp = fl.ptrs(gs)
+    calls = {"fibers": 0, "calls": 0}
+
+    def one(n, x, out, args):
+        X = np.ctypeslib.as_array(x, shape=(n, d))
+        np.ctypeslib.as_array(out, shape=(n,))[:] = func(X)
+        calls["fibers"] += 1
+        calls["calls"] += 1
+        return 0
+
+    def many(F, n, x, out, args):
+        X = np.ctypeslib.as_array(x, shape=(F * n, d))
+        np.ctypeslib.as_array(out, shape=(F * n,))[:] = func(X)
+        calls["fibers"] += F
+        calls["calls"] += 1
+        return 0
+
+    aa = C.c_void_p(L.approx_args_init())
+    L.approx_args_set_cross_tol(aa, C.c_double(kw.get("cross_tol", 1e-10)))
+    L.approx_args_set_round_tol(aa, C.c_double(kw.get("round_tol", 1e-10)))
+    L.approx_args_set_kickrank(aa, C.c_size_t(kw.get("kickrank", 2)))
+    L.approx_args_set_startrank(aa, C.c_size_t(kw.get("startrank", 2)))
+    L.approx_args_set_maxrank(aa, C.c_size_t(kw.get("maxrank", 12)))
+    L.approx_args_set_adapt(aa, C.c_int(kw.get("adapt", 1)))
+    if batch:
+        cb = BATCH_FN(many)
+        vf = C.c_void_p(L.valuef_interp_batch(C.c_size_t(d), cb, None, fl.sp(N), gp, vref, aa, 0))
+    else:
+        cb = FIBER_FN(one)
+        vf = C.c_void_p(L.valuef_interp(C.c_size_t(d), cb, None, fl.sp(N), gp, vref, aa, 0))
+    L.approx_args_free(aa)
+    ranks = [L.valuef_get_ranks(vf)[i] for i in range(d + 1)]
+    return vf, ranks, calls
+
+
+def _nodal_error(L, fl, vf, func, grids, nsamp=400, seed=1):
+    rng = np.random.default_rng(seed)
+    d = len(grids)
+    worst = 0.0
+    for _ in range(nsamp):
+        ind = np.array([rng.integers(0, len(g)) for g in grids], dtype=np.uintp)
+        x = np.array([[grids[m][ind[m]] for m in range(d)]])
+        worst = max(worst, abs(L.valuef_eval_ind(vf, fl.sp(ind)) - func(x)[0]))
+    return worst
+
+
+def test_cross_exact_low_rank_and_rounding():
+    L, fl = _lib()
+    grids = [np.linspace(-1, 2, 17), np.linspace(-2, 3, 21), np.linspace(-3, 1, 15), np.linspace(0, 1, 19)]
+    quad = lambda X: (X ** 2).sum(axis=1) + 0.5  # TT rank 2
+    vf, ranks, calls = _interp(L, fl, quad, grids, startrank=4, maxrank=10)
+    assert ranks[0] == ranks[-1] == 1 and max(ranks) == 2, ranks  # rounding trims the start rank 4 to the true rank
+    assert _nodal_error(L, fl, vf, quad, grids) < 1e-9
+    # the batched callback sees all fibers of a core step in one call
+    vfb, ranksb, callsb = _interp(L, fl, quad, grids, startrank=4, maxrank=10, batch=True)
+    assert ranksb == ranks and callsb["fibers"] == calls["fibers"] and callsb["calls"] < calls["calls"] / 4
+    L.valuef_destroy(vf)
+    L.valuef_destroy(vfb)
+
+
+def test_cross_rank_adaptation_and_warm_start():
+    L, fl = _lib()
+    grids = [np.linspace(-1, 1, 25), np.linspace(-1, 1, 23), np.linspace(-1, 1, 21)]
+    f = lambda X: 1.0 / (1.0 + (X ** 2).sum(axis=1))
+    vf, ranks, calls = _interp(L, fl, f, grids, startrank=2, kickrank=2, maxrank=14, cross_tol=1e-8, round_tol=1e-7)
+    assert max(ranks) > 2  # kicked above the start rank
+    assert _nodal_error(L, fl, vf, f, grids) < 5e-6
+    # warm start from the previous value function (ranks + 1, index sets copied): a slightly different function
+    g = lambda X: 1.0 / (1.05 + (X ** 2).sum(axis=1))
+    vf2, ranks2, calls2 = _interp(L, fl, g, grids, vref=vf, startrank=2, kickrank=2, maxrank=14, cross_tol=1e-8, round_tol=1e-7)
+    assert _nodal_error(L, fl, vf2, g, grids) < 5e-6
+    assert calls2["fibers"] <= calls["fibers"]  # no rank search from scratch
+    d = L.valuef_norm2diff(vf, vf2)
+    assert 0 < d < 0.2
+    L.valuef_destroy(vf)
+    L.valuef_destroy(vf2)
+
+
+def test_continuous_norms_and_offgrid_eval():
+    L, fl = _lib()
+    # constant 0.2 on [-2,2]^2 (tprob_test.c quad2d): ||V||_L2 = 0.2 * 4
+    g2 = [np.linspace(-2, 2, 30), np.linspace(-2, 2, 26)]
+    vf, ranks, _ = _interp(L, fl, lambda X: np.full(len(X), 0.2), g2)
+    assert max(ranks) == 1
+    assert L.valuef_norm(vf) == pytest.approx(0.8, rel=1e-12)
+    # bilinear function: the multilinear interpolant is exact -> closed-form norm and off-grid values
+    g3 = [np.linspace(0, 1, 9), np.linspace(0, 2, 12), np.linspace(-1, 1, 7)]
+    bil = lambda X: (1 + X[:, 0]) * (2 - X[:, 1]) * (0.5 + X[:, 2])
+    vb, _, _ = _interp(L, fl, bil, g3)
+    exact = np.sqrt((7.0 / 3.0) * (8.0 / 3.0) * (2 * 0.25 + 2.0 / 3.0))
+    assert L.valuef_norm(vb) == pytest.approx(exact, rel=1e-11)
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        x = np.array([rng.uniform(0, 1), rng.uniform(0, 2), rng.uniform(-1, 1)])
+        assert L.valuef_eval(vb, fl.dp(x)) == pytest.approx(bil(x[None, :])[0], rel=1e-12)
+    # norm2diff resolves differences far below sqrt(eps)*norm (no Gram-matrix cancellation)
+    vb2, _, _ = _interp(L, fl, lambda X: bil(X) * (1 + 1e-9), g3)
+    assert L.valuef_norm2diff(vb, vb2) == pytest.approx(1e-9 * exact, rel=1e-4)
+    for v in (vf, vb, vb2):
+        L.valuef_destroy(v)

@@ -1,0 +1,127 @@
+"""Value / policy iteration loops through the reference's API names (c3control_init_value, step_vi, vi_solve,
+pi_solve) over the own cross driver, with every core step of the interpolation running as one batched kernel
+launch.  Pinned against the CPU path: the same driver fed by the oracle's bellman_vi (SURVEY.md 8d metric iii:
+nodal L-inf error after a fixed number of iterations, target <= 1e-6)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from c3sc_amd import workloads as wl  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+FIBER_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+def _setup(w, maxrank=12):
+    import facade_lib
+
+    L = facade_lib.lib()
+    for n in ("c3control_init_value", "c3control_step_vi", "c3control_vi_solve", "c3control_pi_solve", "valuef_interp"):
+        getattr(L, n).restype = C.c_void_p
+    for n in ("valuef_norm", "valuef_norm2diff", "valuef_eval_ind", "diag_last_diff"):
+        getattr(L, n).restype = C.c_double
+    L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+    L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
+    L.diag_count.restype = C.c_size_t
+    ctl = facade_lib.Control(w)
+    aa = C.c_void_p(L.approx_args_init())
+    L.approx_args_set_cross_tol(aa, C.c_double(1e-10))
+    L.approx_args_set_round_tol(aa, C.c_double(1e-9))
+    L.approx_args_set_kickrank(aa, C.c_size_t(3))
+    L.approx_args_set_startrank(aa, C.c_size_t(3))
+    L.approx_args_set_maxrank(aa, C.c_size_t(maxrank))
+    return L, facade_lib, ctl, aa
+
+
+def _cores_of(L, vf, w):
+    ranks = [L.valuef_get_ranks(vf)[i] for i in range(w.dx + 1)]
+    pp = L.valuef_get_cores(vf)
+    cores = [np.ctypeslib.as_array(pp[m], shape=(w.ngrid[m] * ranks[m] * ranks[m + 1],)).copy() for m in range(w.dx)]
+    return ranks, cores
+
+
+def _all_values(L, fl, vf, w):
+    out = np.zeros(w.ngrid)
+    for ind in np.ndindex(*w.ngrid):
+        out[ind] = L.valuef_eval_ind(vf, fl.sp(np.array(ind, dtype=np.uintp)))
+    return out
+
+
+def test_value_iteration_gpu_path_matches_cpu_path(oracle):
+    # maxrank >= min N: the cross approximation can become exact, so the two paths may only differ by rounding
+    # (with a truncated rank they differ by the truncation error, through pivot choices -- not a parity statement)
+    w = wl.c1_lqg2d().scaled(ngrid=(19, 17))
+    L, fl, ctl, aa = _setup(w, maxrank=17)
+    const = FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.2), 0)[1])
+    v_gpu = C.c_void_p(L.c3control_init_value(ctl.h, const, None, aa, 0))
+    assert L.valuef_norm(v_gpu) == pytest.approx(0.8, rel=1e-12)  # constant 0.2 on [-2,2]^2
+    # CPU path: the same cross driver, fibers evaluated by the oracle's bellman_vi (with the reference's memo)
+    xg = ctl.xgrid()
+    gs = [fl.f64(g) for g in xg]
+    gp = fl.ptrs(gs)
+    Ng = np.array(w.ngrid, dtype=np.uintp)
+    v_cpu = C.c_void_p(L.valuef_copy(v_gpu))
+    state = {}
+
+    def cpu_fiber(n, x, out, a):
+        X = np.ctypeslib.as_array(x, shape=(n, w.dx)).copy()
+        np.ctypeslib.as_array(out, shape=(n,))[:] = state["P"].bellman_vi(X, use_memo=True)[0]
+        return 0
+
+    cpu_cb = FIBER_FN(cpu_fiber)
+    ne = C.c_size_t(0)
+    for it in range(4):
+        nxt = C.c_void_p(L.c3control_step_vi(ctl.h, v_gpu, aa, ctl.opt, 0, C.byref(ne)))
+        L.valuef_destroy(v_gpu)
+        v_gpu = nxt
+        ranks, cores = _cores_of(L, v_cpu, w)
+        wr = wl.Workload(w.name, w.model, w.params, w.dx, w.du, w.lb, w.ub, w.ngrid, tuple(ranks), w.discount, w.bc,
+                         list(w.obstacles), w.cands)
+        P = oracle.Problem(wr, [c.reshape(w.ngrid[m], -1) for m, c in enumerate(cores)])
+        P.increment_vi_iter()
+        state["P"] = P
+        nxt = C.c_void_p(L.valuef_interp(C.c_size_t(w.dx), cpu_cb, None, fl.sp(Ng), gp, v_cpu, aa, 0))
+        L.valuef_destroy(v_cpu)
+        v_cpu = nxt
+        assert ne.value > 0
+    a, b = _all_values(L, fl, v_gpu, w), _all_values(L, fl, v_cpu, w)
+    print("gpu-vs-cpu path, max nodal difference after 4 sweeps:", np.abs(a - b).max(), "scale", np.abs(b).max())
+    assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+    assert L.valuef_norm2diff(v_gpu, v_cpu) <= 1e-6 * L.valuef_norm(v_cpu)
+    L.valuef_destroy(v_gpu)
+    L.valuef_destroy(v_cpu)
+    L.approx_args_free(aa)
+    ctl.close()
+
+
+def test_policy_and_value_iteration_loops_contract():
+    """The reference's own regression (tprob_test.c:2275-2364, Test_bellman_pi_100) interleaves pi_solve(10) and one
+    vi_solve step on the 2-D LQG problem until the iterates stop moving.  Here: same loop on a coarser grid and a
+    stronger discount so that it contracts within the test budget; differences must shrink and the Diag log fills."""
+    w0 = wl.c1_lqg2d().scaled(ngrid=(41, 41))
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, 8.0, w0.bc, [], w0.cands)
+    L, fl, ctl, aa = _setup(w)
+    const = FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.2), 0)[1])
+    cost = C.c_void_p(L.c3control_init_value(ctl.h, const, None, aa, 0))
+    diag = C.c_void_p(None)
+    diffs = []
+    for upd in range(6):
+        nxt = C.c_void_p(L.c3control_pi_solve(ctl.h, C.c_size_t(10), C.c_double(1e-7), cost, aa, ctl.opt, 0, C.byref(diag)))
+        L.valuef_destroy(cost)
+        tmp = C.c_void_p(L.c3control_vi_solve(ctl.h, C.c_size_t(1), C.c_double(1e-7), nxt, aa, ctl.opt, 0, C.byref(diag)))
+        diffs.append(L.valuef_norm2diff(nxt, tmp))
+        L.valuef_destroy(nxt)
+        cost = tmp
+    assert diffs[-1] < diffs[0] and diffs[-1] < 0.5 * diffs[1]
+    assert np.isfinite(L.valuef_norm(cost)) and L.valuef_norm(cost) > 0
+    assert 12 <= L.diag_count(diag) <= 66
+    L.diag_destroy(C.byref(diag))
+    L.valuef_destroy(cost)
+    L.approx_args_free(aa)
+    ctl.close()

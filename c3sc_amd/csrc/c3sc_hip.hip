@@ -188,14 +188,24 @@ static int upload_static(c3sc_hip_ctx *c)
     return C3SC_OK;
 }
 
-static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, int variant, int k)
+// AUTO picks by batch size: the fiber-pair kernel needs 64 fibers x 1024 resident workgroups to fill the chip and a
+// single tile takes ~0.12 ms whatever F is, while one-wave-per-fiber scales down to ~20 us (measured on car7d:
+// 0.020 / 0.065 / 0.23 ms at F = 2k / 8k / 32k against 0.12 / 0.12 / 0.15 ms) -- cross-approximation core steps
+// (F = r_k r_{k+1}, a few hundred fibers) are latency-bound and take the per-wave kernel.
+static const size_t SMALL_BATCH_FIBERS = 16384;
+
+static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, int variant, int k, size_t F = (size_t)-1)
 {
     const KernelEntry *best = nullptr;
+    const bool small = (variant == C3SC_VARIANT_AUTO) && F < SMALL_BATCH_FIBERS;
     for (const auto &e : kernel_registry()) {
         if (e.model != model || e.d != d || e.rp < rank_needed || e.max_n < N) continue;
         if (e.k >= 0 && e.k != k) continue;
         if (variant != C3SC_VARIANT_AUTO && e.variant != variant) continue;
-        auto pref = [](int v) { return v == C3SC_VARIANT_FIBER_PAIR ? 0 : (v == C3SC_VARIANT_FIBER_PER_WAVE ? 1 : 2); };
+        auto pref = [small](int v) {
+            if (small) return v == C3SC_VARIANT_FIBER_PER_WAVE ? 0 : (v == C3SC_VARIANT_FIBER_PAIR ? 1 : 2);
+            return v == C3SC_VARIANT_FIBER_PAIR ? 0 : (v == C3SC_VARIANT_FIBER_PER_WAVE ? 1 : 2);
+        };
         if (!best || e.rp < best->rp || (e.rp == best->rp && pref(e.variant) < pref(best->variant)) ||
             (e.rp == best->rp && e.variant == best->variant && e.npl < best->npl))
             best = &e;
@@ -477,7 +487,7 @@ static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx
     if (F == 0) return C3SC_OK;
     if (!d_idx || !d_out) return fail(c, C3SC_ERR_ARG, "bellman_fibers: null buffer");
     A.forced = d_policy;
-    const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant, k);
+    const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant, k, F);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};

@@ -48,10 +48,15 @@ def _check(eng, P, w, k, idx):
     return err / scale
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["auto", "fiber_per_wave"])
+PAIR_CONFIGS = {0, 1, 2, 3, 4, 5, 6}  # SMALL entries that have a fiber-pair instantiation (dubins, scar4d r8, car7d, lqg2d, lqg6d)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3], ids=["auto", "fiber_per_wave", "fiber_pair"])
 @pytest.mark.parametrize("name,kw", SMALL, ids=[f"{n}-r{k['rank']}-{i}" for i, (n, k) in enumerate(SMALL)])
 def test_bellman_fibers_vs_oracle(oracle, name, kw, variant):
     w = wl.WORKLOADS[name]().scaled(**kw)
+    if variant == 3 and SMALL.index((name, kw)) not in PAIR_CONFIGS:
+        pytest.skip("no fiber-pair instantiation for this (model, rank): the per-wave kernel serves it")
     cores = wl.synth_cores(w)
     P = oracle.Problem(w, cores)
     eng = _engine(w, cores, variant)

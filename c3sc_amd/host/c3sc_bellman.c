@@ -603,41 +603,52 @@ static void eval_callback_tables(struct ControlParams *cp, size_t k, const int32
     free(nv); free(ab); free(drift); free(diff);
 }
 
-int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg)
-{ /* bellman.c:1295-1423 for F fibers: index conversion + memo on the host, every missing fiber in ONE launch */
-    struct VIparam *vi = arg;
+/* coordinates of the nodes of F fibers from their grid indices (what the cross approximation would hand over) */
+static double *fibers_x_from_idx(const struct MCAparam *mca, size_t F, size_t k, const int32_t *idx)
+{
+    const size_t dx = mca->dx, N = mca->ngrid[k];
+    double *x = xcalloc(F * N * dx, sizeof(double));
+    for (size_t f = 0; f < F; f++)
+        for (size_t j = 0; j < N; j++)
+            for (size_t m = 0; m < dx; m++)
+                x[(f * N + j) * dx + m] = (m == k) ? mca->xgrid[m][j] : mca->xgrid[m][idx[f * dx + m]];
+    return x;
+}
+
+/* bellman.c:1295-1423 for F fibers along dim k0 given by their grid indices: memo per node, every fiber with a
+ * missing node in ONE launch.  fast = 0: the reference's string-keyed table; fast = 1: its integer-keyed twin. */
+static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, const double *x_in, double *out, int fast)
+{
     struct ControlParams *cp = vi->cp;
-    assert(cp != NULL && vi->vf != NULL);
     struct MCAparam *mca = cp->mca;
-    const size_t dx = mca->dx;
+    const size_t dx = mca->dx, N = mca->ngrid[k0];
     struct c3sc_hip_ctx *ctx = sync_device(vi);
     struct HTable *ht = workspace_get_vi_htable(cp->work);
+    struct FastMemo *fm = workspace_get_vi_fastmemo(cp->work);
     size_t *ser = workspace_get_ind_to_serialize(cp->work);
+    const size_t vi_iter = workspace_get_vi_iter(cp->work);
     char key[256];
-
-    int32_t *idx = xcalloc(F * dx, sizeof(int32_t));
-    size_t *kdim = xcalloc(F, sizeof(size_t));
-    unsigned char *need = xcalloc(F, 1);
-    unsigned char *hit = xcalloc(F * N, 1);
-    size_t fi[C3SC_MAX_DIM];
-    size_t k0 = dx;
+    uint64_t fk[4];
+    unsigned char *need = xcalloc(F, 1), *hit = xcalloc(F * N, 1);
     for (size_t f = 0; f < F; f++) {
-        size_t dv;
-        int res = convert_fiber_to_ind(dx, N, x + f * N * dx, mca->ngrid, mca->xgrid, fi, &dv);
-        if (res != 0) { printf("\n======================================\nError calling convert fiber to _ind!!\n"); }
-        assert(res == 0 && dv < dx && N == mca->ngrid[dv]); /* nodeutil.c:681-683 */
-        if (k0 == dx) k0 = dv;
-        if (dv != k0) DIE("bellman_vi_batch: all fibers of a batch must vary the same dimension");
-        kdim[f] = dv;
-        for (size_t m = 0; m < dx; m++) { idx[f * dx + m] = (m == dv) ? 0 : (int32_t)fi[m]; ser[m] = fi[m]; }
-        ser[dx] = 0;                                   /* bellman.c:1337 */
-        ser[dx + 1] = workspace_get_vi_iter(cp->work); /* bellman.c:1338 */
+        for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
+        ser[dx] = 0;           /* bellman.c:1337 */
+        ser[dx + 1] = vi_iter; /* bellman.c:1338 */
         for (size_t j = 0; j < N; j++) { /* memo lookup, bellman.c:1341-1353 */
-            ser[dv] = j;
-            size_t_a_to_char(ser, dx + 2, key);
-            size_t nb = 0;
-            double *v = htable_get_element(ht, key, &nb);
-            if (v != NULL) { out[f * N + j] = v[0]; hit[f * N + j] = 1; }
+            double v = 0.0;
+            int found;
+            if (fast) {
+                fastmemo_key(dx, idx + f * dx, k0, j, 0, vi_iter, fk);
+                found = fastmemo_get(fm, fk, &v);
+            } else {
+                ser[k0] = j;
+                size_t_a_to_char(ser, dx + 2, key);
+                size_t nb = 0;
+                double *pv = htable_get_element(ht, key, &nb);
+                found = pv != NULL;
+                if (found) v = pv[0];
+            }
+            if (found) { out[f * N + j] = v; hit[f * N + j] = 1; }
             else need[f] = 1;
         }
     }
@@ -651,6 +662,11 @@ int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg
         size_t r = 0;
         for (size_t f = 0; f < F; f++)
             if (need[f]) memcpy(ridx + (r++) * dx, idx + f * dx, dx * sizeof(int32_t));
+        double *x_own = NULL;
+        const int want_x = !dp_has_device_model(cp->dp) ||
+                           (!cp->dp->model_checked && cp->dp->stagecost != NULL && cp->dp->boundcost != NULL && cp->dp->obscost != NULL);
+        const double *x = x_in;
+        if (x == NULL && want_x) { x_own = fibers_x_from_idx(mca, F, k0, idx); x = x_own; }
         if (dp_has_device_model(cp->dp)) {
             hipok(ctx, c3sc_hip_bellman_fibers_host(ctx, (int)k0, nrun, ridx, rout, NULL, rabs), "c3sc_hip_bellman_fibers_host");
         } else {
@@ -673,25 +689,62 @@ int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg
         r = 0;
         for (size_t f = 0; f < F; f++) {
             if (!need[f]) continue;
-            if (r == 0 && dp_has_device_model(cp->dp)) cross_check_model(vi, ctx, k0, ridx, N, x + f * N * dx, rout, rabs);
+            if (r == 0 && dp_has_device_model(cp->dp) && x != NULL) cross_check_model(vi, ctx, k0, ridx, N, x + f * N * dx, rout, rabs);
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
             ser[dx] = 0;
-            ser[dx + 1] = workspace_get_vi_iter(cp->work);
+            ser[dx + 1] = vi_iter;
             for (size_t j = 0; j < N; j++) {
                 if (hit[f * N + j]) continue;
                 out[f * N + j] = rout[r * N + j];
-                ser[k0] = j;
-                size_t_a_to_char(ser, dx + 2, key);
-                htable_add_element(ht, key, &out[f * N + j], 1); /* bellman.c:1383, 1413-1417 */
+                if (fast) {
+                    fastmemo_key(dx, idx + f * dx, k0, j, 0, vi_iter, fk);
+                    fastmemo_put(fm, fk, out[f * N + j]);
+                } else {
+                    ser[k0] = j;
+                    size_t_a_to_char(ser, dx + 2, key);
+                    htable_add_element(ht, key, &out[f * N + j], 1); /* bellman.c:1383, 1413-1417 */
+                }
                 vi->nstate_evals++;
                 vi->nnode_evals++;
             }
             r++;
         }
-        free(ridx); free(rout); free(rabs);
+        free(ridx); free(rout); free(rabs); free(x_own);
     }
-    free(idx); free(kdim); free(need); free(hit);
+    free(need); free(hit);
     return 0;
+}
+
+int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg)
+{ /* the reference's coordinate interface: recover the grid indices (nodeutil.c:437-470), then the common core */
+    struct VIparam *vi = arg;
+    struct ControlParams *cp = vi->cp;
+    assert(cp != NULL && vi->vf != NULL);
+    struct MCAparam *mca = cp->mca;
+    const size_t dx = mca->dx;
+    int32_t *idx = xcalloc(F * dx, sizeof(int32_t));
+    size_t fi[C3SC_MAX_DIM], k0 = dx;
+    for (size_t f = 0; f < F; f++) {
+        size_t dv;
+        int res = convert_fiber_to_ind(dx, N, x + f * N * dx, mca->ngrid, mca->xgrid, fi, &dv);
+        if (res != 0) { printf("\n======================================\nError calling convert fiber to _ind!!\n"); }
+        assert(res == 0 && dv < dx && N == mca->ngrid[dv]); /* nodeutil.c:681-683 */
+        if (k0 == dx) k0 = dv;
+        if (dv != k0) DIE("bellman_vi_batch: all fibers of a batch must vary the same dimension");
+        for (size_t m = 0; m < dx; m++) idx[f * dx + m] = (m == dv) ? 0 : (int32_t)fi[m];
+    }
+    const int rc = (F > 0) ? vi_core(vi, F, k0, idx, x, out, 0) : 0;
+    free(idx);
+    return rc;
+}
+
+/* new: the same for fibers given by grid indices (idx[F][dx], entry k ignored) -- what the own cross driver
+ * calls: no coordinate round trip, integer-keyed memo */
+int bellman_vi_batch_idx(size_t F, size_t k, const int32_t *idx, double *out, void *arg)
+{
+    struct VIparam *vi = arg;
+    assert(vi->cp != NULL && vi->vf != NULL && k < vi->cp->mca->dx);
+    return (F > 0) ? vi_core(vi, F, k, idx, NULL, out, 1) : 0;
 }
 
 int bellman_vi(size_t N, const double *x, double *out, void *arg) { return bellman_vi_batch(1, N, x, out, arg); }
@@ -726,55 +779,64 @@ size_t pi_param_get_niter_node_evals(const struct PIparam *p) { return p->niter_
  * which the device recomputes the rates.  Counters follow the reference: every node of every call counts as an
  * iteration evaluation (its value memo is never filled -- SURVEY.md 9 Q2; the lookup is kept, the mis-keyed 1-element
  * entries it pushes into the prob table are not), npol_evals counts nodes whose policy had to be computed. */
-int bellman_pi_batch(size_t F, size_t N, const double *x, double *out, void *arg)
+static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, const double *x_in, double *out, int fast)
 {
-    struct PIparam *pi = arg;
     struct ControlParams *cp = pi->cp;
-    assert(cp != NULL && pi->vf_policy != NULL && pi->vf_iteration != NULL);
     struct MCAparam *mca = cp->mca;
     struct DPparam *dp = cp->dp;
-    const size_t dx = mca->dx;
+    const size_t dx = mca->dx, N = mca->ngrid[k0];
     struct c3sc_hip_ctx *ctx_it = sync_device_ctx(cp, workspace_get_hip_ctx(cp->work), pi->vf_iteration);
     struct c3sc_hip_ctx *ctx_pol = sync_device_ctx(cp, workspace_get_hip_ctx_policy(cp->work), pi->vf_policy);
     struct HTable *ht_prob = workspace_get_pi_prob_htable(cp->work), *ht_iter = workspace_get_pi_htable(cp->work);
+    struct FastMemo *fm = workspace_get_pi_prob_fastmemo(cp->work);
     size_t *ser = workspace_get_ind_to_serialize(cp->work);
+    const size_t pi_iter = workspace_get_pi_iter(cp->work), pi_sub = workspace_get_pi_subiter(cp->work);
     char key1[256], key2[256];
+    uint64_t fk[4];
+    const int have_model = dp_has_device_model(dp);
+    double *x_own = NULL;
+    const double *x = x_in;
+    if (x == NULL) { x_own = fibers_x_from_idx(mca, F, k0, idx); x = x_own; } /* absorbed flags and callbacks need coordinates */
 
-    int32_t *idx = xcalloc(F * dx, sizeof(int32_t));
     int32_t *policy = xcalloc(F * N, sizeof(int32_t));
     int *absorbed = xcalloc(N, sizeof(int));
     size_t *nv = xcalloc(2 * N, sizeof(size_t));
     unsigned char *need = xcalloc(F, 1), *stored = xcalloc(F * N, 1), *miss = xcalloc(F * N, 1);
-    size_t fi[C3SC_MAX_DIM], nf[2 * C3SC_MAX_DIM], k0 = dx;
+    size_t fi[C3SC_MAX_DIM], nf[2 * C3SC_MAX_DIM];
     for (size_t f = 0; f < F; f++) {
-        size_t dv;
-        const double *xf = x + f * N * dx;
-        int res = convert_fiber_to_ind(dx, N, xf, mca->ngrid, mca->xgrid, fi, &dv);
-        assert(res == 0 && dv < dx && N == mca->ngrid[dv]);
-        (void)res;
-        if (k0 == dx) k0 = dv;
-        if (dv != k0) DIE("bellman_pi_batch: all fibers of a batch must vary the same dimension");
-        process_fibers_neighbor(dx, fi, dv, xf, absorbed, nv, nf, mca->ngrid, dp->bound);
-        for (size_t m = 0; m < dx; m++) { idx[f * dx + m] = (m == dv) ? 0 : (int32_t)fi[m]; ser[m] = fi[m]; }
-        ser[dx] = workspace_get_pi_iter(cp->work);        /* bellman.c:1759 */
-        ser[dx + 1] = workspace_get_pi_subiter(cp->work); /* :1760 */
+        for (size_t m = 0; m < dx; m++) { fi[m] = (size_t)idx[f * dx + m]; ser[m] = fi[m]; }
+        fi[k0] = 0;
+        process_fibers_neighbor(dx, fi, k0, x + f * N * dx, absorbed, nv, nf, mca->ngrid, dp->bound);
+        ser[dx] = pi_iter;    /* bellman.c:1759 */
+        ser[dx + 1] = pi_sub; /* :1760 */
         for (size_t j = 0; j < N; j++) {
-            ser[dv] = j;
-            size_t_a_to_char(ser, dx + 2, key1);
-            size_t_a_to_char(ser, dx + 1, key2);
-            size_t nb = 0;
-            double *v = htable_get_element(ht_iter, key1, &nb); /* :1781 (never filled, Q2) */
             policy[f * N + j] = -1;
-            if (v != NULL) { out[f * N + j] = v[0]; stored[f * N + j] = 1; continue; }
+            if (!fast) {
+                ser[k0] = j;
+                size_t_a_to_char(ser, dx + 2, key1);
+                size_t_a_to_char(ser, dx + 1, key2);
+                size_t nb = 0;
+                double *v = htable_get_element(ht_iter, key1, &nb); /* :1781 (never filled, Q2) */
+                if (v != NULL) { out[f * N + j] = v[0]; stored[f * N + j] = 1; continue; }
+            }
             pi->niter_evals++;
             pi->niter_node_evals++;
             if (absorbed[j] == 1 || absorbed[j] == -1) continue; /* :1787, :1794: boundcost / obscost on the device */
-            double *c = htable_get_element(ht_prob, key2, &nb); /* :1806 */
-            if (c != NULL) policy[f * N + j] = (int32_t)c[0];
+            double c = 0.0;
+            int found;
+            if (fast) {
+                fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, 0, fk);
+                found = fastmemo_get(fm, fk, &c);
+            } else {
+                size_t nb = 0;
+                double *pc = htable_get_element(ht_prob, key2, &nb); /* :1806 */
+                found = pc != NULL;
+                if (found) c = pc[0];
+            }
+            if (found) policy[f * N + j] = (int32_t)c;
             else { miss[f * N + j] = 1; need[f] = 1; pi->npol_evals++; }
         }
     }
-    const int have_model = dp_has_device_model(dp);
     const size_t U = c3opt_get_nbrute(cp->opt), S = 2 * dx + 1;
     double *tables = NULL, *costs2 = NULL;
     if (!have_model) { /* universal path: host callbacks evaluated once, used by both passes */
@@ -813,14 +875,19 @@ int bellman_pi_batch(size_t F, size_t N, const double *x, double *out, void *arg
         for (size_t f = 0; f < F; f++) {
             if (!need[f]) continue;
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
-            ser[dx] = workspace_get_pi_iter(cp->work);
+            ser[dx] = pi_iter;
             for (size_t j = 0; j < N; j++) {
                 if (!miss[f * N + j]) continue;
                 policy[f * N + j] = rui[r * N + j];
-                ser[k0] = j;
-                size_t_a_to_char(ser, dx + 1, key2);
                 double c = (double)rui[r * N + j];
-                htable_add_element(ht_prob, key2, &c, 1); /* :1877 (there: 2dx+3 doubles) */
+                if (fast) {
+                    fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, 0, fk);
+                    fastmemo_put(fm, fk, c);
+                } else {
+                    ser[k0] = j;
+                    size_t_a_to_char(ser, dx + 1, key2);
+                    htable_add_element(ht_prob, key2, &c, 1); /* :1877 (there: 2dx+3 doubles) */
+                }
             }
             r++;
         }
@@ -836,9 +903,39 @@ int bellman_pi_batch(size_t F, size_t N, const double *x, double *out, void *arg
     if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
     for (size_t i = 0; i < F * N; i++)
         if (!stored[i]) out[i] = eout[i];
-    free(eout); free(tables); free(costs2);
-    free(idx); free(policy); free(absorbed); free(nv); free(need); free(stored); free(miss);
+    free(eout); free(tables); free(costs2); free(x_own);
+    free(policy); free(absorbed); free(nv); free(need); free(stored); free(miss);
     return 0;
+}
+
+int bellman_pi_batch(size_t F, size_t N, const double *x, double *out, void *arg)
+{
+    struct PIparam *pi = arg;
+    struct ControlParams *cp = pi->cp;
+    assert(cp != NULL && pi->vf_policy != NULL && pi->vf_iteration != NULL);
+    struct MCAparam *mca = cp->mca;
+    const size_t dx = mca->dx;
+    int32_t *idx = xcalloc(F * dx, sizeof(int32_t));
+    size_t fi[C3SC_MAX_DIM], k0 = dx;
+    for (size_t f = 0; f < F; f++) {
+        size_t dv;
+        int res = convert_fiber_to_ind(dx, N, x + f * N * dx, mca->ngrid, mca->xgrid, fi, &dv);
+        assert(res == 0 && dv < dx && N == mca->ngrid[dv]);
+        (void)res;
+        if (k0 == dx) k0 = dv;
+        if (dv != k0) DIE("bellman_pi_batch: all fibers of a batch must vary the same dimension");
+        for (size_t m = 0; m < dx; m++) idx[f * dx + m] = (m == dv) ? 0 : (int32_t)fi[m];
+    }
+    const int rc = (F > 0) ? pi_core(pi, F, k0, idx, x, out, 0) : 0;
+    free(idx);
+    return rc;
+}
+
+int bellman_pi_batch_idx(size_t F, size_t k, const int32_t *idx, double *out, void *arg)
+{ /* new: fibers by grid indices, integer-keyed policy cache (see bellman_vi_batch_idx) */
+    struct PIparam *pi = arg;
+    assert(pi->cp != NULL && pi->vf_policy != NULL && pi->vf_iteration != NULL && k < pi->cp->mca->dx);
+    return (F > 0) ? pi_core(pi, F, k, idx, NULL, out, 1) : 0;
 }
 
 int bellman_pi(size_t N, const double *x, double *out, void *arg) { return bellman_pi_batch(1, N, x, out, arg); }
@@ -1010,7 +1107,7 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
                                  size_t *nevals)
 { /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
     struct VIparam *vi = c3control_begin_vi(c, vf, opt);
-    struct ValueF *next = valuef_interp_batch(c->dx, bellman_vi_batch, vi, c->ngrid, c->xgrid, vf, apargs, verbose);
+    struct ValueF *next = valuef_interp_idx(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, apargs, verbose);
     c3control_end_vi(c, vi, nevals);
     return next;
 }
@@ -1019,7 +1116,7 @@ struct ValueF *c3control_step_pi(struct C3Control *c, struct ValueF *vf, struct 
                                  struct c3Opt *opt, int verbose, size_t *niter_evals)
 { /* bellman.c:2214-2262 */
     c3control_begin_pi_step(c, poli, vf, opt);
-    struct ValueF *next = valuef_interp_batch(c->dx, bellman_pi_batch, poli, c->ngrid, c->xgrid, vf, apargs, verbose);
+    struct ValueF *next = valuef_interp_idx(c->dx, bellman_pi_batch_idx, poli, c->ngrid, c->xgrid, vf, apargs, verbose);
     c3control_end_pi_step(c, poli, niter_evals);
     return next;
 }

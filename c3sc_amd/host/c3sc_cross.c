@@ -505,6 +505,7 @@ double valuef_eval(struct ValueF *vf, const double *x)
 /* ------------------------------------------------------------------------------ cross approximation */
 typedef int (*fiber_fn)(size_t, const double *, double *, void *);
 typedef int (*fiber_batch_fn)(size_t, size_t, const double *, double *, void *);
+typedef int (*fiber_idx_fn)(size_t, size_t, const int32_t *, double *, void *);
 
 struct cross {
     size_t d;
@@ -512,6 +513,7 @@ struct cross {
     double **grid;
     fiber_fn f;
     fiber_batch_fn fb;
+    fiber_idx_fn fi;
     void *args;
     size_t *r;      /* current ranks, r[d+1] */
     int **I, **J;   /* I[k]: r[k] tuples over dims 0..k-1; J[k]: r[k+1] tuples over dims k+1..d-1 */
@@ -523,6 +525,26 @@ struct cross {
 static double *cross_eval_core(struct cross *c, size_t k)
 {
     const size_t d = c->d, N = c->N[k], r0 = c->r[k], r1 = c->r[k + 1], F = r0 * r1;
+    if (c->fi) { /* index-based callback: no coordinates */
+        int32_t *idx = xcalloc(F * d, sizeof(int32_t));
+        double *out = xcalloc(F * N, sizeof(double));
+        for (size_t b = 0; b < r1; b++)
+            for (size_t a = 0; a < r0; a++) {
+                int32_t *t = idx + (a + r0 * b) * d;
+                for (size_t m = 0; m < k; m++) t[m] = c->I[k][a * k + m];
+                t[k] = 0;
+                for (size_t m = k + 1; m < d; m++) t[m] = c->J[k][b * (d - 1 - k) + (m - k - 1)];
+            }
+        const int res = c->fi(F, k, idx, out, c->args);
+        if (res != 0) DIE("valuef_interp: the fiber callback returned %d", res);
+        c->nfibers += F;
+        double *C = xcalloc(r0 * N * r1, sizeof(double));
+        for (size_t b = 0; b < r1; b++)
+            for (size_t a = 0; a < r0; a++)
+                for (size_t j = 0; j < N; j++) C[a + r0 * (j + N * b)] = out[(a + r0 * b) * N + j];
+        free(idx); free(out);
+        return C;
+    }
     double *x = xcalloc(F * N * d, sizeof(double)), *out = xcalloc(F * N, sizeof(double));
     for (size_t b = 0; b < r1; b++)
         for (size_t a = 0; a < r0; a++) {
@@ -633,7 +655,7 @@ static int *resize_tuples(const int *old, size_t nold, size_t nnew, size_t len, 
     return out;
 }
 
-static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, void *args, const size_t *N, double **grid,
+static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber_idx_fn fi, void *args, const size_t *N, double **grid,
                                   struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 {
     if (d < 2) DIE("valuef_interp: need at least two dimensions");
@@ -649,7 +671,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, void 
 
     struct cross c;
     memset(&c, 0, sizeof(c));
-    c.d = d; c.N = N; c.grid = grid; c.f = f; c.fb = fb; c.args = args; c.verbose = verbose;
+    c.d = d; c.N = N; c.grid = grid; c.f = f; c.fb = fb; c.fi = fi; c.args = args; c.verbose = verbose;
     c.r = xcalloc(d + 1, sizeof(size_t));
     c.r[0] = c.r[d] = 1;
     size_t base = approx_args_get_startrank(aargs);
@@ -737,11 +759,17 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, void 
 struct ValueF *valuef_interp(size_t d, int (*f)(size_t, const double *, double *, void *), void *args, const size_t *N,
                              double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 { /* valuefunc.c:603-767 */
-    return interp_impl(d, f, NULL, args, N, grid, vref, aargs, verbose);
+    return interp_impl(d, f, NULL, NULL, args, N, grid, vref, aargs, verbose);
 }
 
 struct ValueF *valuef_interp_batch(size_t d, int (*fb)(size_t, size_t, const double *, double *, void *), void *args,
                                    const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 {
-    return interp_impl(d, NULL, fb, args, N, grid, vref, aargs, verbose);
+    return interp_impl(d, NULL, fb, NULL, args, N, grid, vref, aargs, verbose);
+}
+
+struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
+                                 const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
+{ /* fibers handed over as grid indices: fi(F, dim_vary, idx[F*d], out[F*N], args) */
+    return interp_impl(d, NULL, NULL, fi, args, N, grid, vref, aargs, verbose);
 }

@@ -3,6 +3,7 @@
  * (src/hashgrid.c), ApproxArgs / Workspace (src/util.c) and a brute-force c3Opt.
  * Own implementation of the reference's interface; citations are relative to the reference tree. */
 #include <assert.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -292,6 +293,81 @@ int c3opt_minimize(struct c3Opt *o, double *x, double *val)
     return 0;
 }
 
+/* ------------------------------------------------------------------------------ FastMemo
+ * The per-iteration node memo of bellman_vi / bellman_pi (bellman.c:1333-1353, 1773-1806) with the grid multi-index
+ * packed into integers instead of printed into a string: same keys (node index + iteration counters), same hits
+ * and misses, ~20x cheaper than snprintf + strcmp.  Used by the index-based batch entry points the solver loops
+ * drive; the string-keyed HTable (bit-identical to hashgrid.c) stays behind the coordinate-based callbacks. */
+struct FastMemo {
+    size_t cap, used; /* cap is a power of two */
+    uint64_t *keys;   /* cap x 4 */
+    double *vals;
+    unsigned char *full;
+};
+
+static uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+static uint64_t key_hash(const uint64_t k[4]) { return mix64(k[0] ^ mix64(k[1] ^ mix64(k[2] ^ mix64(k[3])))); }
+
+struct FastMemo *fastmemo_create(void)
+{
+    struct FastMemo *m = xmalloc(sizeof(*m));
+    m->cap = 1u << 16; m->used = 0;
+    m->keys = xmalloc(m->cap * 4 * sizeof(uint64_t));
+    m->vals = xmalloc(m->cap * sizeof(double));
+    m->full = calloc(m->cap, 1);
+    return m;
+}
+void fastmemo_free(struct FastMemo *m) { if (m) { free(m->keys); free(m->vals); free(m->full); free(m); } }
+void fastmemo_clear(struct FastMemo *m) { memset(m->full, 0, m->cap); m->used = 0; }
+size_t fastmemo_size(const struct FastMemo *m) { return m->used; }
+
+static size_t fm_find(const struct FastMemo *m, const uint64_t k[4])
+{
+    size_t i = (size_t)key_hash(k) & (m->cap - 1);
+    while (m->full[i] && memcmp(m->keys + 4 * i, k, 4 * sizeof(uint64_t)) != 0) i = (i + 1) & (m->cap - 1);
+    return i;
+}
+int fastmemo_get(const struct FastMemo *m, const uint64_t k[4], double *val)
+{
+    const size_t i = fm_find(m, k);
+    if (!m->full[i]) return 0;
+    *val = m->vals[i];
+    return 1;
+}
+void fastmemo_put(struct FastMemo *m, const uint64_t k[4], double val)
+{ /* like htable_add_element, a repeated key is not checked by the callers; here the first value stays */
+    if (2 * (m->used + 1) > m->cap) {
+        struct FastMemo old = *m;
+        m->cap *= 2; m->used = 0;
+        m->keys = xmalloc(m->cap * 4 * sizeof(uint64_t));
+        m->vals = xmalloc(m->cap * sizeof(double));
+        m->full = calloc(m->cap, 1);
+        for (size_t i = 0; i < old.cap; i++)
+            if (old.full[i]) fastmemo_put(m, old.keys + 4 * i, old.vals[i]);
+        free(old.keys); free(old.vals); free(old.full);
+    }
+    const size_t i = fm_find(m, k);
+    if (m->full[i]) return;
+    memcpy(m->keys + 4 * i, k, 4 * sizeof(uint64_t));
+    m->vals[i] = val;
+    m->full[i] = 1;
+    m->used++;
+}
+/* grid multi-index (16 bits per dimension, d <= 12) + two counters */
+void fastmemo_key(size_t d, const int32_t *idx, size_t kdim, size_t j, uint64_t c0, uint64_t c1, uint64_t key[4])
+{
+    key[0] = key[1] = key[2] = 0;
+    for (size_t m = 0; m < d; m++) {
+        const uint64_t v = (uint64_t)(m == kdim ? j : (size_t)idx[m]) & 0xffffu;
+        key[m / 4] |= v << (16 * (m % 4));
+    }
+    key[3] = (c0 << 32) ^ c1;
+}
+
 /* ------------------------------------------------------------------------------ Workspace */
 struct Workspace {
     size_t dx, du, dw, N;
@@ -307,6 +383,7 @@ struct Workspace {
     /* policy iteration (util.c:700-715, 766-779) */
     struct HTable *pi_prob_htable, *pi_htable;
     size_t pi_iter, pi_subiter;
+    struct FastMemo *vi_fast, *pi_prob_fast;
 };
 
 #define NBUCKET 1000000 /* util.c:760 */
@@ -328,6 +405,8 @@ struct Workspace *workspace_alloc(size_t dx, size_t du, size_t dw, size_t N)
     for (size_t i = 0; i < N; i++) { w->keys[i] = xmalloc(256); w->keys2[i] = xmalloc(256); }
     w->pi_prob_htable = htable_create(NBUCKET);
     w->pi_htable = htable_create(NBUCKET);
+    w->vi_fast = fastmemo_create();
+    w->pi_prob_fast = fastmemo_create();
     return w;
 }
 
@@ -337,6 +416,7 @@ void workspace_free(struct Workspace *w)
     for (size_t i = 0; i < w->N; i++) { free(w->keys[i]); free(w->keys2[i]); }
     free(w->keys2);
     htable_destroy(w->pi_prob_htable); htable_destroy(w->pi_htable);
+    fastmemo_free(w->vi_fast); fastmemo_free(w->pi_prob_fast);
     if (w->hip_policy) c3sc_hip_ctx_destroy(w->hip_policy);
     free(w->keys); free(w->slab); free(w->costs); free(w->absorbed); free(w->ind_to_serialize);
     htable_destroy(w->vi_htable);
@@ -344,7 +424,14 @@ void workspace_free(struct Workspace *w)
     free(w);
 }
 
-void workspace_reset_vi_htable(struct Workspace *w) { htable_destroy(w->vi_htable); w->vi_htable = htable_create(NBUCKET); }
+void workspace_reset_vi_htable(struct Workspace *w)
+{
+    htable_destroy(w->vi_htable);
+    w->vi_htable = htable_create(NBUCKET);
+    fastmemo_clear(w->vi_fast);
+}
+struct FastMemo *workspace_get_vi_fastmemo(const struct Workspace *w) { return w->vi_fast; }
+struct FastMemo *workspace_get_pi_prob_fastmemo(const struct Workspace *w) { return w->pi_prob_fast; }
 void workspace_increment_vi_iter(struct Workspace *w) { w->vi_iter++; }
 size_t workspace_get_vi_iter(const struct Workspace *w) { return w->vi_iter; }
 struct HTable *workspace_get_vi_htable(const struct Workspace *w) { return w->vi_htable; }
@@ -369,7 +456,12 @@ int *workspace_get_absorbed(struct Workspace *w, size_t n) { return w->absorbed 
 size_t *workspace_get_ind_to_serialize(struct Workspace *w) { return w->ind_to_serialize; }
 char **workspace_get_saved_keys(struct Workspace *w) { return w->keys; }
 char **workspace_get_saved_keys2(struct Workspace *w) { return w->keys2; }
-void workspace_reset_pi_prob_htable(struct Workspace *w) { htable_destroy(w->pi_prob_htable); w->pi_prob_htable = htable_create(NBUCKET); }
+void workspace_reset_pi_prob_htable(struct Workspace *w)
+{
+    htable_destroy(w->pi_prob_htable);
+    w->pi_prob_htable = htable_create(NBUCKET);
+    fastmemo_clear(w->pi_prob_fast);
+}
 void workspace_reset_pi_htable(struct Workspace *w) { htable_destroy(w->pi_htable); w->pi_htable = htable_create(NBUCKET); }
 struct HTable *workspace_get_pi_prob_htable(const struct Workspace *w) { return w->pi_prob_htable; }
 struct HTable *workspace_get_pi_htable(const struct Workspace *w) { return w->pi_htable; }

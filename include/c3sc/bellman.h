@@ -54,6 +54,9 @@ int bellman_vi(size_t N, const double *x, double *out, void *arg); /* bellman.c:
 /* new: many fibers in one launch (what an own cross driver would call per core step); x is F blocks of
  * N x dx; memo semantics identical to F successive bellman_vi calls */
 int bellman_vi_batch(size_t F, size_t N, const double *x, double *out, void *arg);
+/* new: fibers by grid indices idx[F][dx] along dim k (entry k ignored); integer-keyed twin of the memo */
+#include <stdint.h>
+int bellman_vi_batch_idx(size_t F, size_t k, const int32_t *idx, double *out, void *arg);
 
 /* policy evaluation (bellman.c:1430-1491, 1702-1886): vf_policy fixes the control at every node, the Bellman
  * right-hand side is evaluated on vf_iteration */
@@ -66,6 +69,7 @@ size_t pi_param_get_npol_evals(const struct PIparam *);       /* new: read-only 
 size_t pi_param_get_niter_node_evals(const struct PIparam *);
 int bellman_pi(size_t N, const double *x, double *out, void *arg); /* bellman.c:1702-1886 */
 int bellman_pi_batch(size_t F, size_t N, const double *x, double *out, void *arg); /* new: many fibers per launch */
+int bellman_pi_batch_idx(size_t F, size_t k, const int32_t *idx, double *out, void *arg); /* new: by grid indices */
 
 struct C3Control;
 struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, double *ub, size_t *ngrid,

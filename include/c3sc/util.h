@@ -75,6 +75,18 @@ void workspace_increment_pi_iter(struct Workspace *);
 void workspace_increment_pi_subiter(struct Workspace *);
 size_t workspace_get_pi_iter(const struct Workspace *);
 size_t workspace_get_pi_subiter(const struct Workspace *);
+/* new: integer-keyed twin of the node memo (same keys, no strings) behind the index-based batch entry points */
+#include <stdint.h>
+struct FastMemo;
+struct FastMemo *fastmemo_create(void);
+void fastmemo_free(struct FastMemo *);
+void fastmemo_clear(struct FastMemo *);
+size_t fastmemo_size(const struct FastMemo *);
+int fastmemo_get(const struct FastMemo *, const uint64_t key[4], double *val);
+void fastmemo_put(struct FastMemo *, const uint64_t key[4], double val);
+void fastmemo_key(size_t d, const int32_t *idx, size_t kdim, size_t j, uint64_t c0, uint64_t c1, uint64_t key[4]);
+struct FastMemo *workspace_get_vi_fastmemo(const struct Workspace *);
+struct FastMemo *workspace_get_pi_prob_fastmemo(const struct Workspace *);
 /* new: the MI355X engine this workspace drives (created on first use; aborts if no GPU) */
 struct c3sc_hip_ctx;
 struct c3sc_hip_ctx *workspace_get_hip_ctx(struct Workspace *);

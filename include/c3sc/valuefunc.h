@@ -33,6 +33,12 @@ struct ValueF *valuef_interp(size_t d, int (*f)(size_t, const double *, double *
 struct ValueF *valuef_interp_batch(size_t d, int (*fb)(size_t, size_t, const double *, double *, void *), void *args,
                                    const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
                                    int verbose);
+/* new: the callback receives grid indices instead of coordinates: fi(F, dim_vary, idx[F*d] (entry dim_vary ignored),
+ * out[F*N], args) -- bellman_vi_batch_idx / bellman_pi_batch_idx */
+#include <stdint.h>
+struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
+                                 const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
+                                 int verbose);
 double valuef_norm(struct ValueF *);                       /* valuefunc.c:315-322: sqrt(int V^2), linear elements */
 double valuef_norm2diff(struct ValueF *, struct ValueF *); /* valuefunc.c:324-335 */
 double valuef_eval(struct ValueF *, const double *x);      /* valuefunc.c:337-343: off-grid multilinear interpolant */

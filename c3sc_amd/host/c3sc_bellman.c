@@ -950,6 +950,11 @@ struct C3Control {
     struct DPparam *dp;
     struct Workspace *work;
     struct ControlParams *cp_active;
+    /* implicit policy for simulation (bellman.c:1944-1950, 2034-2042) */
+    struct ValueF *policy_sim;
+    struct c3Opt *opt_sim;
+    void (*transform_sim)(size_t, const double *, double *);
+    double *prevpol;
 };
 
 struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, double *ub, size_t *ngrid, double discount)
@@ -982,10 +987,12 @@ void c3control_destroy(struct C3Control *c)
     if (c == NULL) return;
     boundary_free(c->bound); mca_param_destroy(c->mca); dp_param_destroy(c->dp); workspace_free(c->work);
     for (size_t m = 0; m < c->dx; m++) free(c->xgrid[m]);
+    free(c->prevpol);
     free(c->xgrid); free(c->h); free(c);
 }
 
 size_t *c3control_get_ngrid(struct C3Control *c) { return c ? c->ngrid : NULL; }
+struct Boundary *c3control_get_boundary(struct C3Control *c) { return c ? c->bound : NULL; }
 double **c3control_get_xgrid(struct C3Control *c) { return c ? c->xgrid : NULL; }
 void c3control_set_external_boundary(struct C3Control *c, size_t dim, char *type) { boundary_external_set_type(c->bound, dim, type); }
 void c3control_add_obstacle(struct C3Control *c, double *center, double *widths) { boundary_add_obstacle(c->bound, center, widths); }
@@ -1170,4 +1177,114 @@ struct ValueF *c3control_pi_solve(struct C3Control *c, size_t maxiter, double ab
     }
     pi_param_destroy(poli);
     return start;
+}
+
+/* =============================================================================== policy simulation tail */
+int mca_get_neighbor_node_costs(size_t d, const double *x, struct Boundary *bound, struct ValueF *vf, const size_t *ngrid,
+                                double **xgrid, int *absorbed, double *out)
+{ /* nodeutil.c:718-816: value at the 2d neighbours one grid spacing away from an OFF-GRID state; inside an obstacle
+     every entry is the value at x; out[2d] is left untouched otherwise */
+    if (boundary_in_obstacle(bound, x) == 1) {
+        *absorbed = -1;
+        const double val = valuef_eval(vf, x);
+        for (size_t i = 0; i < 2 * d + 1; i++) out[i] = val;
+        return 0;
+    }
+    *absorbed = 0;
+    double *xt = xcalloc(d, sizeof(double));
+    memcpy(xt, x, d * sizeof(double));
+    for (size_t ii = 0; ii < d; ii++) {
+        const double lb = xgrid[ii][0], ub = xgrid[ii][ngrid[ii] - 1], h = xgrid[ii][1] - xgrid[ii][0];
+        if (((x[ii] + h) < ub) && (x[ii] - h > lb)) {
+            xt[ii] = x[ii] - h; out[2 * ii] = valuef_eval(vf, xt);
+            xt[ii] = x[ii] + h; out[2 * ii + 1] = valuef_eval(vf, xt);
+        } else if ((x[ii] - h) <= lb) { /* left boundary is hit */
+            xt[ii] = x[ii] + h; out[2 * ii + 1] = valuef_eval(vf, xt);
+            const enum EBTYPE b = boundary_type_dim(bound, ii, 0);
+            if (b == ABSORB || b == REFLECT) xt[ii] = lb;
+            else if (b == PERIODIC) xt[ii] = (x[ii] > lb) ? ub - (h - (x[ii] - lb)) : (ub - (lb - x[ii])) - h;
+            else { fprintf(stderr, "No boundary specified!\n"); assert(1 == 0); }
+            out[2 * ii] = valuef_eval(vf, xt);
+        } else { /* right boundary is hit */
+            xt[ii] = x[ii] - h; out[2 * ii] = valuef_eval(vf, xt);
+            const enum EBTYPE b = boundary_type_dim(bound, ii, 1);
+            if (b == ABSORB || b == REFLECT) xt[ii] = ub;
+            else if (b == PERIODIC) xt[ii] = (x[ii] < ub) ? lb + (h - (ub - x[ii])) : (lb + (x[ii] - ub)) + h;
+            else { fprintf(stderr, "No boundary specified!\n"); assert(1 == 0); }
+            out[2 * ii + 1] = valuef_eval(vf, xt);
+        }
+        xt[ii] = x[ii];
+    }
+    free(xt);
+    return 0;
+}
+
+void c3control_add_policy_sim(struct C3Control *c, struct ValueF *pol, struct c3Opt *opt_sim,
+                              void (*transform)(size_t, const double *, double *))
+{ /* bellman.c:2034-2042: borrows both */
+    c->policy_sim = pol;
+    c->opt_sim = opt_sim;
+    c->transform_sim = transform;
+}
+
+int c3control_policy_eval(struct C3Control *c, double t, const double *x, double *u)
+{ /* bellman.c:2105-2158: one state, host callbacks (a single node is not GPU work) */
+    assert(c->policy_sim != NULL && c->opt_sim != NULL);
+    if (c->dp->stagecost == NULL) DIE("c3control_policy_eval: the host callbacks (add_drift/diff/stagecost/...) are needed");
+    int *absorbed = workspace_get_absorbed(c->work, 0);
+    double *costs = workspace_get_costs(c->work, 0);
+    struct ControlParams *cp = control_params_create(c->dx, c->dw, c->dp, c->mca, c->work, c->opt_sim);
+    int res = mca_get_neighbor_node_costs(c->dx, x, c->bound, c->policy_sim, c->ngrid, c->xgrid, absorbed, costs);
+    assert(res == 0);
+    (void)res;
+    if (c->prevpol == NULL) c->prevpol = xcalloc(c->du, sizeof(double));
+    for (size_t i = 0; i < c->du; i++) u[i] = c->prevpol[i];
+    control_params_add_time_and_states(cp, t, 1, x);
+    struct Memory mem = {cp, 0};
+    double val;
+    int res2 = bellman_optimal(c->du, u, &val, &mem);
+    assert(res2 == 0);
+    (void)res2;
+    for (size_t i = 0; i < c->du; i++) c->prevpol[i] = u[i];
+    control_params_destroy(cp);
+    return 0;
+}
+
+int c3control_controller(double t, const double *x, double *u, void *args)
+{ /* bellman.c:2160-2175 */
+    struct C3Control *c = args;
+    if (c->transform_sim == NULL) return c3control_policy_eval(c, t, x, u);
+    double *xin = xcalloc(c->dx, sizeof(double));
+    c->transform_sim(c->dx, x, xin);
+    const int out = c3control_policy_eval(c, t, xin, u);
+    free(xin);
+    return out;
+}
+
+int c3control_simulate(struct C3Control *c, const double *x0, double dt, size_t nsteps, const double *noise, double *traj,
+                       double *utraj)
+{ /* new: the closed-loop tail the examples run through cdyn (e.g. lqg2d.c:346-383) as plain Euler(-Maruyama):
+     x_{n+1} = x_n + b(x_n, u_n) dt + sigma(x_n, u_n) dW_n, u_n = controller(x_n); noise = nsteps x dw standard normals
+     or NULL.  traj: (nsteps+1) x dx, utraj: nsteps x du (may be NULL). */
+    const size_t dx = c->dx, du = c->du, dw = c->dw;
+    double *b = xcalloc(dx, sizeof(double)), *s = xcalloc(dx * dw, sizeof(double)), *u = xcalloc(du, sizeof(double));
+    memcpy(traj, x0, dx * sizeof(double));
+    const double sq = sqrt(dt);
+    for (size_t n = 0; n < nsteps; n++) {
+        const double *x = traj + n * dx;
+        double *xn = traj + (n + 1) * dx;
+        int res = c3control_controller((double)n * dt, x, u, c);
+        if (res == 0) res = drift_eval(c->dp->drift, (double)n * dt, x, u, b, NULL);
+        if (res == 0 && noise) res = diff_eval(c->dp->diff, (double)n * dt, x, u, s, NULL);
+        if (res != 0) { free(b); free(s); free(u); return res; }
+        for (size_t i = 0; i < dx; i++) {
+            double acc = x[i] + b[i] * dt;
+            if (noise)
+                for (size_t j = 0; j < dw; j++) acc += s[i * dw + j] * sq * noise[n * dw + j];
+            xn[i] = acc;
+        }
+        if (utraj) memcpy(utraj + n * du, u, du * sizeof(double));
+    }
+    free(b); free(s); free(u);
+    return 0;
 }

@@ -773,3 +773,139 @@ struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32
 { /* fibers handed over as grid indices: fi(F, dim_vary, idx[F*d], out[F*N], args) */
     return interp_impl(d, NULL, NULL, fi, args, N, grid, vref, aargs, verbose);
 }
+
+/* ------------------------------------------------------------------------------ value-function files
+ * The reference saves the C3 FunctionTrain (valuefunc.c:226-295); that byte format lives in C3, so these files are
+ * this library's own: binary "C3SCVF01" | d | N[d] | ranks[d+1] | has_grid | cores (reference layout) | grids, and a
+ * text twin with 21 significant digits.  Return conventions are the reference's: save 0 on success, load NULL when
+ * the file cannot be opened (the examples probe for a saved cost that way, e.g. lqg2d.c:284-294). */
+int valuef_save(struct ValueF *vf, char *filename)
+{
+    FILE *fp = fopen(filename, "wb");
+    if (fp == NULL) return 1;
+    const char magic[8] = {'C', '3', 'S', 'C', 'V', 'F', '0', '1'};
+    uint64_t d = vf->d, hg = vf->grid != NULL;
+    int ok = fwrite(magic, 1, 8, fp) == 8 && fwrite(&d, 8, 1, fp) == 1;
+    for (size_t m = 0; m < vf->d && ok; m++) { uint64_t v = vf->N[m]; ok = fwrite(&v, 8, 1, fp) == 1; }
+    for (size_t m = 0; m <= vf->d && ok; m++) { uint64_t v = vf->ranks[m]; ok = fwrite(&v, 8, 1, fp) == 1; }
+    ok = ok && fwrite(&hg, 8, 1, fp) == 1;
+    for (size_t m = 0; m < vf->d && ok; m++) {
+        const size_t n = vf->N[m] * vf->ranks[m] * vf->ranks[m + 1];
+        ok = fwrite(vf->cores[m], sizeof(double), n, fp) == n;
+    }
+    for (size_t m = 0; m < vf->d && ok && hg; m++) ok = fwrite(vf->grid[m], sizeof(double), vf->N[m], fp) == vf->N[m];
+    fclose(fp);
+    return ok ? 0 : 1;
+}
+
+static struct ValueF *finish_load(size_t d, size_t *N, size_t *ranks, double **cores, double **grid, size_t *ngrid, double **xgrid)
+{
+    struct ValueF *vf = NULL;
+    int same = 1;
+    for (size_t m = 0; m < d && ngrid != NULL; m++) same = same && (ngrid[m] == N[m]);
+    if (same) {
+        vf = valuef_create_nodal(d, N, ranks, cores);
+        if (xgrid) valuef_attach_grid(vf, xgrid);
+        else if (grid) valuef_attach_grid(vf, grid);
+    } else if (grid != NULL && xgrid != NULL) {
+        /* function_train_create_nodal on another grid (valuefunc.c:252): resample every core by linear interpolation */
+        double **rc = xcalloc(d, sizeof(double *));
+        for (size_t m = 0; m < d; m++) {
+            const size_t r = ranks[m] * ranks[m + 1];
+            rc[m] = xcalloc(ngrid[m] * r, sizeof(double));
+            for (size_t j = 0; j < ngrid[m]; j++) {
+                const double xv = xgrid[m][j];
+                size_t i = 0;
+                double wt = 0.0;
+                if (xv <= grid[m][0]) { i = 0; wt = 0.0; }
+                else if (xv >= grid[m][N[m] - 1]) { i = N[m] - 2; wt = 1.0; }
+                else { while (i + 2 < N[m] && grid[m][i + 1] <= xv) i++; wt = (xv - grid[m][i]) / (grid[m][i + 1] - grid[m][i]); }
+                for (size_t q = 0; q < r; q++) rc[m][j * r + q] = (1.0 - wt) * cores[m][i * r + q] + wt * cores[m][(i + 1) * r + q];
+            }
+        }
+        vf = valuef_create_nodal(d, ngrid, ranks, rc);
+        valuef_attach_grid(vf, xgrid);
+        for (size_t m = 0; m < d; m++) free(rc[m]);
+        free(rc);
+    }
+    return vf;
+}
+
+struct ValueF *valuef_load(char *filename, size_t *ngrid, double **xgrid)
+{
+    FILE *fp = fopen(filename, "rb");
+    if (fp == NULL) return NULL;
+    char magic[8];
+    uint64_t d = 0, hg = 0;
+    struct ValueF *vf = NULL;
+    if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "C3SCVF01", 8) != 0 || fread(&d, 8, 1, fp) != 1 || d == 0 || d > 64) { fclose(fp); return NULL; }
+    size_t *N = xcalloc(d, sizeof(size_t)), *ranks = xcalloc(d + 1, sizeof(size_t));
+    double **cores = xcalloc(d, sizeof(double *)), **grid = xcalloc(d, sizeof(double *));
+    int ok = 1;
+    for (size_t m = 0; m < d && ok; m++) { uint64_t v; ok = fread(&v, 8, 1, fp) == 1; N[m] = (size_t)v; }
+    for (size_t m = 0; m <= d && ok; m++) { uint64_t v; ok = fread(&v, 8, 1, fp) == 1; ranks[m] = (size_t)v; }
+    ok = ok && fread(&hg, 8, 1, fp) == 1;
+    for (size_t m = 0; m < d && ok; m++) {
+        const size_t n = N[m] * ranks[m] * ranks[m + 1];
+        cores[m] = xcalloc(n, sizeof(double));
+        ok = fread(cores[m], sizeof(double), n, fp) == n;
+    }
+    for (size_t m = 0; m < d && ok && hg; m++) { grid[m] = xcalloc(N[m], sizeof(double)); ok = fread(grid[m], sizeof(double), N[m], fp) == N[m]; }
+    fclose(fp);
+    if (ok) vf = finish_load(d, N, ranks, cores, hg ? grid : NULL, ngrid, xgrid);
+    for (size_t m = 0; m < d; m++) { free(cores[m]); free(grid[m]); }
+    free(cores); free(grid); free(N); free(ranks);
+    return vf;
+}
+
+int valuef_savetxt(struct ValueF *vf, char *filename)
+{
+    FILE *fp = fopen(filename, "w+");
+    if (fp == NULL) return 1;
+    fprintf(fp, "C3SCVF01 %zu %d\n", vf->d, vf->grid != NULL);
+    for (size_t m = 0; m < vf->d; m++) fprintf(fp, "%zu ", vf->N[m]);
+    fprintf(fp, "\n");
+    for (size_t m = 0; m <= vf->d; m++) fprintf(fp, "%zu ", vf->ranks[m]);
+    fprintf(fp, "\n");
+    for (size_t m = 0; m < vf->d; m++) {
+        const size_t n = vf->N[m] * vf->ranks[m] * vf->ranks[m + 1];
+        for (size_t i = 0; i < n; i++) fprintf(fp, "%3.21G ", vf->cores[m][i]);
+        fprintf(fp, "\n");
+    }
+    if (vf->grid)
+        for (size_t m = 0; m < vf->d; m++) {
+            for (size_t i = 0; i < vf->N[m]; i++) fprintf(fp, "%3.21G ", vf->grid[m][i]);
+            fprintf(fp, "\n");
+        }
+    fclose(fp);
+    return 0;
+}
+
+struct ValueF *valuef_loadtxt(char *filename, size_t *ngrid, double **xgrid)
+{
+    FILE *fp = fopen(filename, "r");
+    if (fp == NULL) return NULL;
+    char magic[16];
+    size_t d = 0;
+    int hg = 0;
+    if (fscanf(fp, "%15s %zu %d", magic, &d, &hg) != 3 || strcmp(magic, "C3SCVF01") != 0 || d == 0 || d > 64) { fclose(fp); return NULL; }
+    size_t *N = xcalloc(d, sizeof(size_t)), *ranks = xcalloc(d + 1, sizeof(size_t));
+    double **cores = xcalloc(d, sizeof(double *)), **grid = xcalloc(d, sizeof(double *));
+    int ok = 1;
+    for (size_t m = 0; m < d && ok; m++) ok = fscanf(fp, "%zu", &N[m]) == 1;
+    for (size_t m = 0; m <= d && ok; m++) ok = fscanf(fp, "%zu", &ranks[m]) == 1;
+    for (size_t m = 0; m < d && ok; m++) {
+        const size_t n = N[m] * ranks[m] * ranks[m + 1];
+        cores[m] = xcalloc(n, sizeof(double));
+        for (size_t i = 0; i < n && ok; i++) ok = fscanf(fp, "%lf", &cores[m][i]) == 1;
+    }
+    for (size_t m = 0; m < d && ok && hg; m++) {
+        grid[m] = xcalloc(N[m], sizeof(double));
+        for (size_t i = 0; i < N[m] && ok; i++) ok = fscanf(fp, "%lf", &grid[m][i]) == 1;
+    }
+    fclose(fp);
+    struct ValueF *vf = ok ? finish_load(d, N, ranks, cores, hg ? grid : NULL, ngrid, xgrid) : NULL;
+    for (size_t m = 0; m < d; m++) { free(cores[m]); free(grid[m]); }
+    free(cores); free(grid); free(N); free(ranks);
+    return vf;
+}

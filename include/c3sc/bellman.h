@@ -77,6 +77,7 @@ struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, 
 void c3control_destroy(struct C3Control *);
 size_t *c3control_get_ngrid(struct C3Control *);
 double **c3control_get_xgrid(struct C3Control *);
+struct Boundary *c3control_get_boundary(struct C3Control *); /* new: read access for callers of the nodeutil functions */
 void c3control_set_external_boundary(struct C3Control *, size_t dim, char *type);
 void c3control_add_obstacle(struct C3Control *, double *center, double *widths);
 void c3control_add_drift(struct C3Control *, c3sc_dyn_fn, void *);
@@ -94,6 +95,15 @@ void c3control_end_vi(struct C3Control *, struct VIparam *, size_t *nevals);
 struct PIparam *c3control_begin_pi(struct C3Control *, struct ValueF *policy);
 void c3control_begin_pi_step(struct C3Control *, struct PIparam *, struct ValueF *vf, struct c3Opt *opt);
 void c3control_end_pi_step(struct C3Control *, struct PIparam *, size_t *niter_evals);
+
+/* ---- implicit policy for closed-loop simulation (bellman.c:2034-2042, 2105-2175) ---- */
+void c3control_add_policy_sim(struct C3Control *, struct ValueF *pol, struct c3Opt *opt_sim,
+                              void (*transform)(size_t, const double *, double *));
+int c3control_policy_eval(struct C3Control *, double t, const double *x, double *u);
+int c3control_controller(double t, const double *x, double *u, void *args /* struct C3Control * */);
+/* new: Euler(-Maruyama) closed loop in place of the cdyn integrators the examples use; traj (nsteps+1) x dx */
+int c3control_simulate(struct C3Control *, const double *x0, double dt, size_t nsteps, const double *noise, double *traj,
+                       double *utraj);
 
 /* ---- solver loops over the own cross driver (valuefunc.h: valuef_interp) ---- */
 #include <stdio.h>

@@ -17,4 +17,7 @@ int process_fibers_neighbor(size_t d, const size_t *fixed_ind, size_t dim_vary, 
 int mca_get_neighbor_costs(size_t d, size_t N, const double *x, struct Boundary *bound, struct ValueF *vf,
                            const size_t *ngrid, double **xgrid, size_t *fixed_ind, size_t *dim_vary, int *absorbed,
                            double *out);                                                /* nodeutil.c:647-713 */
+/* nodeutil.c:718-816: stencil values around an OFF-GRID state (host; valuef_eval) */
+int mca_get_neighbor_node_costs(size_t d, const double *x, struct Boundary *bound, struct ValueF *vf, const size_t *ngrid,
+                                double **xgrid, int *absorbed, double *out);
 #endif

@@ -42,6 +42,12 @@ struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32
 double valuef_norm(struct ValueF *);                       /* valuefunc.c:315-322: sqrt(int V^2), linear elements */
 double valuef_norm2diff(struct ValueF *, struct ValueF *); /* valuefunc.c:324-335 */
 double valuef_eval(struct ValueF *, const double *x);      /* valuefunc.c:337-343: off-grid multilinear interpolant */
+/* valuefunc.c:226-295 in an own file format (the .c3 bytes live in C3): save returns 0 on success, load returns NULL
+ * if the file cannot be opened; ngrid/xgrid (may be NULL) give the grid to resample onto */
+int valuef_save(struct ValueF *, char *filename);
+struct ValueF *valuef_load(char *filename, size_t *ngrid, double **xgrid);
+int valuef_savetxt(struct ValueF *, char *filename);
+struct ValueF *valuef_loadtxt(char *filename, size_t *ngrid, double **xgrid);
 struct c3sc_hip_ctx;
 void valuef_bind_device(struct ValueF *, struct c3sc_hip_ctx *); /* uploads the cores (lazy, once per ctx) */
 #endif

@@ -392,6 +392,78 @@ double orc_valuef_eval_ind(const struct orc_valuef *vf, const size_t *ind)
     return out;
 }
 
+/* valuef_eval off the grid (valuefunc.c:337-343 -> C3 function_train_eval of LINELM cores): every core is the
+ * piecewise-linear interpolant of its nodal table, constant continuation outside the grid. */
+double orc_valuef_eval(const struct orc_valuef *vf, const double *const *xgrid, const double *x)
+{
+    double *v = malloc(vf->maxrank * sizeof(double)), *w = malloc(vf->maxrank * sizeof(double));
+    v[0] = 1.0;
+    for (size_t m = 0; m < vf->d; m++) {
+        const size_t N = vf->N[m], r0 = vf->ranks[m], r1 = vf->ranks[m + 1];
+        const double *g = xgrid[m];
+        size_t i = 0;
+        double wt = 0.0;
+        if (x[m] <= g[0]) { i = 0; wt = 0.0; }
+        else if (x[m] >= g[N - 1]) { i = N - 2; wt = 1.0; }
+        else {
+            while (i + 2 < N && g[i + 1] <= x[m]) i++;
+            wt = (x[m] - g[i]) / (g[i + 1] - g[i]);
+        }
+        const double *G0 = vf->cores[m] + i * r0 * r1, *G1 = vf->cores[m] + (i + 1) * r0 * r1;
+        for (size_t b = 0; b < r1; b++) {
+            double s = 0.0;
+            for (size_t a = 0; a < r0; a++) s += v[a] * ((1.0 - wt) * G0[a + b * r0] + wt * G1[a + b * r0]);
+            w[b] = s;
+        }
+        double *tmp = v; v = w; w = tmp;
+    }
+    const double out = v[0];
+    free(v); free(w);
+    return out;
+}
+
+/* mca_get_neighbor_node_costs (nodeutil.c:718-816): stencil of an off-grid state for the implicit policy */
+int orc_mca_get_neighbor_node_costs(size_t d, const double *x, const struct orc_boundary *bound, const struct orc_valuef *vf,
+                                    const size_t *ngrid, const double *const *xgrid, int *absorbed, double *out)
+{
+    if (orc_boundary_in_obstacle(bound, x) == 1) { /* :726-733 */
+        *absorbed = -1;
+        const double val = orc_valuef_eval(vf, xgrid, x);
+        for (size_t i = 0; i < 2 * d + 1; i++) out[i] = val;
+        return 0;
+    }
+    *absorbed = 0;
+    double xt[32];
+    for (size_t i = 0; i < d; i++) xt[i] = x[i];
+    for (size_t ii = 0; ii < d; ii++) {
+        const double lb = xgrid[ii][0], ub = xgrid[ii][ngrid[ii] - 1], h = xgrid[ii][1] - xgrid[ii][0];
+        if (((x[ii] + h) < ub) && (x[ii] - h > lb)) { /* :745 */
+            xt[ii] = x[ii] - h; out[2 * ii] = orc_valuef_eval(vf, xgrid, xt);
+            xt[ii] = x[ii] + h; out[2 * ii + 1] = orc_valuef_eval(vf, xgrid, xt);
+        } else if ((x[ii] - h) <= lb) { /* :752 */
+            xt[ii] = x[ii] + h; out[2 * ii + 1] = orc_valuef_eval(vf, xgrid, xt);
+            const enum orc_ebtype b = orc_boundary_type_dim(bound, ii, 0);
+            if (b == ORC_ABSORB || b == ORC_REFLECT) { xt[ii] = lb; out[2 * ii] = orc_valuef_eval(vf, xgrid, xt); }
+            else if (b == ORC_PERIODIC) {
+                if (x[ii] > lb) { xt[ii] = ub - (h - (x[ii] - lb)); }
+                else { xt[ii] = (ub - (lb - x[ii])) - h; }
+                out[2 * ii] = orc_valuef_eval(vf, xgrid, xt);
+            } else return 1;
+        } else { /* :781 */
+            xt[ii] = x[ii] - h; out[2 * ii] = orc_valuef_eval(vf, xgrid, xt);
+            const enum orc_ebtype b = orc_boundary_type_dim(bound, ii, 1);
+            if (b == ORC_ABSORB || b == ORC_REFLECT) { xt[ii] = ub; out[2 * ii + 1] = orc_valuef_eval(vf, xgrid, xt); }
+            else if (b == ORC_PERIODIC) {
+                if (x[ii] < ub) { xt[ii] = lb + (h - (ub - x[ii])); }
+                else { xt[ii] = (lb + (x[ii] - ub)) + h; }
+                out[2 * ii + 1] = orc_valuef_eval(vf, xgrid, xt);
+            } else return 1;
+        }
+        xt[ii] = x[ii];
+    }
+    return 0;
+}
+
 /* valuefunc.c:369-585.  Same prefix (fprod) / suffix (bprod) scheme and the same output
  * layout out[j*(2d+1) + 2m + {0,1}] = (-,+) neighbour in dim m, out[j*(2d+1)+2d] = self. */
 int orc_valuef_eval_fiber_ind_nn(struct orc_valuef *vf, const size_t *fixed_ind, size_t dim_vary,
@@ -1037,6 +1109,19 @@ int orc_policy_fibers(struct orc_problem *p, struct orc_valuef *vf_policy, size_
     }
     free(x);
     return res;
+}
+
+/* c3control_policy_eval (bellman.c:2105-2158): greedy control at an off-grid state; value (out[2d] is not written by
+ * mca_get_neighbor_node_costs outside obstacles: the workspace slot keeps whatever it held -- zero here) */
+int orc_policy_eval(struct orc_problem *p, const double *x, int *uidx, double *val)
+{
+    const size_t dx = p->dx, S = 2 * dx + 1;
+    double costs[65];
+    int absorbed = 0;
+    for (size_t i = 0; i < S; i++) costs[i] = 0.0;
+    int res = orc_mca_get_neighbor_node_costs(dx, x, p->bound, p->vf, p->ngrid, (const double *const *)p->xgrid, &absorbed, costs);
+    if (res) return res;
+    return optimal_value(p, absorbed, x, costs, val, uidx);
 }
 
 /* bellman.c:1295-1423 */

@@ -153,6 +153,11 @@ size_t orc_problem_niter_node_evals(const struct orc_problem *p);
 int orc_bellman_pi(struct orc_problem *p, struct orc_valuef *vf_policy, size_t N, const double *x, double *out, int *uidx);
 int orc_policy_fibers(struct orc_problem *p, struct orc_valuef *vf_policy, size_t k, size_t F, const int *idx, double *out,
                       int *uidx);
+/* ---- policy simulation tail ---- */
+double orc_valuef_eval(const struct orc_valuef *vf, const double *const *xgrid, const double *x); /* valuefunc.c:337-343 */
+int orc_mca_get_neighbor_node_costs(size_t d, const double *x, const struct orc_boundary *bound, const struct orc_valuef *vf,
+                                    const size_t *ngrid, const double *const *xgrid, int *absorbed, double *out); /* nodeutil.c:718-816 */
+int orc_policy_eval(struct orc_problem *p, const double *x, int *uidx, double *val); /* bellman.c:2105-2158 */
 /* Same for the FT stencil only: out F*N*(2dx+1). */
 int orc_stencil_fibers(struct orc_problem *p, size_t k, size_t F, const int *idx, double *out, int *absorbed_out);
 

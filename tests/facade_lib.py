@@ -25,7 +25,7 @@ def lib():
         L = C.CDLL(PATH)
         for n in ("boundary_alloc", "drift_alloc", "diff_alloc", "htable_create", "workspace_alloc", "mca_param_create",
                   "dp_param_create", "control_params_create", "vi_param_create", "c3control_create", "c3opt_alloc",
-                  "valuef_create_nodal", "valuef_copy", "c3control_begin_vi", "approx_args_init", "c3control_begin_pi", "pi_param_create"):
+                  "valuef_create_nodal", "valuef_copy", "c3control_begin_vi", "approx_args_init", "c3control_begin_pi", "pi_param_create", "c3control_get_boundary"):
             getattr(L, n).restype = C.c_void_p
         L.size_t_a_to_char.restype = C.c_char_p
         L.c3sc_hashchar.restype = C.c_size_t
@@ -100,6 +100,9 @@ class Control:
     def xgrid(self):
         pp = self.L.c3control_get_xgrid(self.h)
         return [np.ctypeslib.as_array(pp[m], shape=(self.w.ngrid[m],)).copy() for m in range(self.w.dx)]
+
+    def bound(self):
+        return C.c_void_p(self.L.c3control_get_boundary(self.h))
 
     def valuef(self, cores):
         cs = [f64(c) for c in cores]

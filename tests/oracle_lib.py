@@ -252,6 +252,10 @@ class Problem:
         assert res == 0, f"oracle bellman_fibers failed: {res}"
         return out, uidx, ab
 
+    def boundary_handle(self):
+        self.L.orc_problem_boundary.restype = C.c_void_p
+        return C.c_void_p(self.L.orc_problem_boundary(self.h))
+
     # ---- policy iteration (bellman_pi, bellman.c:1702-1886)
     def pi_begin(self):
         self.L.orc_problem_pi_begin(self.h)

@@ -92,6 +92,9 @@ struct c3sc_hip_ctx {
     double prm[C3SC_MAX_PARAMS] = {0};
     int ncand = 0, du = 0;
     std::vector<double> cands;
+    // continuous controls (c3sc_hip_set_control_box)
+    int box_du = 0, box_grid = 0, box_polish = 0;
+    double box_lb[C3SC_MAX_DU] = {0}, box_ub[C3SC_MAX_DU] = {0};
     // value function
     bool have_value = false;
     size_t ranks[MAXD + 1] = {0};
@@ -334,6 +337,26 @@ int c3sc_hip_set_controls(c3sc_hip_ctx *c, int ncand, int du, const double *cand
     return C3SC_OK;
 }
 
+int c3sc_hip_set_control_box(c3sc_hip_ctx *c, int du, const double *lb, const double *ub, int grid, int polish)
+{
+    if (!c || du < 1 || du > C3SC_MAX_DU || !lb || !ub || grid < 2 || polish < 0) return fail(c, C3SC_ERR_ARG, "set_control_box: bad arguments");
+    double tot = 1.0;
+    for (int i = 0; i < du; i++) {
+        if (!(lb[i] <= ub[i])) return fail(c, C3SC_ERR_ARG, "set_control_box: lb > ub");
+        c->box_lb[i] = lb[i];
+        c->box_ub[i] = ub[i];
+        tot *= grid;
+    }
+    if (tot > 1e6) return fail(c, C3SC_ERR_ARG, "set_control_box: grid^du too large");
+    c->box_du = du; c->box_grid = grid; c->box_polish = polish;
+    if (c->ncand == 0) { // the arena layout wants at least one candidate row; it is not read in box mode
+        c->ncand = 1; c->du = du;
+        c->cands.assign(du, 0.0);
+        c->static_dirty = true;
+    }
+    return C3SC_OK;
+}
+
 int c3sc_hip_set_variant(c3sc_hip_ctx *c, int variant)
 {
     if (!c) return C3SC_ERR_ARG;
@@ -499,6 +522,87 @@ int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_i
                             int32_t *d_absorbed, void *stream)
 {
     return launch_bellman(c, k, F, d_idx, nullptr, d_out, d_uidx, d_absorbed, stream);
+}
+
+static int launch_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_policy_u, double *d_out,
+                      double *d_uopt, int32_t *d_absorbed, void *stream)
+{
+    if (!c) return C3SC_ERR_ARG;
+    if (c->box_du == 0) return fail(c, C3SC_ERR_ARG, "bellman_fibers_box: c3sc_hip_set_control_box first");
+    if (model_ncf(c->model) != 0) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: this model needs transcendental functions of the control");
+    KArgs A;
+    int rc = fill_args(c, k, F, A, true);
+    if (rc != C3SC_OK) return rc;
+    if (F == 0) return C3SC_OK;
+    if (!d_idx || !d_out) return fail(c, C3SC_ERR_ARG, "bellman_fibers_box: null buffer");
+    A.cmode = 1;
+    A.ugrid = c->box_grid;
+    A.upolish = c->box_polish;
+    for (int i = 0; i < c->box_du; i++) { A.ulb[i] = c->box_lb[i]; A.uub[i] = c->box_ub[i]; }
+    A.uopt = d_uopt;
+    A.forced_u = d_policy_u;
+    const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, C3SC_VARIANT_FIBER_PER_WAVE, k);
+    if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: no fiber-per-wave instantiation for (model, dim, rank, N)");
+    c->last_kernel = e->name;
+    LaunchIO io{c->arena, d_idx, d_out, nullptr, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
+    HIPCHK(c, e->fn(A, io));
+    return C3SC_OK;
+}
+
+int c3sc_hip_bellman_fibers_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, double *d_out, double *d_uopt,
+                                int32_t *d_absorbed, void *stream)
+{
+    return launch_box(c, k, F, d_idx, nullptr, d_out, d_uopt, d_absorbed, stream);
+}
+
+int c3sc_hip_policy_fibers_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_policy_u, double *d_out,
+                               int32_t *d_absorbed, void *stream)
+{
+    if (F != 0 && !d_policy_u) return fail(c, C3SC_ERR_ARG, "policy_fibers_box: null policy");
+    return launch_box(c, k, F, d_idx, d_policy_u, d_out, nullptr, d_absorbed, stream);
+}
+
+static int box_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const double *h_policy_u, double *h_out, double *h_uopt,
+                    int32_t *h_absorbed)
+{
+    if (!c || c->d == 0 || k < 0 || k >= c->d || c->box_du == 0) return fail(c, C3SC_ERR_ARG, "bellman_fibers_box_host: bad arguments");
+    if (F == 0) return C3SC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->ngrid[k], du = c->box_du;
+    const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * sizeof(double)),
+                 b_u = align256(F * N * du * sizeof(double)), b_i = align256(F * N * sizeof(int32_t));
+    int rc = ensure_scratch(c, b_idx + b_out + b_u + b_i);
+    if (rc != C3SC_OK) return rc;
+    char *base = (char *)c->scratch;
+    int32_t *d_idx = (int32_t *)base;
+    double *d_out = (double *)(base + b_idx);
+    double *d_u = (double *)(base + b_idx + b_out);
+    int32_t *d_ab = (int32_t *)(base + b_idx + b_out + b_u);
+    HIPCHK(c, hipMemcpy(d_idx, h_idx, F * c->d * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (h_policy_u) {
+        HIPCHK(c, hipMemcpy(d_u, h_policy_u, F * N * du * sizeof(double), hipMemcpyHostToDevice));
+        rc = c3sc_hip_policy_fibers_box(c, k, F, d_idx, d_u, d_out, h_absorbed ? d_ab : nullptr, nullptr);
+    } else {
+        rc = c3sc_hip_bellman_fibers_box(c, k, F, d_idx, d_out, h_uopt ? d_u : nullptr, h_absorbed ? d_ab : nullptr, nullptr);
+    }
+    if (rc != C3SC_OK) return rc;
+    HIPCHK(c, hipMemcpy(h_out, d_out, F * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_uopt && !h_policy_u) HIPCHK(c, hipMemcpy(h_uopt, d_u, F * N * du * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_absorbed) HIPCHK(c, hipMemcpy(h_absorbed, d_ab, F * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return C3SC_OK;
+}
+
+int c3sc_hip_bellman_fibers_box_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, double *h_out, double *h_uopt,
+                                     int32_t *h_absorbed)
+{
+    return box_host(c, k, F, h_idx, nullptr, h_out, h_uopt, h_absorbed);
+}
+
+int c3sc_hip_policy_fibers_box_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, const double *h_policy_u, double *h_out,
+                                    int32_t *h_absorbed)
+{
+    if (F != 0 && !h_policy_u) return fail(c, C3SC_ERR_ARG, "policy_fibers_box_host: null policy");
+    return box_host(c, k, F, h_idx, h_policy_u, h_out, nullptr, h_absorbed);
 }
 
 int c3sc_hip_policy_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const int32_t *d_policy, double *d_out,

@@ -40,6 +40,11 @@ struct KArgs {
     unsigned long long *dbgbuf; // [waves][8] segment cycle sums when (dbg & 128)
     const int32_t *forced;      // policy evaluation (bellman_pi): [F][N] candidate index to apply per node, or null = minimise
     int dbg; // ablation switches for profiling builds (0 in production): see kernel_fiber_pair.hpp
+    // continuous controls in a box (bellman_optimal's non-BRUTEFORCE branch, bellman.c:545-1118): cmode = 1
+    int cmode, ugrid, upolish; // grid points per control dim, polish rounds
+    double ulb[C3SC_MAX_DU], uub[C3SC_MAX_DU];
+    double *uopt;              // [F][N][du] minimiser per node (may be null)
+    const double *forced_u;    // policy evaluation with continuous controls: [F][N][du] control to apply, or null
 };
 
 // Output pointers of one launch (separate __restrict__ kernel parameters).
@@ -526,6 +531,143 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     }
     best = (ab != 0) ? absorbed_cost : best;
         ui = (ab != 0) ? -1 : ui;
+    return best;
+}
+
+// Continuous control in a box [ulb, uub]^DU.  The reference hands bellman_control to C3's BFGS with a multistart
+// schedule (box centre, quarter points, random restarts, bellman.c:545-1118) -- an optimiser that lives in C3 and is
+// unseeded for du >= 2, so nothing about its trajectory is pinned.  Here: a dense tensor grid of
+// `ugrid` points per control dimension (wave-uniform candidates generated arithmetically) followed by `upolish`
+// rounds of per-lane coordinate golden-section search inside the cell around the best grid point.  Fixed trip
+// counts and selects only; the objective is exactly node_backup's (rates, dt, bellmanrhs).  Requires NCF == 0
+// (a transcendental feature of a continuous control would have to be evaluated on the device).
+template <class Model>
+__device__ inline double node_backup_box(const KArgs &A, const double (&x)[Model::D],
+                                         const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1],
+                                         const double (&V)[2 * Model::D + 1], int ab, double (&uo)[Model::DU], unsigned &st,
+                                         bool forced, const double *fu)
+{
+    constexpr int D = Model::D, DU = Model::DU;
+    static_assert(DU <= C3SC_MAX_DU, "control dimension");
+#pragma unroll
+    for (int i = 0; i < DU; i++) uo[i] = 0.0;
+    if (ab == 1) return Model::boundcost(A.prm, x);
+    if (ab == -1) return Model::obscost(A.prm, x);
+    typename Model::Node nd;
+    Model::prep(A.prm, x, tv, nd);
+    constexpr unsigned UM = Model::UDEP_MASK;
+    double cf0[1] = {0.0};
+    double Q0 = 0.0, PV0 = 0.0;
+    {
+        double u0[DU], b[D], s[D];
+#pragma unroll
+        for (int i = 0; i < DU; i++) u0[i] = A.ulb[i];
+        Model::drift(A.prm, nd, x, u0, cf0, b);
+        Model::sigma(A.prm, x, u0, s);
+#pragma unroll
+        for (int m = 0; m < D; m++)
+            if (!((UM >> m) & 1u)) {
+                const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
+                const double tb = A.t[2 * m] * b[m];
+                const double pm = (b[m] < -1e-14) ? half - tb : half;
+                const double pp = (b[m] > 1e-14) ? half + tb : half;
+                Q0 += pm;
+                Q0 += pp;
+                PV0 = fma(pm, V[2 * m], PV0);
+                PV0 = fma(pp, V[2 * m + 1], PV0);
+            }
+    }
+    bool any_stationary = false;
+    auto evalu = [&](const double (&u)[DU]) -> double {
+        double b[D], s[D];
+        Model::drift(A.prm, nd, x, u, cf0, b);
+        Model::sigma(A.prm, x, u, s);
+        const double stage = Model::stage(A.prm, x, u);
+        double Q = Q0, PV = PV0;
+#pragma unroll
+        for (int m = 0; m < D; m++)
+            if ((UM >> m) & 1u) {
+                const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
+                const double tb = A.t[2 * m] * b[m];
+                const double pm = (b[m] < -1e-14) ? half - tb : half;
+                const double pp = (b[m] > 1e-14) ? half + tb : half;
+                Q += pm;
+                Q += pp;
+                PV = fma(pm, V[2 * m], PV);
+                PV = fma(pp, V[2 * m + 1], PV);
+            }
+        const bool ok = !(Q < 1e-14);
+        any_stationary |= !ok;
+        const double Qs = ok ? Q : 1.0;
+        const double inv = 1.0 / Qs;
+        const double dt = A.h2 * inv;
+        const double pself = fma(-Qs, inv, 1.0);
+        const double ctg = fma(pself, V[2 * D], PV * inv);
+        const double ebt = (A.discount == 0.0) ? 1.0 : exp(-A.discount * dt);
+        const double val = dt * stage + ebt * ctg;
+        return ok ? val : 1.0e300;
+    };
+    double ub[DU], best;
+    if (forced) { // policy evaluation: apply the given control
+#pragma unroll
+        for (int i = 0; i < DU; i++) ub[i] = fu[i];
+        best = evalu(ub);
+    } else {
+        double dl[DU];
+        const int G = A.ugrid;
+        int total = 1;
+#pragma unroll
+        for (int i = 0; i < DU; i++) { dl[i] = (G > 1) ? (A.uub[i] - A.ulb[i]) / (double)(G - 1) : 0.0; total *= G; }
+        best = 1.0e301;
+#pragma unroll
+        for (int i = 0; i < DU; i++) ub[i] = A.ulb[i];
+        for (int c = 0; c < total; c++) { // wave-uniform candidates
+            double u[DU];
+            int rem = c;
+#pragma unroll
+            for (int i = 0; i < DU; i++) { const int gi = rem % G; rem /= G; u[i] = (gi == G - 1) ? A.uub[i] : fma((double)gi, dl[i], A.ulb[i]); }
+            const double v = evalu(u);
+            const bool take = v < best;
+            best = take ? v : best;
+#pragma unroll
+            for (int i = 0; i < DU; i++) ub[i] = take ? u[i] : ub[i];
+        }
+        const double gr = 0.6180339887498949;
+        for (int round = 0; round < A.upolish; round++) {
+#pragma unroll
+            for (int i = 0; i < DU; i++) {
+                double lo = fmax(A.ulb[i], ub[i] - dl[i]), hi = fmin(A.uub[i], ub[i] + dl[i]);
+                double u[DU];
+#pragma unroll
+                for (int q = 0; q < DU; q++) u[q] = ub[q];
+                double x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo);
+                u[i] = x1;
+                double f1 = evalu(u);
+                u[i] = x2;
+                double f2 = evalu(u);
+                for (int it = 0; it < 40; it++) {
+                    const bool left = f1 < f2; // keep [lo, x2]
+                    hi = left ? x2 : hi;
+                    lo = left ? lo : x1;
+                    const double xn = left ? hi - gr * (hi - lo) : lo + gr * (hi - lo);
+                    u[i] = xn;
+                    const double fn = evalu(u);
+                    const double ox1 = x1, of1 = f1;
+                    x1 = left ? xn : x2;
+                    f1 = left ? fn : f2;
+                    x2 = left ? ox1 : xn;
+                    f2 = left ? of1 : fn;
+                }
+                const double xm = (f1 < f2) ? x1 : x2, fm = fmin(f1, f2);
+                const bool take = fm < best;
+                best = take ? fm : best;
+                ub[i] = take ? xm : ub[i];
+            }
+        }
+    }
+    if (any_stationary) st |= C3SC_STATUS_STATIONARY;
+#pragma unroll
+    for (int i = 0; i < DU; i++) uo[i] = ub[i];
     return best;
 }
 

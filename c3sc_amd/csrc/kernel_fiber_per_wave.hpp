@@ -307,6 +307,20 @@ __global__ void __launch_bounds__(256)
                 if constexpr (Model::IS_TABLE) {
                     const size_t node = (size_t)f * N + jj;
                     val = node_backup_tables<D>(A, tbl + node * A.ncand * S, tcost + node * 2, V, ab, ui, st, forced, fu);
+                } else if constexpr (Model::NCF == 0) {
+                    double tv[Model::NTAB > 0 ? Model::NTAB : 1];
+                    table_values<Model>(A, ro, ix, tv);
+                    if (A.cmode == 1) { // continuous controls in a box (wave-uniform switch)
+                        double uo[Model::DU];
+                        const bool fcd = A.forced_u != nullptr;
+                        val = node_backup_box<Model>(A, x, tv, V, ab, uo, st, fcd,
+                                                     fcd ? A.forced_u + ((size_t)f * N + jj) * Model::DU : nullptr);
+                        ui = -1;
+                        if (live && A.uopt)
+                            for (int i = 0; i < Model::DU; i++) A.uopt[((size_t)f * N + j) * Model::DU + i] = uo[i];
+                    } else {
+                        val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+                    }
                 } else {
                     double tv[Model::NTAB > 0 ? Model::NTAB : 1];
                     table_values<Model>(A, ro, ix, tv);

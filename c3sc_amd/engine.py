@@ -28,6 +28,8 @@ EXPORTS = [
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
     "c3sc_hip_bellman_fibers", "c3sc_hip_bellman_fibers_tables", "c3sc_hip_bellman_fibers_tables_host", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
     "c3sc_hip_policy_fibers", "c3sc_hip_policy_fibers_host", "c3sc_hip_policy_fibers_tables", "c3sc_hip_policy_fibers_tables_host",
+    "c3sc_hip_set_control_box", "c3sc_hip_bellman_fibers_box", "c3sc_hip_bellman_fibers_box_host", "c3sc_hip_policy_fibers_box",
+    "c3sc_hip_policy_fibers_box_host",
     "c3sc_hip_stencil_fibers_host", "c3sc_hip_stencil_fibers_nb", "c3sc_hip_stencil_fibers_nb_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
     "c3sc_hip_debug_read", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]
@@ -245,6 +247,30 @@ class BellmanEngine:
         ab = np.empty((F, N), dtype=np.int32)
         self._chk(self.L.c3sc_hip_policy_fibers_host(self.h, k, F, idx.ctypes.data, policy.ctypes.data, out.ctypes.data,
                                                      ab.ctypes.data), "policy_fibers_host")
+        return out, ab
+
+    # ---- continuous controls in a box
+    def set_control_box(self, lb, ub, grid=33, polish=2):
+        lb, ub = _f64(lb), _f64(ub)
+        self.box_du = len(lb)
+        self._chk(self.L.c3sc_hip_set_control_box(self.h, len(lb), lb.ctypes.data_as(c_double_p), ub.ctypes.data_as(c_double_p),
+                                                  int(grid), int(polish)), "set_control_box")
+
+    def bellman_fibers_box_host(self, k: int, idx: np.ndarray):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        F, N = idx.shape[0], self.ngrid[k]
+        out, uo, ab = np.empty((F, N)), np.empty((F, N, self.box_du)), np.empty((F, N), dtype=np.int32)
+        self._chk(self.L.c3sc_hip_bellman_fibers_box_host(self.h, k, C.c_size_t(F), C.c_void_p(idx.ctypes.data), C.c_void_p(out.ctypes.data),
+                                                          C.c_void_p(uo.ctypes.data), C.c_void_p(ab.ctypes.data)), "bellman_fibers_box_host")
+        return out, uo, ab
+
+    def policy_fibers_box_host(self, k: int, idx: np.ndarray, policy_u: np.ndarray):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        pu = _f64(policy_u)
+        F, N = idx.shape[0], self.ngrid[k]
+        out, ab = np.empty((F, N)), np.empty((F, N), dtype=np.int32)
+        self._chk(self.L.c3sc_hip_policy_fibers_box_host(self.h, k, C.c_size_t(F), C.c_void_p(idx.ctypes.data), C.c_void_p(pu.ctypes.data),
+                                                         C.c_void_p(out.ctypes.data), C.c_void_p(ab.ctypes.data)), "policy_fibers_box_host")
         return out, ab
 
     def bellman_fibers_tables_host(self, k: int, idx: np.ndarray, tables: np.ndarray, costs2: np.ndarray):

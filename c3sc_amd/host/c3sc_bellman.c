@@ -437,7 +437,7 @@ double bellman_control(size_t du, const double *u, double *grad_u, void *args)
 }
 
 int bellman_optimal(size_t du, double *u, double *val, void *arg)
-{ /* bellman.c:504-543: single node on the host (what c3control_controller needs); BRUTEFORCE only */
+{ /* bellman.c:504-543 (BRUTEFORCE) and the box branch of :545-1118: single node on the host (c3control_controller) */
     struct Memory *mem = arg;
     struct ControlParams *p = mem->shared;
     const int ab = *workspace_get_absorbed(p->work, mem->private);
@@ -448,8 +448,7 @@ int bellman_optimal(size_t du, double *u, double *val, void *arg)
     }
     struct c3Opt *opt = c3opt_copy(p->opt);
     c3opt_add_objective(opt, &bellman_control, mem);
-    if (!c3opt_is_bruteforce(opt)) DIE("bellman_optimal: only BRUTEFORCE minimisation is supported");
-    c3opt_minimize(opt, u, val);
+    c3opt_minimize(opt, u, val); /* BRUTEFORCE: list scan; otherwise the box minimiser (grid + golden section) */
     c3opt_free(opt);
     return 0;
 }
@@ -487,7 +486,10 @@ static struct c3sc_hip_ctx *sync_device_ctx(struct ControlParams *cp, struct c3s
     const size_t d = mca->dx;
     if (dp->model == 0 && (dp->stagecost == NULL || dp->boundcost == NULL || dp->obscost == NULL))
         DIE("bellman_vi/pi: neither a device model (dp_param_set_device_model) nor the host callbacks are set");
-    if (!c3opt_is_bruteforce(cp->opt)) DIE("bellman_vi/pi: only BRUTEFORCE control minimisation runs on the device");
+    const int brute = c3opt_is_bruteforce(cp->opt);
+    const size_t odu = c3opt_get_d(cp->opt);
+    if (!brute && odu > C3SC_MAX_DU) DIE("bellman_vi/pi: the box minimiser handles up to %d control dimensions", C3SC_MAX_DU);
+    if (!brute && dp->model == 0) DIE("bellman_vi/pi: continuous controls need a device model (dp_param_set_device_model); host-callback tables are per candidate");
     /* signature of everything the device holds besides the value function */
     int bc[C3SC_MAX_DIM];
     double lb[C3SC_MAX_OBSTACLES * C3SC_MAX_DIM], ub[C3SC_MAX_OBSTACLES * C3SC_MAX_DIM];
@@ -511,15 +513,26 @@ static struct c3sc_hip_ctx *sync_device_ctx(struct ControlParams *cp, struct c3s
     sig = fnv(sig, &dp->discount, sizeof(double));
     sig = fnv(sig, &dp->model, sizeof(int));
     sig = fnv(sig, dp->prm, sizeof(dp->prm));
-    sig = fnv(sig, c3opt_get_brute_vals(cp->opt), c3opt_get_nbrute(cp->opt) * c3opt_get_d(cp->opt) * sizeof(double));
+    sig = fnv(sig, &brute, sizeof(int));
+    if (brute) sig = fnv(sig, c3opt_get_brute_vals(cp->opt), c3opt_get_nbrute(cp->opt) * odu * sizeof(double));
+    else {
+        const size_t g = c3opt_get_box_grid(cp->opt), pl = c3opt_get_box_polish(cp->opt);
+        sig = fnv(sig, c3opt_get_lb(cp->opt), odu * sizeof(double));
+        sig = fnv(sig, c3opt_get_ub(cp->opt), odu * sizeof(double));
+        sig = fnv(sig, &g, sizeof(g));
+        sig = fnv(sig, &pl, sizeof(pl));
+    }
     const int sl = ctx_slot(ctx);
     if (!g_ctx[sl].cfg_set || g_ctx[sl].cfg_sig != sig) {
         hipok(ctx, c3sc_hip_set_grid(ctx, (int)d, mca->ngrid, (const double *const *)mca->xgrid), "c3sc_hip_set_grid");
         hipok(ctx, c3sc_hip_set_boundary(ctx, bc, (int)nobs, lb, ub), "c3sc_hip_set_boundary");
         hipok(ctx, c3sc_hip_set_mca(ctx, mca->h2, mca->t, dp->discount), "c3sc_hip_set_mca");
         if (dp->model != 0) hipok(ctx, c3sc_hip_set_model(ctx, dp->model, dp->prm, dp->nprm), "c3sc_hip_set_model");
-        hipok(ctx, c3sc_hip_set_controls(ctx, (int)c3opt_get_nbrute(cp->opt), (int)c3opt_get_d(cp->opt), c3opt_get_brute_vals(cp->opt)),
-              "c3sc_hip_set_controls");
+        if (brute)
+            hipok(ctx, c3sc_hip_set_controls(ctx, (int)c3opt_get_nbrute(cp->opt), (int)odu, c3opt_get_brute_vals(cp->opt)), "c3sc_hip_set_controls");
+        else
+            hipok(ctx, c3sc_hip_set_control_box(ctx, (int)odu, c3opt_get_lb(cp->opt), c3opt_get_ub(cp->opt), (int)c3opt_get_box_grid(cp->opt),
+                                                (int)c3opt_get_box_polish(cp->opt)), "c3sc_hip_set_control_box");
         g_ctx[sl].cfg_set = 1;
         g_ctx[sl].cfg_sig = sig;
         g_ctx[sl].version = 0; /* set_grid invalidates the resident value function */
@@ -667,7 +680,9 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
                            (!cp->dp->model_checked && cp->dp->stagecost != NULL && cp->dp->boundcost != NULL && cp->dp->obscost != NULL);
         const double *x = x_in;
         if (x == NULL && want_x) { x_own = fibers_x_from_idx(mca, F, k0, idx); x = x_own; }
-        if (dp_has_device_model(cp->dp)) {
+        if (!c3opt_is_bruteforce(cp->opt)) {
+            hipok(ctx, c3sc_hip_bellman_fibers_box_host(ctx, (int)k0, nrun, ridx, rout, NULL, rabs), "c3sc_hip_bellman_fibers_box_host");
+        } else if (dp_has_device_model(cp->dp)) {
             hipok(ctx, c3sc_hip_bellman_fibers_host(ctx, (int)k0, nrun, ridx, rout, NULL, rabs), "c3sc_hip_bellman_fibers_host");
         } else {
             /* universal path: the user's callbacks are evaluated here, exactly where bellman_control would call
@@ -794,14 +809,16 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
     char key1[256], key2[256];
     uint64_t fk[4];
     const int have_model = dp_has_device_model(dp);
+    const int brute = c3opt_is_bruteforce(cp->opt);
+    const size_t pw = brute ? 1 : c3opt_get_d(cp->opt); /* cached policy per node: candidate index, or the control itself */
     double *x_own = NULL;
     const double *x = x_in;
     if (x == NULL) { x_own = fibers_x_from_idx(mca, F, k0, idx); x = x_own; } /* absorbed flags and callbacks need coordinates */
 
-    int32_t *policy = xcalloc(F * N, sizeof(int32_t));
+    double *polv = xcalloc(F * N * pw, sizeof(double));
     int *absorbed = xcalloc(N, sizeof(int));
     size_t *nv = xcalloc(2 * N, sizeof(size_t));
-    unsigned char *need = xcalloc(F, 1), *stored = xcalloc(F * N, 1), *miss = xcalloc(F * N, 1);
+    unsigned char *need = xcalloc(F, 1), *stored = xcalloc(F * N, 1), *miss = xcalloc(F * N, 1), *has = xcalloc(F * N, 1);
     size_t fi[C3SC_MAX_DIM], nf[2 * C3SC_MAX_DIM];
     for (size_t f = 0; f < F; f++) {
         for (size_t m = 0; m < dx; m++) { fi[m] = (size_t)idx[f * dx + m]; ser[m] = fi[m]; }
@@ -810,7 +827,6 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
         ser[dx] = pi_iter;    /* bellman.c:1759 */
         ser[dx + 1] = pi_sub; /* :1760 */
         for (size_t j = 0; j < N; j++) {
-            policy[f * N + j] = -1;
             if (!fast) {
                 ser[k0] = j;
                 size_t_a_to_char(ser, dx + 2, key1);
@@ -822,18 +838,19 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
             pi->niter_evals++;
             pi->niter_node_evals++;
             if (absorbed[j] == 1 || absorbed[j] == -1) continue; /* :1787, :1794: boundcost / obscost on the device */
-            double c = 0.0;
-            int found;
+            int found = 1;
             if (fast) {
-                fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, 0, fk);
-                found = fastmemo_get(fm, fk, &c);
+                for (size_t q = 0; q < pw && found; q++) {
+                    fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, q, fk);
+                    found = fastmemo_get(fm, fk, &polv[(f * N + j) * pw + q]);
+                }
             } else {
                 size_t nb = 0;
                 double *pc = htable_get_element(ht_prob, key2, &nb); /* :1806 */
                 found = pc != NULL;
-                if (found) c = pc[0];
+                if (found) memcpy(&polv[(f * N + j) * pw], pc, pw * sizeof(double));
             }
-            if (found) policy[f * N + j] = (int32_t)c;
+            if (found) has[f * N + j] = 1;
             else { miss[f * N + j] = 1; need[f] = 1; pi->npol_evals++; }
         }
     }
@@ -849,11 +866,13 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
     for (size_t f = 0; f < F; f++) nrun += need[f];
     if (nrun > 0) {
         int32_t *ridx = xcalloc(nrun * dx, sizeof(int32_t)), *rui = xcalloc(nrun * N, sizeof(int32_t));
-        double *rout = xcalloc(nrun * N, sizeof(double));
+        double *rout = xcalloc(nrun * N, sizeof(double)), *ruo = xcalloc(nrun * N * pw, sizeof(double));
         size_t r = 0;
         for (size_t f = 0; f < F; f++)
             if (need[f]) memcpy(ridx + (r++) * dx, idx + f * dx, dx * sizeof(int32_t));
-        if (have_model) {
+        if (!brute) {
+            hipok(ctx_pol, c3sc_hip_bellman_fibers_box_host(ctx_pol, (int)k0, nrun, ridx, rout, ruo, NULL), "c3sc_hip_bellman_fibers_box_host");
+        } else if (have_model) {
             hipok(ctx_pol, c3sc_hip_bellman_fibers_host(ctx_pol, (int)k0, nrun, ridx, rout, rui, NULL), "c3sc_hip_bellman_fibers_host");
         } else {
             double *rt = xcalloc(nrun * N * U * S, sizeof(double)), *rc2 = xcalloc(nrun * N * 2, sizeof(double));
@@ -878,24 +897,34 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
             ser[dx] = pi_iter;
             for (size_t j = 0; j < N; j++) {
                 if (!miss[f * N + j]) continue;
-                policy[f * N + j] = rui[r * N + j];
-                double c = (double)rui[r * N + j];
+                double *pv = &polv[(f * N + j) * pw];
+                has[f * N + j] = 1;
+                if (brute) pv[0] = (double)rui[r * N + j];
+                else memcpy(pv, &ruo[(r * N + j) * pw], pw * sizeof(double));
                 if (fast) {
-                    fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, 0, fk);
-                    fastmemo_put(fm, fk, c);
+                    for (size_t q = 0; q < pw; q++) {
+                        fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, q, fk);
+                        fastmemo_put(fm, fk, pv[q]);
+                    }
                 } else {
                     ser[k0] = j;
                     size_t_a_to_char(ser, dx + 1, key2);
-                    htable_add_element(ht_prob, key2, &c, 1); /* :1877 (there: 2dx+3 doubles) */
+                    htable_add_element(ht_prob, key2, pv, pw); /* :1877 (there: 2dx+3 doubles) */
                 }
             }
             r++;
         }
-        free(ridx); free(rui); free(rout);
+        free(ridx); free(rui); free(rout); free(ruo);
     }
     /* evaluation pass on vf_iteration with the policy applied (:1807-1815, :1857-1865) */
     double *eout = xcalloc(F * N, sizeof(double));
-    if (have_model) hipok(ctx_it, c3sc_hip_policy_fibers_host(ctx_it, (int)k0, F, idx, policy, eout, NULL), "c3sc_hip_policy_fibers_host");
+    int32_t *policy = xcalloc(F * N, sizeof(int32_t));
+    for (size_t i = 0; i < F * N; i++) { /* nodes without a policy (absorbed / obstacle): index -1, control 0 */
+        if (brute) policy[i] = has[i] ? (int32_t)polv[i] : -1;
+        else if (!has[i]) memset(&polv[i * pw], 0, pw * sizeof(double));
+    }
+    if (!brute) hipok(ctx_it, c3sc_hip_policy_fibers_box_host(ctx_it, (int)k0, F, idx, polv, eout, NULL), "c3sc_hip_policy_fibers_box_host");
+    else if (have_model) hipok(ctx_it, c3sc_hip_policy_fibers_host(ctx_it, (int)k0, F, idx, policy, eout, NULL), "c3sc_hip_policy_fibers_host");
     else hipok(ctx_it, c3sc_hip_policy_fibers_tables_host(ctx_it, (int)k0, F, idx, tables, costs2, policy, eout, NULL),
                "c3sc_hip_policy_fibers_tables_host");
     unsigned st = 0;
@@ -904,7 +933,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
     for (size_t i = 0; i < F * N; i++)
         if (!stored[i]) out[i] = eout[i];
     free(eout); free(tables); free(costs2); free(x_own);
-    free(policy); free(absorbed); free(nv); free(need); free(stored); free(miss);
+    free(policy); free(polv); free(absorbed); free(nv); free(need); free(stored); free(miss); free(has);
     return 0;
 }
 

@@ -3,6 +3,7 @@
  * (src/hashgrid.c), ApproxArgs / Workspace (src/util.c) and a brute-force c3Opt.
  * Own implementation of the reference's interface; citations are relative to the reference tree. */
 #include <assert.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -233,24 +234,31 @@ size_t uniform_stride(size_t N, size_t M)
     return s - 1;
 }
 
-/* ------------------------------------------------------------------------------ brute-force c3Opt */
+/* ------------------------------------------------------------------------------ c3Opt
+ * BRUTEFORCE: the candidate list is scanned in order, first strict minimum wins (assumed upstream behaviour).
+ * Any other algorithm (the examples ask for BFGS with box bounds): C3's gradient optimiser is not available, the
+ * minimiser is a tensor grid over the box + coordinate golden-section polish -- the same algorithm the device runs
+ * (kernel_common.hpp: node_backup_box); tolerances and iteration limits are accepted and ignored. */
 struct c3Opt {
     enum c3opt_alg alg;
     size_t d, n;
     double *vals;
+    double *lb, *ub;
+    size_t grid, polish;
     double (*f)(size_t, const double *, double *, void *);
     void *farg;
 };
 
 struct c3Opt *c3opt_alloc(enum c3opt_alg alg, size_t d)
 {
-    if (alg != BRUTEFORCE) {
-        fprintf(stderr, "c3sc (MI355X build): only BRUTEFORCE control minimisation is supported; "
-                        "gradient-based c3opt algorithms live in C3 and are out of scope\n");
-        exit(1);
-    }
     struct c3Opt *o = xmalloc(sizeof(*o));
+    memset(o, 0, sizeof(*o));
     o->alg = alg; o->d = d;
+    o->lb = xmalloc(d * sizeof(double));
+    o->ub = xmalloc(d * sizeof(double));
+    for (size_t i = 0; i < d; i++) { o->lb[i] = -1.0; o->ub[i] = 1.0; }
+    o->grid = d == 1 ? 33 : (d == 2 ? 17 : 9);
+    o->polish = 2;
     return o;
 }
 
@@ -258,12 +266,16 @@ struct c3Opt *c3opt_copy(struct c3Opt *o)
 {
     struct c3Opt *c = xmalloc(sizeof(*c));
     *c = *o;
-    c->vals = xmalloc(o->n * o->d * sizeof(double));
-    memcpy(c->vals, o->vals, o->n * o->d * sizeof(double));
+    c->vals = xmalloc((o->n * o->d + 1) * sizeof(double));
+    if (o->n) memcpy(c->vals, o->vals, o->n * o->d * sizeof(double));
+    c->lb = xmalloc(o->d * sizeof(double));
+    c->ub = xmalloc(o->d * sizeof(double));
+    memcpy(c->lb, o->lb, o->d * sizeof(double));
+    memcpy(c->ub, o->ub, o->d * sizeof(double));
     return c;
 }
 
-void c3opt_free(struct c3Opt *o) { if (o) { free(o->vals); free(o); } }
+void c3opt_free(struct c3Opt *o) { if (o) { free(o->vals); free(o->lb); free(o->ub); free(o); } }
 
 void c3opt_set_brute_force_vals(struct c3Opt *o, size_t n, double *vals)
 {
@@ -273,15 +285,78 @@ void c3opt_set_brute_force_vals(struct c3Opt *o, size_t n, double *vals)
     memcpy(o->vals, vals, n * o->d * sizeof(double));
 }
 
+void c3opt_add_lb(struct c3Opt *o, double *lb) { memcpy(o->lb, lb, o->d * sizeof(double)); }
+void c3opt_add_ub(struct c3Opt *o, double *ub) { memcpy(o->ub, ub, o->d * sizeof(double)); }
+double *c3opt_get_lb(struct c3Opt *o) { return o->lb; }
+double *c3opt_get_ub(struct c3Opt *o) { return o->ub; }
+/* knobs of C3's line-search optimisers: accepted so that the examples' set-up code links and runs */
+void c3opt_set_relftol(struct c3Opt *o, double v) { (void)o; (void)v; }
+void c3opt_set_absxtol(struct c3Opt *o, double v) { (void)o; (void)v; }
+void c3opt_set_gtol(struct c3Opt *o, double v) { (void)o; (void)v; }
+void c3opt_set_maxiter(struct c3Opt *o, size_t v) { (void)o; (void)v; }
+void c3opt_ls_set_maxiter(struct c3Opt *o, size_t v) { (void)o; (void)v; }
+void c3opt_ls_set_alpha(struct c3Opt *o, double v) { (void)o; (void)v; }
+void c3opt_ls_set_beta(struct c3Opt *o, double v) { (void)o; (void)v; }
+void c3opt_set_verbose(struct c3Opt *o, int v) { (void)o; (void)v; }
+void c3opt_set_storage_options(struct c3Opt *o, int a, int b, int c) { (void)o; (void)a; (void)b; (void)c; }
+/* new: resolution of the box minimiser (grid points per control dimension, polish rounds) */
+void c3opt_set_box_search(struct c3Opt *o, size_t grid, size_t polish) { o->grid = grid < 2 ? 2 : grid; o->polish = polish; }
+size_t c3opt_get_box_grid(const struct c3Opt *o) { return o->grid; }
+size_t c3opt_get_box_polish(const struct c3Opt *o) { return o->polish; }
+
 int c3opt_is_bruteforce(const struct c3Opt *o) { return o->alg == BRUTEFORCE; }
 void c3opt_add_objective(struct c3Opt *o, double (*f)(size_t, const double *, double *, void *), void *arg) { o->f = f; o->farg = arg; }
 size_t c3opt_get_nbrute(const struct c3Opt *o) { return o->n; }
 const double *c3opt_get_brute_vals(const struct c3Opt *o) { return o->vals; }
 size_t c3opt_get_d(const struct c3Opt *o) { return o->d; }
 
+static int box_minimize(struct c3Opt *o, double *x, double *val)
+{ /* node_backup_box on the host: tensor grid, then coordinate golden section in the best cell */
+    const size_t d = o->d, G = o->grid;
+    double dl[8], u[8], ub[8];
+    size_t total = 1;
+    assert(d <= 8);
+    for (size_t i = 0; i < d; i++) { dl[i] = (o->ub[i] - o->lb[i]) / (double)(G - 1); total *= G; ub[i] = o->lb[i]; }
+    double best = 1.0e301;
+    for (size_t c = 0; c < total; c++) {
+        size_t rem = c;
+        for (size_t i = 0; i < d; i++) { const size_t gi = rem % G; rem /= G; u[i] = (gi == G - 1) ? o->ub[i] : fma((double)gi, dl[i], o->lb[i]); }
+        const double v = o->f(d, u, NULL, o->farg);
+        if (v < best) { best = v; memcpy(ub, u, d * sizeof(double)); }
+    }
+    const double gr = 0.6180339887498949;
+    for (size_t round = 0; round < o->polish; round++)
+        for (size_t i = 0; i < d; i++) {
+            double lo = fmax(o->lb[i], ub[i] - dl[i]), hi = fmin(o->ub[i], ub[i] + dl[i]);
+            memcpy(u, ub, d * sizeof(double));
+            double x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo);
+            u[i] = x1; double f1 = o->f(d, u, NULL, o->farg);
+            u[i] = x2; double f2 = o->f(d, u, NULL, o->farg);
+            for (int it = 0; it < 40; it++) {
+                const int left = f1 < f2;
+                hi = left ? x2 : hi;
+                lo = left ? lo : x1;
+                const double xn = left ? hi - gr * (hi - lo) : lo + gr * (hi - lo);
+                u[i] = xn;
+                const double fn = o->f(d, u, NULL, o->farg);
+                const double ox1 = x1, of1 = f1;
+                x1 = left ? xn : x2; f1 = left ? fn : f2;
+                x2 = left ? ox1 : xn; f2 = left ? of1 : fn;
+            }
+            const double xm = (f1 < f2) ? x1 : x2, fm = fmin(f1, f2);
+            if (fm < best) { best = fm; ub[i] = xm; }
+        }
+    memcpy(x, ub, d * sizeof(double));
+    *val = best;
+    return 0;
+}
+
 int c3opt_minimize(struct c3Opt *o, double *x, double *val)
-{ /* candidates in list order, first strict minimum wins */
-    assert(o->f != NULL && o->n > 0);
+{
+    assert(o->f != NULL);
+    if (o->alg != BRUTEFORCE) return box_minimize(o, x, val);
+    /* candidates in list order, first strict minimum wins */
+    assert(o->n > 0);
     size_t best = 0;
     double bv = 0.0;
     for (size_t c = 0; c < o->n; c++) {

@@ -31,7 +31,7 @@ size_t uniform_stride(size_t N, size_t M); /* util.c:995-1006 */
 /* ---- brute-force c3Opt subset (C3 lib_optimization.h names, own implementation) ---- */
 enum c3opt_alg { BFGS = 0, LBFGS = 1, BATCHGRAD = 2, BRUTEFORCE = 3 };
 struct c3Opt;
-struct c3Opt *c3opt_alloc(enum c3opt_alg alg, size_t d); /* only BRUTEFORCE is supported; others abort */
+struct c3Opt *c3opt_alloc(enum c3opt_alg alg, size_t d); /* BRUTEFORCE: list scan; others: box grid + golden-section polish */
 struct c3Opt *c3opt_copy(struct c3Opt *);
 void c3opt_free(struct c3Opt *);
 void c3opt_set_brute_force_vals(struct c3Opt *, size_t n, double *vals /* n x d */);
@@ -41,6 +41,22 @@ int c3opt_minimize(struct c3Opt *, double *x, double *val); /* scan in order, st
 size_t c3opt_get_nbrute(const struct c3Opt *);
 const double *c3opt_get_brute_vals(const struct c3Opt *);
 size_t c3opt_get_d(const struct c3Opt *);
+void c3opt_add_lb(struct c3Opt *, double *lb);
+void c3opt_add_ub(struct c3Opt *, double *ub);
+double *c3opt_get_lb(struct c3Opt *);
+double *c3opt_get_ub(struct c3Opt *);
+void c3opt_set_relftol(struct c3Opt *, double);  /* the line-search knobs of C3's optimisers are accepted and ignored */
+void c3opt_set_absxtol(struct c3Opt *, double);
+void c3opt_set_gtol(struct c3Opt *, double);
+void c3opt_set_maxiter(struct c3Opt *, size_t);
+void c3opt_ls_set_maxiter(struct c3Opt *, size_t);
+void c3opt_ls_set_alpha(struct c3Opt *, double);
+void c3opt_ls_set_beta(struct c3Opt *, double);
+void c3opt_set_verbose(struct c3Opt *, int);
+void c3opt_set_storage_options(struct c3Opt *, int, int, int);
+void c3opt_set_box_search(struct c3Opt *, size_t grid, size_t polish); /* new */
+size_t c3opt_get_box_grid(const struct c3Opt *);
+size_t c3opt_get_box_polish(const struct c3Opt *);
 
 /* ---- Workspace (util.c:689-964): per-node scratch, key buffers, memo tables, + the device context ---- */
 struct Workspace;

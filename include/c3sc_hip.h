@@ -34,6 +34,7 @@ extern "C" {
 #define C3SC_MAX_DIM 12
 #define C3SC_MAX_OBSTACLES 10 /* boundary.c:393 */
 #define C3SC_MAX_PARAMS 8
+#define C3SC_MAX_DU 4 /* control dimensions of the continuous (box) minimiser */
 
 /* error codes (0 = ok, like the reference's int returns) */
 enum {
@@ -117,6 +118,23 @@ int c3sc_hip_policy_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_
                            double *d_out, int32_t *d_absorbed, void *stream);
 int c3sc_hip_policy_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, const int32_t *h_policy,
                                 double *h_out, int32_t *h_absorbed);
+
+/* Continuous controls (bellman_optimal's non-BRUTEFORCE branch, bellman.c:545-1118; the reference hands the node
+ * objective to C3's BFGS with multistarts -- third party, unseeded for du >= 2, unpinned): the device minimises over
+ * the box [lb, ub]^du with a tensor grid of `grid` points per control dimension followed by `polish` rounds of
+ * coordinate golden-section search in the cell around the best grid point.  Models with per-candidate features
+ * (C3SC_MODEL_SCAR4D: tan(u0)) are not served.  set_controls is not needed in this mode.
+ *   d_uopt double [F*N_k*du] or NULL: the minimiser per node (zeros at absorbed nodes)
+ * c3sc_hip_policy_fibers_box evaluates a given control per node (bellman_pi with continuous controls). */
+int c3sc_hip_set_control_box(c3sc_hip_ctx *ctx, int du, const double *lb, const double *ub, int grid, int polish);
+int c3sc_hip_bellman_fibers_box(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, double *d_out, double *d_uopt,
+                                int32_t *d_absorbed, void *stream);
+int c3sc_hip_bellman_fibers_box_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, double *h_out, double *h_uopt,
+                                     int32_t *h_absorbed);
+int c3sc_hip_policy_fibers_box(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, const double *d_policy_u,
+                               double *d_out, int32_t *d_absorbed, void *stream);
+int c3sc_hip_policy_fibers_box_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, const double *h_policy_u,
+                                    double *h_out, int32_t *h_absorbed);
 
 /* The same hot path for ARBITRARY host callbacks (the reference's examples unchanged): the host evaluates
  * drift_eval / diff_eval / stagecost (dynamics.c:127-139,224-239; bellman.c:414-444) for every (node, candidate)

@@ -15,6 +15,7 @@ DYN_FN = C.CFUNCTYPE(C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_
 STAGE_FN = C.CFUNCTYPE(C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p)
 BOUND_FN = C.CFUNCTYPE(C.c_int, C.c_double, c_double_p, c_double_p)
 OBS_FN = C.CFUNCTYPE(C.c_int, c_double_p, c_double_p)
+FIBER_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, c_double_p, c_double_p, C.c_void_p)
 
 
 def lib():
@@ -72,7 +73,7 @@ def ptrs(arrs):
 class Control:
     """c3control_create + problem wiring from a workloads.Workload (device model + optional host callbacks)."""
 
-    def __init__(self, w, callbacks=None, device_model=True):
+    def __init__(self, w, callbacks=None, device_model=True, box=None):
         L = lib()
         self.L, self.w = L, w
         self._lb, self._ub, self._ng = f64(w.lb), f64(w.ub), usz(w.ngrid)
@@ -93,9 +94,20 @@ class Control:
             L.c3control_add_stagecost(self.h, st)
             L.c3control_add_boundcost(self.h, bd)
             L.c3control_add_obscost(self.h, ob)
-        self.opt = C.c_void_p(L.c3opt_alloc(C.c_int(3), C.c_size_t(w.du)))
-        cands = f64(w.cands)
-        L.c3opt_set_brute_force_vals(self.opt, C.c_size_t(cands.shape[0]), dp(cands))
+        if box is None:
+            self.opt = C.c_void_p(L.c3opt_alloc(C.c_int(3), C.c_size_t(w.du)))  # BRUTEFORCE
+            cands = f64(w.cands)
+            L.c3opt_set_brute_force_vals(self.opt, C.c_size_t(cands.shape[0]), dp(cands))
+        else:  # the examples' set-up for continuous controls (e.g. tprob_test.c:2291-2299): BFGS + box bounds
+            lb, ub = f64(box[0]), f64(box[1])
+            self.opt = C.c_void_p(L.c3opt_alloc(C.c_int(0), C.c_size_t(w.du)))
+            L.c3opt_add_lb(self.opt, dp(lb))
+            L.c3opt_add_ub(self.opt, dp(ub))
+            L.c3opt_set_relftol(self.opt, C.c_double(1e-8))
+            L.c3opt_set_gtol(self.opt, C.c_double(1e-30))
+            L.c3opt_ls_set_maxiter(self.opt, C.c_size_t(10))
+            L.c3opt_set_verbose(self.opt, C.c_int(0))
+            L.c3opt_set_maxiter(self.opt, C.c_size_t(10))
 
     def xgrid(self):
         pp = self.L.c3control_get_xgrid(self.h)

@@ -323,3 +323,86 @@ def test_bellman_pi_through_reference_api(oracle, device_model):
         assert ctl.end_pi_step(pi) == P.niter_node_evals()
     L.pi_param_destroy(pi)
     ctl.close()
+
+
+def _lqg2d_callbacks():
+    """tprob_test.c f1b / s1 / stagecost2d / boundcost / ocost (lines 132-318)."""
+    import facade_lib
+
+    def drift(t, x, u, out, jac, args):
+        out[0], out[1] = x[1], u[0]
+        return 0
+
+    def diff(t, x, u, out, grad, args):
+        out[0], out[1], out[2], out[3] = 1.0, 0.0, 0.0, 1.0
+        return 0
+
+    def stage(t, x, u, out, grad):
+        out[0] = x[0] * x[0] + x[1] * x[1] + u[0] * u[0]
+        return 0
+
+    def bcost(t, x, out):
+        out[0] = 100.0
+        return 0
+
+    def ocost(x, out):
+        out[0] = 0.0
+        return 0
+
+    return (facade_lib.DYN_FN(drift), facade_lib.DYN_FN(diff), facade_lib.STAGE_FN(stage), facade_lib.BOUND_FN(bcost),
+            facade_lib.OBS_FN(ocost))
+
+
+@pytest.mark.gpu
+def test_continuous_controls_through_reference_api(oracle):
+    """c3opt_alloc(BFGS) + add_lb/ub as the reference's tests and examples set it up (tprob_test.c:2291-2299):
+    bellman_vi minimises over the control box on the device; the device result is cross-checked against the host
+    box minimiser over the user's callbacks on the first fiber (cross_check_model), obeys the reference's own
+    property (not above the 100-point grid minimum + 1e-10, tprob_test.c:1540), and value/policy iteration run."""
+    import facade_lib
+
+    L = facade_lib.lib()
+    for n in ("c3control_init_value", "c3control_vi_solve", "c3control_pi_solve"):
+        getattr(L, n).restype = C.c_void_p
+    L.valuef_norm2diff.restype = C.c_double
+    w0 = wl.c1_lqg2d().scaled(ngrid=(25, 23), rank=4)
+    cores = wl.synth_cores(w0)
+    ctl = facade_lib.Control(w0, _lqg2d_callbacks(), box=([-1.0], [1.0]))
+    vf = ctl.valuef(cores)
+    vi = ctl.begin_vi(vf)
+    xg = ctl.xgrid()
+    w100 = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, w0.discount, w0.bc, [],
+                       np.linspace(-1, 1, 100).reshape(-1, 1))
+    P100 = oracle.Problem(w100, cores)
+    for k in range(2):
+        idx = wl.synth_fibers(w0, k, 12)
+        N = w0.ngrid[k]
+        x = np.array([[[xg[m][j] if m == k else xg[m][row[m]] for m in range(2)] for j in range(N)] for row in idx])
+        out = ctl.bellman_vi_batch(vi, x)
+        ref, _, ab = P100.bellman_fibers(k, idx)
+        assert (out[ab == 0] <= ref[ab == 0] + 1e-10).all()
+        assert (out[ab == 0] >= ref[ab == 0] - 1e-3 * np.abs(ref).max()).all()
+        np.testing.assert_allclose(out[ab != 0], ref[ab != 0], rtol=1e-12)
+    ctl.end_vi(vi)
+    ctl.close()
+    # the solver loops with continuous controls (stronger discount so that a few updates visibly contract)
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, 8.0, w0.bc, [], w0.cands)
+    ctl = facade_lib.Control(w, box=([-1.0], [1.0]))
+    aa = C.c_void_p(L.approx_args_init())
+    L.approx_args_set_maxrank(aa, C.c_size_t(12))
+    L.approx_args_set_startrank(aa, C.c_size_t(3))
+    L.approx_args_set_kickrank(aa, C.c_size_t(3))
+    const = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.2), 0)[1])
+    cost = C.c_void_p(L.c3control_init_value(ctl.h, const, None, aa, 0))
+    diffs = []
+    for upd in range(4):
+        nxt = C.c_void_p(L.c3control_pi_solve(ctl.h, C.c_size_t(5), C.c_double(1e-7), cost, aa, ctl.opt, 0, None))
+        L.valuef_destroy(cost)
+        tmp = C.c_void_p(L.c3control_vi_solve(ctl.h, C.c_size_t(1), C.c_double(1e-7), nxt, aa, ctl.opt, 0, None))
+        diffs.append(L.valuef_norm2diff(nxt, tmp))
+        L.valuef_destroy(nxt)
+        cost = tmp
+    assert diffs[-1] < diffs[0]
+    L.valuef_destroy(cost)
+    L.approx_args_free(aa)
+    ctl.close()

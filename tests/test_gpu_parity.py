@@ -260,3 +260,46 @@ def test_policy_evaluation_vs_oracle(oracle, name, kw):
             assert np.abs(out2 - ref).max() <= REL_TOL * scale
         worst = max(worst, err[~bad].max() / scale)
     assert P.niter_node_evals() > 0 and P.npol_evals() > 0
+
+
+def _with_cands(w, cands):
+    return wl.Workload(w.name, w.model, w.params, w.dx, w.du, w.lb, w.ub, w.ngrid, w.ranks, w.discount, w.bc,
+                       list(w.obstacles), np.asarray(cands, dtype=np.float64))
+
+
+@pytest.mark.parametrize("name,kw,grid,fine", [("lqg2d", dict(ngrid=(21, 19), rank=4), 33, 20001),
+                                               ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8), 9, 41)],
+                         ids=["lqg2d-du1", "lqg6d-du3"])
+def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
+    """c3sc_hip_bellman_fibers_box: the non-BRUTEFORCE branch of bellman_optimal (bellman.c:545-1118).  The optimiser
+    there is C3's BFGS (third party, unpinned), so the check is the reference's own (tprob_test.c:1494-1540):
+    the result must not exceed the minimum over a 100-point linspace of the control box by more than 1e-10 -- plus a
+    lower bound from a much finer grid and a policy-evaluation round trip of the returned control."""
+    import itertools
+
+    w = wl.WORKLOADS[name]().scaled(**kw)
+    cores = wl.synth_cores(w)
+    lb, ub = -np.ones(w.du), np.ones(w.du)
+    eng = _engine(w, cores, 0)
+    eng.set_control_box(lb, ub, grid=grid, polish=2)
+    n100 = 100 if w.du == 1 else 11
+    axes = lambda n: list(itertools.product(*[np.linspace(lb[i], ub[i], n) for i in range(w.du)]))
+    P100 = oracle.Problem(_with_cands(w, axes(n100)), cores)
+    Pfine = oracle.Problem(_with_cands(w, axes(fine)), cores)
+    for k in range(w.dx):
+        idx = wl.synth_fibers(w, k, 9)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        out, uo, ab = eng.bellman_fibers_box_host(k, idx)
+        assert eng.status() == 0 and "fiber_per_wave" in eng.last_kernel()
+        r100, _, ab0 = P100.bellman_fibers(k, idx)
+        rfine, _, _ = Pfine.bellman_fibers(k, idx)
+        np.testing.assert_array_equal(ab, ab0)
+        live = ab == 0
+        scale = np.abs(rfine).max()
+        assert (out[live] <= r100[live] + 1e-10).all()          # the reference's assertion on bellman_optimal
+        assert (out[live] >= rfine[live] - 2e-5 * scale).all()  # not below what a much finer scan finds (up to its spacing)
+        np.testing.assert_allclose(out[~live], rfine[~live], rtol=1e-12)  # absorbed nodes: boundcost / obscost
+        assert (uo >= lb - 1e-15).all() and (uo <= ub + 1e-15).all()
+        back, _ = eng.policy_fibers_box_host(k, idx, uo)  # bellman_pi with the continuous policy
+        np.testing.assert_allclose(back, out, rtol=1e-12, atol=1e-12 * scale)

@@ -1039,6 +1039,9 @@ struct VIparam *c3control_begin_vi(struct C3Control *c, struct ValueF *vf, struc
     vi_param_add_cp(vi, c->cp_active);
     vi_param_add_value(vi, vf);
     workspace_increment_vi_iter(c->work);
+    /* entries of earlier iterations can never be hit again (the key carries vi_iter); the reference lets them linger
+     * until the next reset, which only costs memory -- and cache misses: keep the integer table small */
+    fastmemo_clear(workspace_get_vi_fastmemo(c->work));
     return vi;
 }
 

@@ -197,6 +197,19 @@ def test_full_size_properties():
     cores = wl.synth_cores(w)
     eng = _engine(w, cores)
     k = 2
+    # (0) the two production kernels agree at full size: 70 000 fibers = more tiles than resident workgroups for the
+    # fiber-pair kernel (second trip of its tile loop, ragged last tile) against one-wave-per-fiber
+    big = wl.synth_fibers(w, k, 70000)
+    eng.set_variant(3)
+    o_pair, u_pair, a_pair = eng.bellman_fibers_host(k, big)
+    assert "fiber_pair" in eng.last_kernel()
+    eng.set_variant(1)
+    o_wave, u_wave, a_wave = eng.bellman_fibers_host(k, big)
+    assert "fiber_per_wave" in eng.last_kernel()
+    np.testing.assert_array_equal(a_pair, a_wave)
+    assert np.abs(o_pair - o_wave).max() <= REL_TOL * np.abs(o_wave).max()
+    assert (u_pair != u_wave).mean() < 1e-4  # argmin only differs on (near) ties
+    eng.set_variant(3)
     idx = wl.synth_fibers(w, k, 4096)
     out, ui, ab = eng.bellman_fibers_host(k, idx)
     assert np.isfinite(out).all()
@@ -303,3 +316,26 @@ def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
         assert (uo >= lb - 1e-15).all() and (uo <= ub + 1e-15).all()
         back, _ = eng.policy_fibers_box_host(k, idx, uo)  # bellman_pi with the continuous policy
         np.testing.assert_allclose(back, out, rtol=1e-12, atol=1e-12 * scale)
+
+
+def test_edge_cases_empty_batch_max_rank_max_nodes(oracle):
+    """Empty batch; the largest compiled rank (scar-4D at FT rank 20) and the largest node count (128 per
+    fiber: two nodes per lane, both lane-table registers in use)."""
+    w = wl.WORKLOADS["scar4d"]().scaled(ngrid=(12, 11, 10, 9), rank=20)
+    cores = wl.synth_cores(w)
+    eng = _engine(w, cores)
+    out, ui, ab = eng.bellman_fibers_host(1, np.zeros((0, w.dx), dtype=np.int32))
+    assert out.shape == (0, 11) and eng.status() == 0
+    P = oracle.Problem(w, cores)
+    for k in range(w.dx):
+        _check(eng, P, w, k, wl.synth_fibers(w, k, 9))
+    w2 = wl.c2_dubins().scaled(ngrid=(128, 5, 128), rank=4)
+    cores2 = wl.synth_cores(w2)
+    P2 = oracle.Problem(w2, cores2)
+    for variant in (1, 3):
+        eng2 = _engine(w2, cores2, variant)
+        for k in (0, 2):
+            idx = wl.synth_fibers(w2, k, 70)
+            idx[0, :] = 0
+            idx[1, :] = np.array(w2.ngrid) - 1
+            _check(eng2, P2, w2, k, idx)

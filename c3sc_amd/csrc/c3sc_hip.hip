@@ -545,7 +545,9 @@ static int launch_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, co
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: no fiber-per-wave instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, nullptr, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
-    HIPCHK(c, e->fn(A, io));
+    const hipError_t he = e->fn(A, io);
+    if (he == hipErrorNotSupported) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: no box-minimiser instantiation for this model");
+    HIPCHK(c, he);
     return C3SC_OK;
 }
 

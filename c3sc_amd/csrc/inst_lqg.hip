@@ -2,17 +2,17 @@
 #include "launch_fpw.hpp"
 #include "models.hpp"
 namespace c3sc {
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 4, 1, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 4, 1, LqgNd<2>)
 // ranks an adaptive cross approximation of the 2-D problems reaches (c3control_vi_solve / pi_solve, N up to 128)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 4, 2, LqgNd<2>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 8, 1, LqgNd<2>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 8, 2, LqgNd<2>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 12, 1, LqgNd<2>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 12, 2, LqgNd<2>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 20, 1, LqgNd<2>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 20, 2, LqgNd<2>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 4, 1, LqgNd<6>)
-C3SC_REG_FPW(C3SC_MODEL_LQGND, 8, 1, LqgNd<6>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 4, 2, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 8, 1, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 8, 2, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 12, 1, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 12, 2, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 20, 1, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 20, 2, LqgNd<2>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 4, 1, LqgNd<6>)
+C3SC_REG_FPW_BOX(C3SC_MODEL_LQGND, 8, 1, LqgNd<6>)
 C3SC_REG_FPW(C3SC_MODEL_CHAIN, 4, 1, Chain<2>)
 C3SC_REG_STENCIL(2, 4, 1)
 C3SC_REG_STENCIL(2, 4, 2)

@@ -66,8 +66,10 @@ __device__ inline double dot_lds(const double *s, const double (&v)[RP])
 // LDS stride (in doubles) of one node's matrix of the varying core: odd => conflict-free ds_read_b64
 __host__ __device__ constexpr int kcore_stride(int rp, bool edge) { return (edge ? rp : rp * rp) | 1; }
 
-template <class Model, int RP, int NPL, bool STENCIL>
-__global__ void __launch_bounds__(256)
+// (256, 2): two workgroups per CU = 2 waves per SIMD, i.e. at most 256 registers per lane; without the bound the
+// rank-16 instantiations take 256 + a few AGPRs and drop to one wave per SIMD (quad10d: 9.7e8 -> 7.0e8 nodes/s)
+template <class Model, int RP, int NPL, bool STENCIL, bool BOX = false>
+__global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bound to one workgroup per CU anyway
     k_fiber_per_wave(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
                      int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed, const int32_t *__restrict__ nbf,
                      const int32_t *__restrict__ nbv, const double *__restrict__ tbl, const double *__restrict__ tcost)
@@ -307,10 +309,12 @@ __global__ void __launch_bounds__(256)
                 if constexpr (Model::IS_TABLE) {
                     const size_t node = (size_t)f * N + jj;
                     val = node_backup_tables<D>(A, tbl + node * A.ncand * S, tcost + node * 2, V, ab, ui, st, forced, fu);
-                } else if constexpr (Model::NCF == 0) {
+                } else if constexpr (BOX) { // continuous controls in a box: a separate instantiation (the minimiser
+                                            // costs ~60 VGPRs, which halves the occupancy of the rank-16 kernels)
+                    static_assert(Model::NCF == 0, "box minimiser: no transcendental functions of the control");
                     double tv[Model::NTAB > 0 ? Model::NTAB : 1];
                     table_values<Model>(A, ro, ix, tv);
-                    if (A.cmode == 1) { // continuous controls in a box (wave-uniform switch)
+                    {
                         double uo[Model::DU];
                         const bool fcd = A.forced_u != nullptr;
                         val = node_backup_box<Model>(A, x, tv, V, ab, uo, st, fcd,
@@ -318,8 +322,6 @@ __global__ void __launch_bounds__(256)
                         ui = -1;
                         if (live && A.uopt)
                             for (int i = 0; i < Model::DU; i++) A.uopt[((size_t)f * N + j) * Model::DU + i] = uo[i];
-                    } else {
-                        val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
                     }
                 } else {
                     double tv[Model::NTAB > 0 ? Model::NTAB : 1];

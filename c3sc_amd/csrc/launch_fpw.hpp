@@ -7,14 +7,15 @@ namespace c3sc {
 
 constexpr int NUM_CU = 256; // MI355X
 
-template <class Model, int RP, int NPL, bool STENCIL>
+template <class Model, int RP, int NPL, bool STENCIL, bool BOX = false>
 hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
 {
+    if (A.cmode == 1 && !BOX) return hipErrorNotSupported; // this entry has no box-minimiser instantiation
     constexpr int D = Model::D;
     constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL;
     const bool kedge = (A.k == 0) || (A.k == D - 1);
     const size_t shmem = (size_t)(4 * WS + A.N * kcore_stride(RP, kedge)) * sizeof(double);
-    auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL>;
+    auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL, BOX>;
     static int blocks_per_cu = 0;
     static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
     hipError_t e;
@@ -47,6 +48,17 @@ hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
     static Registrar C3SC_CAT(reg_fpw_, __COUNTER__)(KernelEntry{                                            \
         MODEL_ID, __VA_ARGS__::D, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL, -1,                          \
         &launch_fpw<__VA_ARGS__, RP, NPL, false>, "k_fiber_per_wave<" #__VA_ARGS__ "," #RP "," #NPL ">"});
+
+// the same entry serving both the candidate-list kernel and the box minimiser (continuous controls)
+template <class Model, int RP, int NPL>
+hipError_t launch_fpw_both(const KArgs &A, const LaunchIO &io)
+{
+    return A.cmode == 1 ? launch_fpw<Model, RP, NPL, false, true>(A, io) : launch_fpw<Model, RP, NPL, false, false>(A, io);
+}
+#define C3SC_REG_FPW_BOX(MODEL_ID, RP, NPL, ...)                                                             \
+    static Registrar C3SC_CAT(reg_fpwb_, __COUNTER__)(KernelEntry{                                           \
+        MODEL_ID, __VA_ARGS__::D, RP, NPL, C3SC_VARIANT_FIBER_PER_WAVE, 64 * NPL, -1,                          \
+        &launch_fpw_both<__VA_ARGS__, RP, NPL>, "k_fiber_per_wave<" #__VA_ARGS__ "," #RP "," #NPL ">"});
 
 #define C3SC_REG_STENCIL(DIM, RP, NPL)                                                                       \
     static Registrar C3SC_CAT(reg_st_, __COUNTER__)(KernelEntry{                                             \

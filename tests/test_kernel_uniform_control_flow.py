@@ -16,7 +16,8 @@ EXEC_WRITE = re.compile(r"saveexec|s_mov_b64 exec|s_and_b64 exec|s_andn2_b64 exe
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src,kernel", [("inst_car7d_fpp.hip", "k_fiber_pair"), ("inst_car7d_fpl.hip", "k_fiber_per_lane")])
+@pytest.mark.parametrize("src,kernel", [("inst_car7d_fpp.hip", "k_fiber_pair"), ("inst_other_fpp.hip", "k_fiber_pair"),
+                                        ("inst_lqg6_fpp.hip", "k_fiber_pair"), ("inst_car7d_fpl.hip", "k_fiber_per_lane")])
 def test_no_lane_divergent_control_flow(tmp_path, src, kernel):
     out = tmp_path / "k.s"
     subprocess.run([HIPCC, "-std=c++20", "-O3", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),

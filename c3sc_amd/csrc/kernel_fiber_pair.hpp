@@ -25,6 +25,9 @@
 #ifndef FPP_CGD
 #define FPP_CGD 3
 #endif
+#ifndef FPP_NV
+#define FPP_NV 4 // vectors per pass over a staged matrix in the folding phase (2: 0.361 ms, 3: 0.343, 4: 0.340 on car7d)
+#endif
 #ifndef FPP_ROWPIPE
 #define FPP_ROWPIPE 0
 #endif
@@ -32,6 +35,31 @@
 namespace c3sc {
 
 constexpr int FPP_THREADS = 128;
+
+// apply the staged matrix G to W[FIRST .. FIRST+COUNT) AND to one extra vector E in the same passes: every pass
+// re-reads the 100-element matrix of the lane's node from LDS, and LDS (gathered rows, ~2x bank conflicts) is the
+// busiest unit of the folding phase, so the running prefix/suffix rides along instead of taking a pass of its own
+template <int RP, int NW, int FIRST, int COUNT, bool ROWVEC>
+__device__ inline void apply_core_and(const double *G, double (&W)[NW][RP], double (&E)[RP])
+{
+    constexpr int N1 = COUNT >= FPP_NV - 1 ? FPP_NV - 1 : COUNT;
+    double tmp[N1 + 1][RP];
+#pragma unroll
+    for (int a = 0; a < RP; a++) tmp[0][a] = E[a];
+#pragma unroll
+    for (int s = 0; s < N1; s++)
+#pragma unroll
+        for (int a = 0; a < RP; a++) tmp[s + 1][a] = W[FIRST + s][a];
+    if constexpr (ROWVEC) vecmat_lds<RP, N1 + 1>(G, tmp);
+    else matvec_lds<RP, N1 + 1>(G, tmp);
+#pragma unroll
+    for (int a = 0; a < RP; a++) E[a] = tmp[0][a];
+#pragma unroll
+    for (int s = 0; s < N1; s++)
+#pragma unroll
+        for (int a = 0; a < RP; a++) W[FIRST + s][a] = tmp[s + 1][a];
+    apply_core<RP, NW, FIRST + N1, COUNT - N1, ROWVEC, FPP_NV>(G, W);
+}
 
 __device__ inline void pair_barrier()
 { // workgroup barrier + LDS visibility between the two wavefronts.  Only LDS traffic is exchanged, so only
@@ -167,8 +195,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 pair_barrier();
                 FPP_STAMP(7)
                 const double *G = sK + fi[m] * str;
-                apply_core<RP, NOWN, 0, before, true>(G, W);
-                if constexpr (pair_owner<K>(m) == H) {
+                if constexpr (pair_owner<K>(m) == H) { // the new pair first: it needs the prefix BEFORE this core
                     double t0[1][RP], t1[1][RP];
 #pragma unroll
                     for (int a = 0; a < RP; a++) { t0[0][a] = L[a]; t1[0][a] = L[a]; }
@@ -177,14 +204,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
 #pragma unroll
                     for (int a = 0; a < RP; a++) { W[before][a] = t0[0][a]; W[before + 1][a] = t1[0][a]; }
                 }
-                {
-                    double t[1][RP];
-#pragma unroll
-                    for (int a = 0; a < RP; a++) t[0][a] = L[a];
-                    vecmat_lds<RP, 1>(G, t);
-#pragma unroll
-                    for (int a = 0; a < RP; a++) L[a] = t[0][a];
-                }
+                apply_core_and<RP, NOWN, 0, before, true>(G, W, L);
             };
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (left_step(std::integral_constant<int, Ms + 1>{}), ...); }
             (std::make_integer_sequence<int, (K > 1 ? K - 1 : 0)>{});
@@ -218,7 +238,6 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 pair_barrier();
                 FPP_STAMP(7)
                 const double *G = sK + fi[m] * str;
-                apply_core<RP, NOWN, NOL, after, false>(G, W);
                 if constexpr (pair_owner<K>(m) == H) {
                     double t0[1][RP], t1[1][RP];
 #pragma unroll
@@ -228,14 +247,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
 #pragma unroll
                     for (int a = 0; a < RP; a++) { W[NOL + after][a] = t0[0][a]; W[NOL + after + 1][a] = t1[0][a]; }
                 }
-                {
-                    double t[1][RP];
-#pragma unroll
-                    for (int a = 0; a < RP; a++) t[0][a] = R[a];
-                    matvec_lds<RP, 1>(G, t);
-#pragma unroll
-                    for (int a = 0; a < RP; a++) R[a] = t[0][a];
-                }
+                apply_core_and<RP, NOWN, NOL, after, false>(G, W, R);
             };
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (right_step(std::integral_constant<int, D - 2 - Ms>{}), ...); }
             (std::make_integer_sequence<int, (D - 2 - K > 0 ? D - 2 - K : 0)>{});

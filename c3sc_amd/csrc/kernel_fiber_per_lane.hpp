@@ -121,11 +121,11 @@ __device__ inline void matvec_lds(const double *G, double (&v)[NV][RP])
 }
 
 // apply `op` to W[FIRST .. FIRST+COUNT) in passes of at most 4 vectors (compile-time recursion)
-template <int RP, int NW, int FIRST, int COUNT, bool ROWVEC>
+template <int RP, int NW, int FIRST, int COUNT, bool ROWVEC, int NVMAX = FPL_NV>
 __device__ inline void apply_core(const double *G, double (&W)[NW][RP])
 {
     if constexpr (COUNT > 0) {
-        constexpr int NV = COUNT >= FPL_NV ? FPL_NV : COUNT;
+        constexpr int NV = COUNT >= NVMAX ? NVMAX : COUNT;
         double tmp[NV][RP];
 #pragma unroll
         for (int s = 0; s < NV; s++)
@@ -137,7 +137,7 @@ __device__ inline void apply_core(const double *G, double (&W)[NW][RP])
         for (int s = 0; s < NV; s++)
 #pragma unroll
             for (int a = 0; a < RP; a++) W[FIRST + s][a] = tmp[s][a];
-        apply_core<RP, NW, FIRST + NV, COUNT - NV, ROWVEC>(G, W);
+        apply_core<RP, NW, FIRST + NV, COUNT - NV, ROWVEC, NVMAX>(G, W);
     }
 }
 

@@ -278,6 +278,32 @@ __device__ inline void table_values(const KArgs &A, const double *__restrict__ r
     for (int t = 0; t < Model::NTAB; t++) tv[t] = ro[A.tab_off[t] + ix[Model::tab_dim(t)]];
 }
 
+// exp(x) for the discount factor exp(-beta dt) (bellman.c:94).  With an MCA time step dt = h^2/Q the argument is tiny
+// (|x| ~ 1e-4 for the LQG examples); below 2^-7 a degree-7 Taylor polynomial is exact to double rounding (the first
+// omitted term is < 2^-56/40320 relative), so the ~30-instruction libm path runs only when some lane needs it
+// (wave-uniform branch).
+__device__ __forceinline__ double sgpr_const(double c)
+{ // materialised on the scalar unit where it is used: a literal the compiler hoists out of the node loop sits in a
+  // VGPR pair for the whole kernel (seven of them cost the undiscounted car7d kernel 11 %)
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
+__device__ inline double exp_discount(double x)
+{
+    if (__all(fabs(x) < 0.0078125)) {
+        double p = sgpr_const(1.0 / 5040.0);
+        p = fma(p, x, sgpr_const(1.0 / 720.0));
+        p = fma(p, x, sgpr_const(1.0 / 120.0));
+        p = fma(p, x, sgpr_const(1.0 / 24.0));
+        p = fma(p, x, sgpr_const(1.0 / 6.0));
+        p = fma(p, x, 0.5);
+        p = fma(p, x, 1.0);
+        return fma(p, x, 1.0);
+    }
+    return exp(x);
+}
+
 // One node of the Bellman operator from host-evaluated callback tables (TableModel): row = this node's
 // [U][2D+1] block, cost = (boundcost, obscost).  Same arithmetic as node_backup below.
 template <int D>
@@ -516,7 +542,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
             const double dt = h2l * inv;               // nodeutil.c:369
             const double pself = fma(-Qs, inv, 1.0);   // 1 - sum_i p_i/Q: rounding residue, as in the reference
             const double ctg = fma(pself, V[2 * D], PV * inv);
-            const double ebt = (A.discount == 0.0) ? 1.0 : exp(-discl * dt); // bellman.c:94
+            const double ebt = (A.discount == 0.0) ? 1.0 : exp_discount(-discl * dt); // bellman.c:94
             val[q] = dt * stage + ebt * ctg;                                 // bellman.c:97
         }
 #pragma unroll
@@ -603,7 +629,7 @@ __device__ inline double node_backup_box(const KArgs &A, const double (&x)[Model
         const double dt = A.h2 * inv;
         const double pself = fma(-Qs, inv, 1.0);
         const double ctg = fma(pself, V[2 * D], PV * inv);
-        const double ebt = (A.discount == 0.0) ? 1.0 : exp(-A.discount * dt);
+        const double ebt = (A.discount == 0.0) ? 1.0 : exp_discount(-A.discount * dt);
         const double val = dt * stage + ebt * ctg;
         return ok ? val : 1.0e300;
     };

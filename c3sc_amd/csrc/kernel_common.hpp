@@ -45,6 +45,7 @@ struct KArgs {
     double ulb[C3SC_MAX_DU], uub[C3SC_MAX_DU];
     double *uopt;              // [F][N][du] minimiser per node (may be null)
     const double *forced_u;    // policy evaluation with continuous controls: [F][N][du] control to apply, or null
+    int tbl_off;               // fiber-pair kernel: offset (doubles) of the candidate / node tables in dynamic LDS
 };
 
 // Output pointers of one launch (separate __restrict__ kernel parameters).
@@ -232,6 +233,12 @@ struct CandRegs {
     double cf[Model::NCF > 0 ? Model::NCF : 1];
     double rpm[NUC], rpp[NUC]; // rate to the (-,+) neighbour of each UCONST dim
     double qab;                // their sum, in the association the scan uses: (sum pm) + (sum pp)
+    // accessors shared with CandLds (the same table in LDS): candidate c is wave-uniform
+    __device__ inline double get_u(int i, int c) const { return readlane_f64(u[i], c); }
+    __device__ inline double get_cf(int i, int c) const { return readlane_f64(cf[i], c); }
+    __device__ inline double get_rpm(int slot, int c) const { return readlane_f64(rpm[slot], c); }
+    __device__ inline double get_rpp(int slot, int c) const { return readlane_f64(rpp[slot], c); }
+    __device__ inline double get_qab(int c) const { return readlane_f64(qab, c); }
     __device__ inline void load(const KArgs &A, const double *__restrict__ ro)
     {
         constexpr int D = Model::D;
@@ -266,6 +273,60 @@ struct CandRegs {
             qab = Qa + Qb;
         }
     }
+};
+
+// The same candidate table in LDS (one row of CW doubles per candidate), read with a wave-uniform address (broadcast):
+// no VGPRs held across the node loop and nothing that depends on inactive lanes.  Filled once per workgroup from a
+// CandRegs (every lane writes its own candidate's row; lanes past ncand repeat the last candidate).
+template <class Model>
+struct CandLds {
+    static constexpr int DU = Model::DU, NCFa = Model::NCF > 0 ? Model::NCF : 1, NUC = CandRegs<Model>::NUC;
+    static constexpr int CW = DU + NCFa + 2 * NUC + 1;
+    const double *tb;
+    __host__ __device__ static constexpr int doubles(int ncand) { return ncand * CW; }
+    __device__ inline void fill(double *dst, const CandRegs<Model> &cr, int ncand)
+    {
+        const int c = min((int)(threadIdx.x & 63), ncand - 1);
+        double *row = dst + c * CW;
+#pragma unroll
+        for (int i = 0; i < DU; i++) row[i] = cr.u[i];
+#pragma unroll
+        for (int i = 0; i < NCFa; i++) row[DU + i] = cr.cf[i];
+#pragma unroll
+        for (int i = 0; i < NUC; i++) { row[DU + NCFa + i] = cr.rpm[i]; row[DU + NCFa + NUC + i] = cr.rpp[i]; }
+        row[DU + NCFa + 2 * NUC] = cr.qab;
+        tb = dst;
+    }
+    __device__ inline double get_u(int i, int c) const { return tb[c * CW + i]; }
+    __device__ inline double get_cf(int i, int c) const { return tb[c * CW + DU + i]; }
+    __device__ inline double get_rpm(int slot, int c) const { return tb[c * CW + DU + NCFa + slot]; }
+    __device__ inline double get_rpp(int slot, int c) const { return tb[c * CW + DU + NCFa + NUC + slot]; }
+    __device__ inline double get_qab(int c) const { return tb[c * CW + DU + NCFa + 2 * NUC]; }
+};
+
+// NodeRegs in LDS: per node of the varying dim (x, K-indexed tables..., obstacle mask as a double-sized slot)
+template <class Model, int K>
+struct NodeLds {
+    static constexpr int NKT = NodeRegs<Model, K>::NKT;
+    static constexpr int NW = 2 + NKT; // x, mask, tables
+    const double *tb;
+    __host__ __device__ static constexpr int doubles(int N) { return N * NW; }
+    __device__ inline void fill(double *dst, const NodeRegs<Model, K> &nr, int N)
+    {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int j = min((int)(threadIdx.x & 63) + 64 * q, N - 1);
+            double *row = dst + j * NW;
+            row[0] = nr.xk[q];
+            row[1] = __hiloint2double(0, (int)nr.km[q]);
+#pragma unroll
+            for (int t = 0; t < NKT; t++) row[2 + t] = nr.tk[t][q];
+        }
+        tb = dst;
+    }
+    __device__ inline double x_at(int j) const { return tb[j * NW]; }
+    __device__ inline unsigned mask_at(int j) const { return (unsigned)__double2loint(tb[j * NW + 1]); }
+    __device__ inline double tab_at(int t, int j) const { return tb[j * NW + 2 + NodeRegs<Model, K>::kslot(t)]; }
 };
 
 // values of the model's tables at the node with grid indices ix[]
@@ -347,9 +408,9 @@ __device__ inline double node_backup_tables(const KArgs &A, const double *__rest
 // (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)
 // neighbour in dim m, V[2D] = value at the node.  The candidate scan keeps the first minimum
 // (strict '<'), as the brute-force c3opt is assumed to.
-template <class Model, int CG = 1, int CGD = 1>
+template <class Model, int CG = 1, int CGD = 1, class Cand = CandRegs<Model>>
 __device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
-                                     const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1], const CandRegs<Model> &cr,
+                                     const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1], const Cand &cr,
                                      const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st, bool forced = false,
                                      int fu = -1)
 {
@@ -386,11 +447,11 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     {
         double u[DU], b[D], s[D];
 #pragma unroll
-        for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], 0);
+        for (int i = 0; i < DU; i++) u[i] = cr.get_u(i, 0);
         double cf0[Model::NCF > 0 ? Model::NCF : 1];
         cf0[0] = 0.0;
 #pragma unroll
-        for (int i = 0; i < Model::NCF; i++) cf0[i] = readlane_f64(cr.cf[i], 0);
+        for (int i = 0; i < Model::NCF; i++) cf0[i] = cr.get_cf(i, 0);
         Model::drift(A.prm, nd, x, u, cf0, b);
         Model::sigma(A.prm, x, u, s);
         if constexpr (!Model::STAGE_UDEP) stage0 = Model::stage(A.prm, x, u);
@@ -434,19 +495,19 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
 #pragma unroll
                     for (int m = 0; m < D; m++) {
                         if ((UM >> m) & 1u) {
-                            PVa = fma(readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c), V[2 * m], PVa);
-                            PVb = fma(readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c), V[2 * m + 1], PVb);
+                            PVa = fma(cr.get_rpm(CandRegs<Model>::ucslot(m), c), V[2 * m], PVa);
+                            PVb = fma(cr.get_rpp(CandRegs<Model>::ucslot(m), c), V[2 * m + 1], PVb);
                         }
                     }
-                    Q = Q0 + readlane_f64(cr.qab, c);
+                    Q = Q0 + cr.get_qab(c);
                     num = fma(h2l, stage0, PV0 + (PVa + PVb));
                 } else {
                     double u[DU], cf[NCFa];
 #pragma unroll
-                    for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
+                    for (int i = 0; i < DU; i++) u[i] = cr.get_u(i, c);
                     cf[0] = 0.0;
 #pragma unroll
-                    for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
+                    for (int i = 0; i < Model::NCF; i++) cf[i] = cr.get_cf(i, c);
                     double b[D], sg[D];
                     Model::drift(A.prm, nd, x, u, cf, b);
                     Model::sigma(A.prm, x, u, sg);
@@ -457,8 +518,8 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
                         if ((UM >> m) & 1u) {
                             double pm, pp;
                             if ((UCm >> m) & 1u) {
-                                pm = readlane_f64(cr.rpm[CandRegs<Model>::ucslot(m)], c);
-                                pp = readlane_f64(cr.rpp[CandRegs<Model>::ucslot(m)], c);
+                                pm = cr.get_rpm(CandRegs<Model>::ucslot(m), c);
+                                pp = cr.get_rpp(CandRegs<Model>::ucslot(m), c);
                             } else {
                                 const double half = t2l[m] * (sg[m] * sg[m]) / 2.0;
                                 const double tb = tl[m] * b[m];
@@ -513,10 +574,10 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
             const int c = (c0 + q < nc) ? c0 + q : nc - 1;
             double u[DU], cf[NCFa];
 #pragma unroll
-            for (int i = 0; i < DU; i++) u[i] = readlane_f64(cr.u[i], c);
+            for (int i = 0; i < DU; i++) u[i] = cr.get_u(i, c);
             cf[0] = 0.0;
 #pragma unroll
-            for (int i = 0; i < Model::NCF; i++) cf[i] = readlane_f64(cr.cf[i], c);
+            for (int i = 0; i < Model::NCF; i++) cf[i] = cr.get_cf(i, c);
             double b[D], s[D];
             Model::drift(A.prm, nd, x, u, cf, b);
             Model::sigma(A.prm, x, u, s);

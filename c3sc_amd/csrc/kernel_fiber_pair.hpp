@@ -135,10 +135,21 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
     const int N = A.N;
     const long ntiles = (A.F + 63) / 64;
     unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-    CandRegs<Model> cr;
-    cr.load(A, ro);
-    NodeRegs<Model, K> nr;
-    nr.load(A, ro);
+    // candidate and node tables: computed lane-distributed once, then kept in LDS behind the exchange rows and read
+    // with wave-uniform addresses -- 16 VGPRs less in the node loop than keeping them in lanes, and no dependence on
+    // what a spill does to inactive lanes
+    CandLds<Model> cr;
+    NodeLds<Model, K> nr;
+    {
+        CandRegs<Model> cr0;
+        cr0.load(A, ro);
+        NodeRegs<Model, K> nr0;
+        nr0.load(A, ro);
+        double *tb = sK + A.tbl_off;
+        cr.fill(tb, cr0, A.ncand);
+        nr.fill(tb + CandLds<Model>::doubles(A.ncand), nr0, N);
+        pair_barrier();
+    }
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         FPP_STAMP(7)
@@ -458,7 +469,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             // FORCED (policy evaluation) is a separate instantiation: as a run-time flag it costs the minimising kernel 4 %
             int fu = -1;
             if constexpr (FORCED) fu = A.forced[(size_t)f * N + jn];
-            const double val = node_backup<Model, 1, FPP_CGD>(A, ro, x, tv, cr, V, ab, ui, st, FORCED, fu);
+            const double val = node_backup<Model, 1, FPP_CGD, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, FORCED, fu);
             FPP_STAMP(9) // control scan
             // lanes past the last fiber duplicate fiber F-1 and store the same numbers to the same place: no
             // divergent branch in the node loop (see node_backup on spilled lane tables)

@@ -20,6 +20,10 @@ hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
         const size_t need = (size_t)A.ngrid[m] * fpl_lds_stride(elems);
         if (need > doubles) doubles = need;
     }
+    // wave-uniform tables (candidates, nodes of dim K) behind everything else: they persist across tiles
+    KArgs B = A;
+    B.tbl_off = (int)doubles;
+    doubles += (size_t)CandLds<Model>::doubles(A.ncand) + (size_t)NodeLds<Model, K>::doubles(A.N);
     const size_t shmem = doubles * sizeof(double);
     auto kern = k_fiber_pair<Model, RP, K, FORCED>;
     static int blocks_per_cu = 0;
@@ -41,7 +45,7 @@ hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
     const long cap = 256L * blocks_per_cu;
     int grid = (int)(ntiles < cap ? ntiles : cap);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FPP_THREADS), shmem, io.stream, A, io.ro, io.idx, io.out, io.uidx, io.absorbed);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FPP_THREADS), shmem, io.stream, B, io.ro, io.idx, io.out, io.uidx, io.absorbed);
     return hipGetLastError();
 }
 

@@ -153,26 +153,30 @@ __device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
 // cooperative global -> LDS copy of one core with the padded node stride
 __device__ inline void stage_core_n(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride, int nthreads)
 {
-    // dst index = e + (e / elems) * (stride - elems), kept incrementally (no integer division per element).
-    // Full trips first (every thread in range), then one tail trip in which the threads past the end repeat the
-    // last element (same value to the same slot): no lane-divergent branch or loop exit.
-    const int total = n_nodes * elems, pad = stride - elems;
-    int j = (int)threadIdx.x / elems, w = (int)threadIdx.x - j * elems;
-    const int dj = nthreads / elems, dw = nthreads - dj * elems;
-    const int full = total / nthreads;
-    int e = threadIdx.x;
-#pragma unroll 4
-    for (int it = 0; it < full; it++) {
-        sK[e + j * pad] = src[e];
-        e += nthreads;
-        j += dj;
-        w += dw;
-        if (w >= elems) { w -= elems; j++; }
-    }
-    if (full * nthreads < total) {
-        const bool in = e < total;
-        const int ee = in ? e : total - 1, jj = in ? j : (total - 1) / elems;
-        sK[ee + jj * pad] = src[ee];
+    // The copy is pure latency (33 KB from L2 per core and tile): every thread moves PAIRS of doubles (16-byte
+    // loads; elems is even, so a pair never straddles two nodes) and keeps a batch of 8 loads in flight before
+    // the first LDS write.  dst index of element e = e + (e / elems) * (stride - elems).  Trip counts are the same
+    // for every thread; past the end a thread repeats the last pair (same values to the same slots): no
+    // lane-divergent branch or loop exit.
+    const int pairs = (n_nodes * elems) >> 1, pad = stride - elems;
+    constexpr int B = 8;
+    const int per_batch = B * nthreads;
+    for (int base = 0; base < pairs; base += per_batch) {
+        double2 buf[B];
+        int pe[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int p = base + q * nthreads + (int)threadIdx.x;
+            pe[q] = 2 * (p < pairs ? p : pairs - 1);
+            buf[q] = *reinterpret_cast<const double2 *>(src + pe[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int node = pe[q] / elems; // elems is a small wave-uniform value: one multiply-high
+            double *d = sK + pe[q] + node * pad;
+            d[0] = buf[q].x;
+            d[1] = buf[q].y;
+        }
     }
 }
 

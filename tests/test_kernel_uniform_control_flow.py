@@ -23,16 +23,23 @@ def test_no_lane_divergent_control_flow(tmp_path, src, kernel):
     subprocess.run([HIPCC, "-std=c++20", "-O3", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
                     "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)], check=True, cwd=CSRC,
                    stderr=subprocess.DEVNULL)
-    name, sites, seen = None, 0, 0
+    name, seen = None, 0
+    body = []
     for line in open(out):
         m = re.match(r"^(_ZN4c3sc\d+%s\S*):" % kernel, line)
         if m:
-            name, sites = m.group(1), 0
-        elif name and EXEC_WRITE.search(line):
-            sites += 1
+            name, body = m.group(1), []
         elif name and line.startswith(".Lfunc_end"):
-            # epilogue: `if (st) atomicOr(status, st)` = one saveexec + one single-lane mask
-            assert sites <= 2, f"{name}: {sites} writes to EXEC -- lane-divergent control flow crept in"
+            # the only EXEC writes allowed belong to the epilogue `if (st) atomicOr(status, st)`: a saveexec + a
+            # single-lane mask right before global_atomic_or / s_endpgm (the block may be tail-duplicated and placed
+            # anywhere in the listing)
+            bad = []
+            for i, l in enumerate(body):
+                if EXEC_WRITE.search(l) and not any("global_atomic_or" in t or "s_endpgm" in t for t in body[i:i + 24]):
+                    bad.append(i)
+            assert not bad, f"{name}: {len(bad)} writes to EXEC outside the epilogue -- lane-divergent control flow crept in"
             seen += 1
             name = None
+        elif name:
+            body.append(line)
     assert seen > 0

@@ -514,7 +514,10 @@ static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
-    HIPCHK(c, e->fn(A, io));
+    const hipError_t he = e->fn(A, io);
+    if (he == hipErrorOutOfMemory)
+        return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: N x rank^2 of the varying core exceeds the 160 KB of LDS the per-wave kernel stages it in");
+    HIPCHK(c, he);
     return C3SC_OK;
 }
 

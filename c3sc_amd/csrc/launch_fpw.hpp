@@ -15,6 +15,7 @@ hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
     constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL;
     const bool kedge = (A.k == 0) || (A.k == D - 1);
     const size_t shmem = (size_t)(4 * WS + A.N * kcore_stride(RP, kedge)) * sizeof(double);
+    if (shmem > 160u * 1024u) return hipErrorOutOfMemory; // the varying core (N x RP^2) must fit the CU's LDS
     auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL, BOX>;
     static int blocks_per_cu = 0;
     static size_t attr_shmem = 0, occ_shmem = (size_t)-1;

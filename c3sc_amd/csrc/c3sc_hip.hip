@@ -497,7 +497,12 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
     A.status = c->d_status;
     if (!c->d_dbg) { HIPCHK(c, hipMalloc((void **)&c->d_dbg, 65536 * 8 * sizeof(unsigned long long))); }
     A.dbgbuf = c->d_dbg;
-    { const char *e = getenv("C3SC_DBG"); A.dbg = e ? atoi(e) : 0; if (A.dbg & 8) A.ncand = 1; if (A.dbg & 16) A.ncand = 3; }
+    { // ablation switches of the diagnostic build (make STAMPS=1); read once
+        static const int dbg_env = [] { const char *e = getenv("C3SC_DBG"); return e ? atoi(e) : 0; }();
+        A.dbg = dbg_env;
+        if (A.dbg & 8) A.ncand = 1;
+        if (A.dbg & 16) A.ncand = 3;
+    }
     return C3SC_OK;
 }
 

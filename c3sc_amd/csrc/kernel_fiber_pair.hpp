@@ -28,9 +28,6 @@
 #ifndef FPP_NV
 #define FPP_NV 4 // vectors per pass over a staged matrix in the folding phase (2: 0.361 ms, 3: 0.343, 4: 0.340 on car7d)
 #endif
-#ifndef FPP_ROWPIPE
-#define FPP_ROWPIPE 0
-#endif
 
 namespace c3sc {
 
@@ -357,13 +354,12 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             } else {
                 // This wave's rows of G_K[j]: c_h[i] = sum_b G[hi, b] R[b] reads row hi of the row-major copy,
                 // a_h[i] = sum_a L[a] G[a, hi] reads column hi of the column-major one; either is RP contiguous
-                // doubles on the scalar path.  The rows are walked one at a time with the next row's s_load in
-                // flight (volatile asm keeps that order): left to itself the compiler issues every s_load of the
-                // node first and spills the SGPR tuples to VGPR lanes (v_writelane / v_readlane storms).
+                // doubles on the scalar path.  (Walking the rows one at a time with the next row's s_load in flight
+                // was tried: SMEM returns out of order, every wait is lgkmcnt(0), and ten short waits lose to the
+                // compiler's bulk issue -- 0.381 vs 0.363 ms.)
                 const double *GT = ro + A.coreT_off[K] + (size_t)j * RP * RP + (size_t)H * RH * RP;
                 const double *GC = Gk + (size_t)j * RP * RP + (size_t)H * RH * RP;
                 double ch[RH], ah[RH];
-#if FPP_ROWPIPE == 0
 #pragma unroll
                 for (int i = 0; i < RH; i++) { ch[i] = 0.0; ah[i] = 0.0; }
 #pragma unroll
@@ -378,50 +374,6 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
 #pragma unroll
                     for (int i = 0; i < RH; i++) ah[i] = fma(la, GC[a + i * RP], ah[i]);
                 }
-#else
-                double cur[RP], nxt[RP], vec[RP];
-                {
-                    int o = 0; // an opaque OFFSET orders the loads; laundering the pointer would lose `ro`'s noalias
-                    asm volatile("" : "+s"(o));
-#pragma unroll
-                    for (int b = 0; b < RP; b++) cur[b] = GT[o + b];
-                }
-#pragma unroll
-                for (int b = 0; b < RP; b++) vec[b] = sR[b * 64 + lane];
-#pragma unroll
-                for (int k = 0; k < 2 * RH; k++) {
-                    const int i = k < RH ? k : k - RH;
-                    if (k + 1 < 2 * RH) {
-                        int o = (k + 1 < RH) ? (k + 1) * RP : (k + 1 - RH) * RP;
-                        asm volatile("" : "+s"(o));
-                        const double *p = (k + 1 < RH) ? GT : GC;
-#pragma unroll
-                        for (int b = 0; b < RP; b++) nxt[b] = p[o + b];
-                    }
-                    if (k == RH) {
-#pragma unroll
-                        for (int a = 0; a < RP; a++) vec[a] = sL[a * 64 + lane];
-                    }
-                    double e = 0.0, o = 0.0; // two chains per row
-#pragma unroll
-                    for (int b = 0; b < RP; b += 2) {
-                        e = fma(cur[b], vec[b], e);
-                        if (b + 1 < RP) o = fma(cur[b + 1], vec[b + 1], o);
-                    }
-                    const double r = e + o;
-                    if (k < RH) ch[i] = r;
-                    else ah[i] = r;
-                    if (k + 1 < 2 * RH) {
-#pragma unroll
-                        for (int b = 0; b < RP; b++) {
-                            asm volatile("" : "+s"(nxt[b]));
-                            cur[b] = nxt[b];
-                        }
-                    }
-                    if (k < RH) pin_vgpr(ch[i]);
-                    else pin_vgpr(ah[i]);
-                }
-#endif
                 double v = 0.0;
 #pragma unroll
                 for (int i = 0; i < RH; i++) v = fma(sL[(H * RH + i) * 64 + lane], ch[i], v);

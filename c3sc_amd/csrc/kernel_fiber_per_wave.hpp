@@ -68,7 +68,7 @@ __host__ __device__ constexpr int kcore_stride(int rp, bool edge) { return (edge
 
 // (256, 2): two workgroups per CU = 2 waves per SIMD, i.e. at most 256 registers per lane; without the bound the
 // rank-16 instantiations take 256 + a few AGPRs and drop to one wave per SIMD (quad10d: 9.7e8 -> 7.0e8 nodes/s)
-template <class Model, int RP, int NPL, bool STENCIL, bool BOX = false>
+template <class Model, int RP, int NPL, bool STENCIL, bool BOX = false, bool STAGED = true>
 __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bound to one workgroup per CU anyway
     k_fiber_per_wave(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
                      int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed, const int32_t *__restrict__ nbf,
@@ -90,8 +90,10 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
     const int kstr = kcore_stride(RP, kedge);
     const int kelems = kedge ? RP : RP * RP;
 
-    // ---- stage core k (shared by every fiber of this launch) into LDS, coalesced
-    {
+    // ---- stage core k (shared by every fiber of this launch) into LDS, coalesced.  STAGED = false: the core is too
+    // large for the CU's LDS (N x RP^2 doubles, e.g. rank 20 on a 100-node dimension); every lane then reads its own
+    // node's matrix from global memory (L2-resident), the rest of the kernel is unchanged.
+    if constexpr (STAGED) {
         const double *src = ro + A.core_off[k];
         const int total = N * kelems;
         for (int e = threadIdx.x; e < total; e += blockDim.x) {
@@ -196,7 +198,9 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
         for (int q = 0; q < NPL; q++) {
             const int j = lane + 64 * q;
             const int jj = j < N ? j : N - 1; // clamp idle lanes onto a valid node
-            const double *g = sK + jj * kstr;
+            const double *g;
+            if constexpr (STAGED) g = sK + jj * kstr;
+            else g = ro + A.core_off[k] + (size_t)jj * kelems;
             if (k == 0) { // first core: 1 x r row
                 double v = 0.0;
 #pragma unroll

@@ -7,16 +7,14 @@ namespace c3sc {
 
 constexpr int NUM_CU = 256; // MI355X
 
-template <class Model, int RP, int NPL, bool STENCIL, bool BOX = false>
-hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
+template <class Model, int RP, int NPL, bool STENCIL, bool BOX, bool STAGED>
+hipError_t launch_fpw_impl(const KArgs &A, const LaunchIO &io)
 {
-    if (A.cmode == 1 && !BOX) return hipErrorNotSupported; // this entry has no box-minimiser instantiation
     constexpr int D = Model::D;
     constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL;
     const bool kedge = (A.k == 0) || (A.k == D - 1);
-    const size_t shmem = (size_t)(4 * WS + A.N * kcore_stride(RP, kedge)) * sizeof(double);
-    if (shmem > 160u * 1024u) return hipErrorOutOfMemory; // the varying core (N x RP^2) must fit the CU's LDS
-    auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL, BOX>;
+    const size_t shmem = (size_t)(4 * WS + (STAGED ? A.N * kcore_stride(RP, kedge) : 0)) * sizeof(double);
+    auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL, BOX, STAGED>;
     static int blocks_per_cu = 0;
     static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
     hipError_t e;
@@ -39,6 +37,20 @@ hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, io.stream, A, io.ro, io.idx, io.out, io.uidx, io.absorbed,
                        io.nbf, io.nbv, io.tbl, io.tcost);
     return hipGetLastError();
+}
+
+template <class Model, int RP, int NPL, bool STENCIL, bool BOX = false>
+hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
+{
+    if (A.cmode == 1 && !BOX) return hipErrorNotSupported; // this entry has no box-minimiser instantiation
+    constexpr int D = Model::D;
+    constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL;
+    const bool kedge = (A.k == 0) || (A.k == D - 1);
+    const size_t staged = (size_t)(4 * WS + A.N * kcore_stride(RP, kedge)) * sizeof(double);
+    // the varying core (N x RP^2 doubles) is staged in LDS when it fits the CU, otherwise read from L2
+    if (staged <= 160u * 1024u) return launch_fpw_impl<Model, RP, NPL, STENCIL, BOX, true>(A, io);
+    if constexpr (RP >= 12) return launch_fpw_impl<Model, RP, NPL, STENCIL, BOX, false>(A, io);
+    else return hipErrorOutOfMemory; // small ranks always fit for N <= 128
 }
 
 #define C3SC_CAT2(a, b) a##b

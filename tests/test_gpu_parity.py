@@ -339,3 +339,24 @@ def test_edge_cases_empty_batch_max_rank_max_nodes(oracle):
             idx[0, :] = 0
             idx[1, :] = np.array(w2.ngrid) - 1
             _check(eng2, P2, w2, k, idx)
+
+
+def test_large_core_not_staged_in_lds(oracle):
+    """Rank 20 on a 100-node dimension (the reference's own regression size, tprob_test.c:2284,2310): N x RP^2 doubles
+    exceed the CU's LDS, the per-wave kernel then reads each node's matrix from L2 instead of staging the core."""
+    w = wl.c1_lqg2d().scaled(ngrid=(100, 100), rank=20)
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    eng = _engine(w, cores)
+    for k in range(2):
+        idx = wl.synth_fibers(w, k, 11)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        _check(eng, P, w, k, idx)
+        assert "fiber_per_wave" in eng.last_kernel()
+    w3 = wl.c2_dubins().scaled(ngrid=(101, 33, 101), rank=16)
+    cores3 = wl.synth_cores(w3)
+    P3 = oracle.Problem(w3, cores3)
+    eng3 = _engine(w3, cores3)
+    for k in (0, 1, 2):
+        _check(eng3, P3, w3, k, wl.synth_fibers(w3, k, 9))

@@ -185,6 +185,25 @@ def test_golden_fixture_car7d(oracle):
         assert np.abs(out - ref).max() <= REL_TOL * np.abs(ref).max()
 
 
+def test_golden_fixture_policy_evaluation():
+    """Committed golden vectors for bellman_pi (tests/golden/pi_dubins_small.npz, tests/make_golden.py): the policy's
+    candidate indices and the evaluated right-hand side on a second value function, without the oracle in the loop."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pi_dubins_small.npz"))
+    w = wl.c2_dubins().scaled(ngrid=tuple(int(n) for n in g["ngrid"]), rank=int(g["rank"]))
+    eng_pol = _engine(w, wl.synth_cores(w))
+    eng_it = _engine(w, wl.smooth_cores(w))
+    for k in range(w.dx):
+        idx, pol = g[f"idx{k}"], g[f"policy{k}"]
+        _, ui, ab = eng_pol.bellman_fibers_host(k, idx)
+        np.testing.assert_array_equal(ab, g[f"ab{k}"])
+        np.testing.assert_array_equal(ui, pol)  # three well-separated candidates: no ties on this fixture
+        out, _ = eng_it.policy_fibers_host(k, idx, pol)
+        ref = g[f"out{k}"]
+        assert np.abs(out - ref).max() <= REL_TOL * np.abs(ref).max()
+
+
 def test_full_size_properties():
     """BASELINE full size (car7d N=41 r=10): size-independent properties instead of the oracle.
     (1) absorbed nodes return exactly the boundary / obstacle cost; (2) a batch equals the

@@ -135,13 +135,23 @@ static int fail(c3sc_hip_ctx *ctx, int code, const char *msg)
 // Host companions of the device models (models.hpp): the univariate functions of a grid coordinate and of
 // a control candidate are evaluated HERE with libm, exactly as the reference's callbacks would
 // (dubinscar.c:48-49, scar.c:65-67), and handed to the kernels as tables.
-static int model_ntab(int model) { return model == C3SC_MODEL_DUBINS3D || model == C3SC_MODEL_SCAR4D ? 2 : (model == C3SC_MODEL_CAR7D ? 3 : 0); }
-static int model_tab_dim(int model, int t) { return (model == C3SC_MODEL_CAR7D && t == 2) ? 5 : 2; }
+// Besides the trigonometric tables, any other expensive univariate function of a grid coordinate is tabulated
+// here with the host's IEEE arithmetic (correctly rounded division, the same result the device's division sequence
+// gives): the car models' speed factor v / (0.2 (1 + v/8)) costs a ~15-instruction dependent chain per node otherwise.
+static int model_ntab(int model) { return model == C3SC_MODEL_DUBINS3D ? 2 : (model == C3SC_MODEL_SCAR4D ? 3 : (model == C3SC_MODEL_CAR7D ? 4 : 0)); }
+static int model_tab_dim(int model, int t)
+{
+    if (model == C3SC_MODEL_CAR7D) return t == 2 ? 5 : (t == 3 ? 3 : 2);
+    if (model == C3SC_MODEL_SCAR4D) return t == 2 ? 3 : 2;
+    return 2;
+}
 static double model_table_value(int model, int t, double xv)
 {
-    (void)model;
     if (t == 0) return cos(xv);
     if (t == 1) return sin(xv);
+    if (model == C3SC_MODEL_CAR7D && t == 2) return tan(xv);
+    if (model == C3SC_MODEL_CAR7D && t == 3) return xv / (0.2 * (1.0 + xv / 8.0));
+    if (model == C3SC_MODEL_SCAR4D && t == 2) return (1.0 / (1.0 + (xv / 8.0))) * (xv / 0.2); /* scar.c:68-71 with L = 0.2, vcar = 8 */
     return tan(xv);
 }
 static int model_ncf(int model) { return model == C3SC_MODEL_SCAR4D ? 1 : 0; }

@@ -62,17 +62,16 @@ struct Dubins3D {
 struct Scar4D {
     static constexpr bool IS_TABLE = false;
     static constexpr int D = 4, DU = 2;
-    static constexpr int NTAB = 2, NCF = 1; // tables: cos(x2), sin(x2); candidate feature: tan(u0)
+    static constexpr int NTAB = 3, NCF = 1; // tables: cos(x2), sin(x2), speed factor of x3; candidate feature: tan(u0)
     static constexpr unsigned UDEP_MASK = (1u << 2) | (1u << 3);
     static constexpr unsigned UCONST_MASK = 1u << 3; // b[2] also depends on the speed
     static constexpr bool STAGE_UDEP = false;
-    __host__ __device__ static constexpr int tab_dim(int) { return 2; }
+    __host__ __device__ static constexpr int tab_dim(int t) { return t == 2 ? 3 : 2; }
     struct Node { double vc, vs, pre; };
-    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[2], Node &n)
+    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[3], Node &n)
     {
         const double speed = x[3];
-        const double L = 0.2, vcar = 8.0;
-        n.pre = (1.0 / (1.0 + (speed / vcar))) * (speed / L);
+        n.pre = tv[2]; // (1 / (1 + speed/vcar)) * (speed / L), L = 0.2, vcar = 8: tabulated over dim 3 on the host
         n.vc = speed * tv[0];
         n.vs = speed * tv[1];
     }
@@ -97,18 +96,18 @@ struct Scar4D {
 struct Car7D {
     static constexpr bool IS_TABLE = false;
     static constexpr int D = 7, DU = 2;
-    static constexpr int NTAB = 3, NCF = 0; // tables: cos(x2), sin(x2), tan(x5)
+    static constexpr int NTAB = 4, NCF = 0; // tables: cos(x2), sin(x2), tan(x5), v / (0.2 (1 + v/8)) over x3
     static constexpr unsigned UDEP_MASK = (1u << 5) | (1u << 6);
     static constexpr unsigned UCONST_MASK = UDEP_MASK;
     static constexpr bool STAGE_UDEP = false;
-    __host__ __device__ static constexpr int tab_dim(int t) { return t == 2 ? 5 : 2; }
+    __host__ __device__ static constexpr int tab_dim(int t) { return t == 2 ? 5 : (t == 3 ? 3 : 2); }
     struct Node { double b0, b1, b4; };
-    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[3], Node &n)
+    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[4], Node &n)
     {
         const double v = x[3], om = x[4];
         n.b0 = v * tv[0];
         n.b1 = v * tv[1];
-        n.b4 = (v / (0.2 * (1.0 + v / 8.0)) * tv[2] - om) / 0.5;
+        n.b4 = (tv[3] * tv[2] - om) / 0.5; // tv[3] = v / (0.2 (1 + v/8)), tabulated on the host
     }
     __device__ static inline void drift(const double *, const Node &n, const double (&x)[D], const double *u, const double *,
                                         double (&b)[D])

@@ -630,8 +630,15 @@ static double *fibers_x_from_idx(const struct MCAparam *mca, size_t F, size_t k,
 
 /* bellman.c:1295-1423 for F fibers along dim k0 given by their grid indices: memo per node, every fiber with a
  * missing node in ONE launch.  fast = 0: the reference's string-keyed table; fast = 1: its integer-keyed twin. */
+/* C3SC_PROFILE=1: where a sweep's host time goes (printed by c3control_end_vi) */
+#include <time.h>
+static double g_t_lookup, g_t_device, g_t_store;
+static size_t g_n_calls;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, const double *x_in, double *out, int fast)
 {
+    const double t_begin = now_s();
     struct ControlParams *cp = vi->cp;
     struct MCAparam *mca = cp->mca;
     const size_t dx = mca->dx, N = mca->ngrid[k0];
@@ -668,10 +675,16 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
     /* compact the fibers that still need work and run them in one launch */
     size_t nrun = 0;
     for (size_t f = 0; f < F; f++) nrun += need[f];
+    const double t_looked = now_s();
+    g_t_lookup += t_looked - t_begin;
+    g_n_calls++;
     if (nrun > 0) {
         int32_t *ridx = xcalloc(nrun * dx, sizeof(int32_t));
         double *rout = xcalloc(nrun * N, sizeof(double));
-        int32_t *rabs = xcalloc(nrun * N, sizeof(int32_t));
+        /* absorbed flags travel back only while the first-fiber cross-check is still pending */
+        const int want_abs = dp_has_device_model(cp->dp) && !cp->dp->model_checked && cp->dp->stagecost != NULL &&
+                             cp->dp->boundcost != NULL && cp->dp->obscost != NULL;
+        int32_t *rabs = want_abs ? xcalloc(nrun * N, sizeof(int32_t)) : NULL;
         size_t r = 0;
         for (size_t f = 0; f < F; f++)
             if (need[f]) memcpy(ridx + (r++) * dx, idx + f * dx, dx * sizeof(int32_t));
@@ -701,10 +714,12 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
         unsigned st = 0;
         hipok(ctx, c3sc_hip_get_status(ctx, &st, 1), "c3sc_hip_get_status");
         if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+        const double t_dev = now_s();
+        g_t_device += t_dev - t_looked;
         r = 0;
         for (size_t f = 0; f < F; f++) {
             if (!need[f]) continue;
-            if (r == 0 && dp_has_device_model(cp->dp) && x != NULL) cross_check_model(vi, ctx, k0, ridx, N, x + f * N * dx, rout, rabs);
+            if (r == 0 && want_abs && x != NULL) cross_check_model(vi, ctx, k0, ridx, N, x + f * N * dx, rout, rabs);
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
             ser[dx] = 0;
             ser[dx + 1] = vi_iter;
@@ -725,6 +740,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
             r++;
         }
         free(ridx); free(rout); free(rabs); free(x_own);
+        g_t_store += now_s() - t_dev;
     }
     free(need); free(hit);
     return 0;
@@ -1072,6 +1088,11 @@ void c3control_end_pi_step(struct C3Control *c, struct PIparam *pi, size_t *nite
 
 void c3control_end_vi(struct C3Control *c, struct VIparam *vi, size_t *nevals)
 {
+    if (getenv("C3SC_PROFILE")) {
+        fprintf(stderr, "c3sc profile: %zu batch calls, memo lookup %.2f ms, device calls %.2f ms, memo store %.2f ms\n", g_n_calls,
+                1e3 * g_t_lookup, 1e3 * g_t_device, 1e3 * g_t_store);
+        g_n_calls = 0; g_t_lookup = g_t_device = g_t_store = 0.0;
+    }
     if (nevals) *nevals = vi->nnode_evals;
     vi_param_destroy(vi);
     control_params_destroy(c->cp_active);

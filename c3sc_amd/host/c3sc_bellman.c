@@ -135,6 +135,12 @@ double valuef_eval_ind(struct ValueF *vf, const size_t *ind)
     return out;
 }
 
+void c3sc_forget_ctx(struct c3sc_hip_ctx *ctx)
+{ /* called before a context is destroyed: a later context at the same address must not inherit its bookkeeping */
+    for (int i = 0; i < MAX_TRACKED_CTX; i++)
+        if (g_ctx[i].ctx == ctx) { g_ctx[i].ctx = NULL; g_ctx[i].version = 0; g_ctx[i].cfg_set = 0; }
+}
+
 void valuef_bind_device(struct ValueF *vf, struct c3sc_hip_ctx *ctx)
 {
     vf->bound = ctx;

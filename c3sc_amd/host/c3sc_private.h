@@ -24,6 +24,7 @@ struct ValueF {
     unsigned long version;       /* bumps on every construction: identifies an upload */
     struct c3sc_hip_ctx *bound;  /* device context the cores were uploaded to */
 };
+void c3sc_forget_ctx(struct c3sc_hip_ctx *ctx);
 void valuef_set_cross_indices(struct ValueF *vf, const size_t *nisl, int *const *isl, const size_t *nisr, int *const *isr);
 void valuef_free_cross_indices(struct ValueF *vf);
 #endif

@@ -11,6 +11,7 @@
 
 #include "c3sc/c3sc.h"
 #include "c3sc_hip.h"
+#include "c3sc_private.h"
 
 static void *xmalloc(size_t n)
 {
@@ -492,10 +493,10 @@ void workspace_free(struct Workspace *w)
     free(w->keys2);
     htable_destroy(w->pi_prob_htable); htable_destroy(w->pi_htable);
     fastmemo_free(w->vi_fast); fastmemo_free(w->pi_prob_fast);
-    if (w->hip_policy) c3sc_hip_ctx_destroy(w->hip_policy);
+    if (w->hip_policy) { c3sc_forget_ctx(w->hip_policy); c3sc_hip_ctx_destroy(w->hip_policy); }
     free(w->keys); free(w->slab); free(w->costs); free(w->absorbed); free(w->ind_to_serialize);
     htable_destroy(w->vi_htable);
-    if (w->hip) c3sc_hip_ctx_destroy(w->hip);
+    if (w->hip) { c3sc_forget_ctx(w->hip); c3sc_hip_ctx_destroy(w->hip); }
     free(w);
 }
 

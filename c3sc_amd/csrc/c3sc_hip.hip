@@ -27,16 +27,15 @@ std::vector<KernelEntry> &kernel_registry()
 // into the rank-padded device layout: first core [N][RP] (index b), last core [N][RP] (index a),
 // middle cores [N][RP*RP] (a + b*RP); padding entries are zero, which leaves every contraction exact.
 __global__ void k_pad_core(const double *__restrict__ src, double *__restrict__ dst, int N, int r0, int r1, int RP,
-                           int kind /*0 first, 1 middle, 2 last, 3 middle row-major (a*RP + b)*/)
+                           int kind /*0 first, 1 middle, 2 last*/)
 {
-    const int per = (kind == 1 || kind == 3) ? RP * RP : RP;
+    const int per = (kind == 1) ? RP * RP : RP;
     const long total = (long)N * per;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int j = (int)(e / per), w = (int)(e - (long)j * per);
         int a, b;
         if (kind == 0) { a = 0; b = w; }
         else if (kind == 2) { a = w; b = 0; }
-        else if (kind == 3) { a = w / RP; b = w % RP; }
         else { a = w % RP; b = w / RP; }
         double v = 0.0;
         if (a < r0 && b < r1) v = src[(size_t)j * r0 * r1 + a + (size_t)b * r0];
@@ -105,7 +104,6 @@ struct c3sc_hip_ctx {
     size_t static_doubles = 0; // size of the static section the arena was laid out with
     bool static_dirty = true;
     long core_off[MAXD] = {0};
-    long coreT_off[MAXD] = {0};
     int obs_off = 0, cands_off = 0, tab_off[4] = {0, 0, 0, 0}, cfeat_off = 0;
     unsigned *d_status = nullptr;
     unsigned long long *d_dbg = nullptr; // diagnostic stamps (C3SC_DBG & 128)
@@ -389,15 +387,11 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
     HIPCHK(c, hipSetDevice(c->device));
     const size_t stat = static_layout(c);
     size_t off = stat;
-    long core_off[MAXD], coreT_off[MAXD];
+    long core_off[MAXD];
     for (int m = 0; m < d; m++) {
         core_off[m] = (long)off;
         const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
         off += ((size_t)c->ngrid[m] * per + 15) & ~(size_t)15;
-    }
-    for (int m = 0; m < d; m++) { // row-major copies of the middle cores
-        coreT_off[m] = (long)off;
-        if (m != 0 && m != d - 1) off += ((size_t)c->ngrid[m] * rp * rp + 15) & ~(size_t)15;
     }
     if (off > c->arena_cap) {
         if (c->arena) HIPCHK(c, hipFree(c->arena));
@@ -409,7 +403,7 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
     }
     if (stat != c->static_doubles) c->static_dirty = true;
     c->static_doubles = stat;
-    for (int m = 0; m < d; m++) { c->core_off[m] = core_off[m]; c->coreT_off[m] = coreT_off[m]; }
+    for (int m = 0; m < d; m++) c->core_off[m] = core_off[m];
     for (int m = 0; m <= d; m++) c->ranks[m] = ranks[m];
     c->rp = rp;
     *cores_doubles = off - stat;
@@ -427,7 +421,6 @@ int c3sc_hip_upload_value(c3sc_hip_ctx *c, const size_t *ranks, const double *co
     for (int m = 0; m < d; m++) {
         const size_t r0 = ranks[m], r1 = ranks[m + 1];
         double *dst = buf.data() + (c->core_off[m] - (long)c->static_doubles);
-        double *dstT = buf.data() + (c->coreT_off[m] - (long)c->static_doubles);
         const double *src = cores[m];
         const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
         for (int j = 0; j < c->ngrid[m]; j++)
@@ -439,7 +432,6 @@ int c3sc_hip_upload_value(c3sc_hip_ctx *c, const size_t *ranks, const double *co
                     else if (m == d - 1) w = a;
                     else w = a + b * rp;
                     dst[(size_t)j * per + w] = v;
-                    if (m != 0 && m != d - 1) dstT[(size_t)j * per + a * rp + b] = v;
                 }
     }
     HIPCHK(c, hipMemcpy(c->arena + c->static_doubles, buf.data(), cd * sizeof(double), hipMemcpyHostToDevice));
@@ -459,9 +451,6 @@ int c3sc_hip_upload_value_device(c3sc_hip_ctx *c, const size_t *ranks, const dou
         const int grid = (int)std::min<long>((total + 255) / 256, 1024);
         hipLaunchKernelGGL(k_pad_core, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_cores[m], c->arena + c->core_off[m],
                            c->ngrid[m], (int)ranks[m], (int)ranks[m + 1], rp, kind);
-        if (kind == 1)
-            hipLaunchKernelGGL(k_pad_core, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_cores[m], c->arena + c->coreT_off[m],
-                               c->ngrid[m], (int)ranks[m], (int)ranks[m + 1], rp, 3);
     }
     HIPCHK(c, hipGetLastError());
     c->have_value = true;
@@ -493,7 +482,6 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
         A.bctype[m] = c->bctype[m];
         A.xg_off[m] = c->xg_off_rel[m];
         A.core_off[m] = c->core_off[m];
-        A.coreT_off[m] = c->coreT_off[m];
     }
     A.nobs = c->nobs;
     A.obs_off = c->obs_off;

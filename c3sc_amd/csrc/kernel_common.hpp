@@ -27,7 +27,6 @@ struct KArgs {
     // parameter, so that the compiler may keep wave-uniform reads on the scalar (SGPR) path
     int xg_off[MAXD];    // xgrid[m][0..N_m)
     long core_off[MAXD]; // rank-padded cores, see k_pad_core
-    long coreT_off[MAXD]; // middle cores once more, row-major ([N][a*RP + b]): rows are contiguous for scalar loads
     int nobs;
     int obs_off; // [nobs][2][d]: lb row then ub row per obstacle
     int cands_off; // [ncand][DU]

@@ -352,13 +352,14 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
 #pragma unroll
                 for (int g = 0; g < NV; g++) sink(g, dot_reg<RH>(Wh[g], ch));
             } else {
-                // This wave's rows of G_K[j]: c_h[i] = sum_b G[hi, b] R[b] reads row hi of the row-major copy,
-                // a_h[i] = sum_a L[a] G[a, hi] reads column hi of the column-major one; either is RP contiguous
-                // doubles on the scalar path.  (Walking the rows one at a time with the next row's s_load in flight
-                // was tried: SMEM returns out of order, every wait is lgkmcnt(0), and ten short waits lose to the
-                // compiler's bulk issue -- 0.381 vs 0.363 ms.)
-                const double *GT = ro + A.coreT_off[K] + (size_t)j * RP * RP + (size_t)H * RH * RP;
-                const double *GC = Gk + (size_t)j * RP * RP + (size_t)H * RH * RP;
+                // This wave's rows / columns of G_K[j] on the scalar path: c_h[i] = sum_b G[hi, b] R[b] (stride RP),
+                // a_h[i] = sum_a L[a] G[a, hi] (contiguous).  A second, row-major copy of the core made the c-part
+                // contiguous too and was 2.5 % faster in isolation, but it doubles what a workgroup pulls through the
+                // 16 KB scalar cache (28 % of the requests missed or waited on a miss): without it 0.299 -> 0.282 ms.
+                // (Walking the rows one at a time with the next row's s_load in flight was tried as well: SMEM
+                // returns out of order, every wait is lgkmcnt(0), ten short waits lose to the compiler's bulk issue.)
+                const double *GC0 = Gk + (size_t)j * RP * RP;
+                const double *GC = GC0 + (size_t)H * RH * RP;
                 double ch[RH], ah[RH];
 #pragma unroll
                 for (int i = 0; i < RH; i++) { ch[i] = 0.0; ah[i] = 0.0; }
@@ -366,7 +367,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 for (int b = 0; b < RP; b++) {
                     const double rb = sR[b * 64 + lane];
 #pragma unroll
-                    for (int i = 0; i < RH; i++) ch[i] = fma(GT[i * RP + b], rb, ch[i]);
+                    for (int i = 0; i < RH; i++) ch[i] = fma(GC0[H * RH + i + b * RP], rb, ch[i]);
                 }
 #pragma unroll
                 for (int a = 0; a < RP; a++) {

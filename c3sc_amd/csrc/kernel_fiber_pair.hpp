@@ -25,6 +25,9 @@
 #ifndef FPP_CGD
 #define FPP_CGD 3
 #endif
+#ifndef FPP_PIPE2
+#define FPP_PIPE2 1
+#endif
 #ifndef FPP_NV
 #define FPP_NV 4 // vectors per pass over a staged matrix in the folding phase (2: 0.361 ms, 3: 0.343, 4: 0.340 on car7d)
 #endif
@@ -390,6 +393,87 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         auto to_lds = [&](double *dst) __attribute__((always_inline)) {
             return [dst, lane](int g, double v) __attribute__((always_inline)) { dst[g * 64 + lane] = v; };
         };
+        // The same for a middle core in two halves, so that two nodes can be software-pipelined: the scalar loads and
+        // FMAs of the second node's (c, a) are in the instruction stream BEFORE the register-only dots of the first
+        // node, which then cover the scalar-memory latency.
+        auto ca_part = [&](int j, double (&ch)[RH], double (&ah)[RH], auto &&filler) __attribute__((always_inline)) {
+            // Scalar loads return out of order, so every wait on one is lgkmcnt(0): nothing can stay in flight across a
+            // wait.  Left alone the compiler loads just in time and waits ~8 times per node; here the 75 values a wave
+            // needs are fetched in four batches of <= 25 doubles (50 SGPRs), each issued back to back and waited for once.
+            const double *GC0 = Gk + (size_t)j * RP * RP;
+            const double *GC = GC0 + (size_t)H * RH * RP;
+#pragma unroll
+            for (int i = 0; i < RH; i++) { ch[i] = 0.0; ah[i] = 0.0; }
+            constexpr int BH = (RP + 1) / 2; // columns per batch
+            double vec[RP]; // R, then L: read from LDS ahead of the scalar batch so that one wait covers both
+#pragma unroll
+            for (int b = 0; b < RP; b++) vec[b] = sR[b * 64 + lane];
+#pragma unroll
+            for (int b0 = 0; b0 < RP; b0 += BH) {
+                double g[BH][RH];
+#pragma unroll
+                for (int b = 0; b < BH; b++)
+#pragma unroll
+                    for (int i = 0; i < RH; i++) g[b][i] = (b0 + b < RP) ? GC0[H * RH + i + (b0 + b) * RP] : 0.0;
+                __builtin_amdgcn_sched_barrier(0); // loads stay above, the filler (register-only work) below
+                filler(b0 / BH);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < BH; b++)
+#pragma unroll
+                    for (int i = 0; i < RH; i++) asm volatile("" : "+s"(g[b][i]));
+#pragma unroll
+                for (int b = 0; b < BH; b++) {
+                    if (b0 + b < RP) {
+                        const double rb = vec[b0 + b];
+#pragma unroll
+                        for (int i = 0; i < RH; i++) ch[i] = fma(g[b][i], rb, ch[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < RP; a++) vec[a] = sL[a * 64 + lane];
+#pragma unroll
+            for (int a0 = 0; a0 < RP; a0 += BH) {
+                double g[RH][BH];
+#pragma unroll
+                for (int i = 0; i < RH; i++)
+#pragma unroll
+                    for (int a = 0; a < BH; a++) g[i][a] = (a0 + a < RP) ? GC[a0 + a + i * RP] : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+                filler(2 + a0 / BH);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RH; i++)
+#pragma unroll
+                    for (int a = 0; a < BH; a++) asm volatile("" : "+s"(g[i][a]));
+#pragma unroll
+                for (int a = 0; a < BH; a++) {
+                    if (a0 + a < RP) {
+                        const double la = vec[a0 + a];
+#pragma unroll
+                        for (int i = 0; i < RH; i++) ah[i] = fma(la, g[i][a], ah[i]);
+                    }
+                }
+            }
+        };
+        // quarter q (0..3) of the 2d-1 dots of a node: register-only work that fills the scalar-load waits of the next node
+        auto dots_quarter = [&](int q, const double (&ch)[RH], const double (&ah)[RH], auto &&sink) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < NV; g++)
+                if (g * 4 / NV == q) sink(g, (g < 2 * K) ? dot_reg<RH>(Wh[g], ch) : dot_reg<RH>(ah, Wh[g]));
+        };
+        auto dots_part = [&](const double (&ch)[RH], const double (&ah)[RH], auto &&sink) __attribute__((always_inline)) -> double {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < RH; i++) v = fma(sL[(H * RH + i) * 64 + lane], ch[i], v);
+#pragma unroll
+            for (int g = 0; g < 2 * K; g++) sink(g, dot_reg<RH>(Wh[g], ch));
+#pragma unroll
+            for (int g = 2 * K; g < NV; g++) sink(g, dot_reg<RH>(ah, Wh[g]));
+            sink(NV, v);
+            return v;
+        };
         // LDS exchange rows after L/R
         double *B0 = sK + 2 * RP * 64;    // wave 0 -> wave 1 : P_0(j1)[NP], then v_0(j0)
         double *B1 = B0 + (NP + 1) * 64;  // wave 1 -> wave 0 : P_1(j0)[NP], then v_1(j1)
@@ -455,10 +539,42 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             double Pown[NP]; // wave 0: its partial sums of the node it finalises stay in registers
 #pragma unroll
             for (int g = 0; g < NP; g++) Pown[g] = 0.0;
-            if constexpr (H == 0) { // the other wave's node first, the own node last
+            auto own_sink = [&](int g, double v) __attribute__((always_inline)) { Pown[g] = v; };
+            if constexpr (K > 0 && K < D - 1 && FPP_PIPE2) {
+                if (has0 && has1) { // both nodes: (c, a) of the second before the dots of the first
+                    double chA[RH], ahA[RH], chB[RH], ahB[RH];
+                    auto nofill = [](int) __attribute__((always_inline)) {};
+                    auto value_of = [&](const double (&ch)[RH]) __attribute__((always_inline)) -> double {
+                        double v = 0.0;
+#pragma unroll
+                        for (int i = 0; i < RH; i++) v = fma(sL[(H * RH + i) * 64 + lane], ch[i], v);
+                        return v;
+                    };
+                    if constexpr (H == 0) {
+                        auto sinkA = to_lds(B0);
+                        ca_part(j1, chA, ahA, nofill);
+                        ca_part(j0, chB, ahB, [&](int q) __attribute__((always_inline)) { dots_quarter(q, chA, ahA, sinkA); });
+                        pv1 = value_of(chA);
+                        sinkA(NV, pv1);
+                        pv0 = dots_part(chB, ahB, own_sink);
+                        B0[NP * 64 + lane] = pv0;
+                    } else {
+                        auto sinkA = to_lds(B1);
+                        ca_part(j0, chA, ahA, nofill);
+                        ca_part(j1, chB, ahB, [&](int q) __attribute__((always_inline)) { dots_quarter(q, chA, ahA, sinkA); });
+                        pv0 = value_of(chA);
+                        sinkA(NV, pv0);
+                        pv1 = dots_part(chB, ahB, to_lds(B2));
+                        B1[NP * 64 + lane] = pv1;
+                    }
+                } else if (has0) { // the last, unpaired node
+                    if constexpr (H == 0) { pv0 = partials(j0, own_sink); B0[NP * 64 + lane] = pv0; }
+                    else pv0 = partials(j0, to_lds(B1));
+                }
+            } else if constexpr (H == 0) { // the other wave's node first, the own node last
                 if (has1) pv1 = partials(j1, to_lds(B0));
                 if (has0) {
-                    pv0 = partials(j0, [&](int g, double v) __attribute__((always_inline)) { Pown[g] = v; });
+                    pv0 = partials(j0, own_sink);
                     B0[NP * 64 + lane] = pv0;
                 }
             } else {

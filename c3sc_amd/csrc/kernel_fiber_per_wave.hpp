@@ -104,8 +104,16 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
     __syncthreads();
 
     const int sel = lane / RP, bb = lane - sel * RP; // (vector, component) role in the per-fiber setup
-    CandRegs<Model> cr;
-    if constexpr (!STENCIL && !Model::IS_TABLE) cr.load(A, ro);
+    // candidate table in LDS (read with wave-uniform addresses): this kernel HAS lane-divergent control flow (lanes are
+    // nodes), so a table kept in VGPR lanes could be corrupted by a spill reloaded under a partial EXEC mask
+    CandLds<Model> cr;
+    cr.tb = nullptr;
+    if constexpr (!STENCIL && !Model::IS_TABLE) {
+        CandRegs<Model> cr0;
+        cr0.load(A, ro);
+        cr.fill(smem + A.tbl_off, cr0, A.ncand); // every wave writes the same rows
+        __syncthreads();
+    }
     unsigned st = 0;
 
     for (long f = (long)blockIdx.x * 4 + wv; f < A.F; f += (long)gridDim.x * 4) {
@@ -330,7 +338,7 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
                 } else {
                     double tv[Model::NTAB > 0 ? Model::NTAB : 1];
                     table_values<Model>(A, ro, ix, tv);
-                    val = node_backup<Model>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+                    val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
                 }
                 if (live) {
                     outv[(size_t)f * N + j] = val;

@@ -13,7 +13,11 @@ hipError_t launch_fpw_impl(const KArgs &A, const LaunchIO &io)
     constexpr int D = Model::D;
     constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL;
     const bool kedge = (A.k == 0) || (A.k == D - 1);
-    const size_t shmem = (size_t)(4 * WS + (STAGED ? A.N * kcore_stride(RP, kedge) : 0)) * sizeof(double);
+    size_t doubles = (size_t)(4 * WS + (STAGED ? A.N * kcore_stride(RP, kedge) : 0));
+    KArgs B = A;
+    B.tbl_off = (int)doubles; // candidate table behind everything else
+    if constexpr (!STENCIL && !Model::IS_TABLE) doubles += (size_t)CandLds<Model>::doubles(A.ncand);
+    const size_t shmem = doubles * sizeof(double);
     auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL, BOX, STAGED>;
     static int blocks_per_cu = 0;
     static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
@@ -34,7 +38,7 @@ hipError_t launch_fpw_impl(const KArgs &A, const LaunchIO &io)
     long cap = (long)NUM_CU * blocks_per_cu;
     int grid = (int)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, io.stream, A, io.ro, io.idx, io.out, io.uidx, io.absorbed,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, io.stream, B, io.ro, io.idx, io.out, io.uidx, io.absorbed,
                        io.nbf, io.nbv, io.tbl, io.tcost);
     return hipGetLastError();
 }
@@ -46,7 +50,8 @@ hipError_t launch_fpw(const KArgs &A, const LaunchIO &io)
     constexpr int D = Model::D;
     constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL;
     const bool kedge = (A.k == 0) || (A.k == D - 1);
-    const size_t staged = (size_t)(4 * WS + A.N * kcore_stride(RP, kedge)) * sizeof(double);
+    size_t staged = (size_t)(4 * WS + A.N * kcore_stride(RP, kedge)) * sizeof(double);
+    if constexpr (!STENCIL && !Model::IS_TABLE) staged += (size_t)CandLds<Model>::doubles(A.ncand) * sizeof(double);
     // the varying core (N x RP^2 doubles) is staged in LDS when it fits the CU, otherwise read from L2
     if (staged <= 160u * 1024u) return launch_fpw_impl<Model, RP, NPL, STENCIL, BOX, true>(A, io);
     if constexpr (RP >= 12) return launch_fpw_impl<Model, RP, NPL, STENCIL, BOX, false>(A, io);

@@ -168,16 +168,18 @@ int valuef_eval_fiber_ind_nn(struct ValueF *vf, const size_t *fixed_ind, size_t 
 }
 
 /* =============================================================================== nodeutil */
-int transition_assemble(size_t dx, size_t du, size_t dw, double h2, const double *tv, const double *drift,
+static int assemble_rates(size_t dx, size_t du, size_t dw, double h2, const double *tv, const double *hvec, const double *drift,
                         const double *grad_drift, const double *ddiff, const double *grad_ddiff, double *prob,
-                        double *grad_prob, double *dt, double *grad_dt, double *space)
+                        double *grad_prob, double *dt, double *grad_dt, double *space, int twice_left)
 { /* nodeutil.c:267-406: upwind rates p_m^{-+} = t2_m s_mm^2/2 + t_m max(-+b_m, 0), dead zone 1e-14 */
     const int want_grad = (grad_prob != NULL);
     int res = 0;
     if (space != NULL) for (size_t j = 0; j < du; j++) space[j] = 0.0;
     double Q = 0.0;
     for (size_t m = 0; m < dx; m++) {
-        const double t = tv[2 * m], t2 = tv[2 * m + 1];
+        /* new routine: (h^2/h_m, h^2/h_m^2) handed in (nodeutil.c:291-292); old one: built from the spacings (:126-127) */
+        const double t = tv ? tv[2 * m] : h2 / hvec[m];
+        const double t2 = tv ? tv[2 * m + 1] : t / hvec[m];
         const double s2 = ddiff[m * dx + m] * ddiff[m * dx + m];
         const double base = t2 * s2 / 2.0;
         const int sgn = drift[m] < -1e-14 ? -1 : (drift[m] > 1e-14 ? 1 : 0);
@@ -196,7 +198,10 @@ int transition_assemble(size_t dx, size_t du, size_t dw, double h2, const double
             else {
                 for (size_t j = 0; j < du; j++) {
                     const double g = grad_drift[j * dx + m];
-                    if (g < 0) { for (size_t q = 0; q < du; q++) gm[q] -= t * grad_drift[m + q * dx]; }
+                    if (g < 0) { /* the old routine applies this update twice, a daxpy and a loop (nodeutil.c:162-165) */
+                        for (int rep = 0; rep <= twice_left; rep++)
+                            for (size_t q = 0; q < du; q++) gm[q] -= t * grad_drift[m + q * dx];
+                    }
                     else if (g > 0) { for (size_t q = 0; q < du; q++) gp[q] += t * grad_drift[m + q * dx]; }
                     else res = 2;
                 }
@@ -221,6 +226,20 @@ int transition_assemble(size_t dx, size_t du, size_t dw, double h2, const double
         for (size_t i = 0; i < 2 * dx; i++) { prob[i] /= Q; prob[2 * dx] -= prob[i]; }
     }
     return res;
+}
+
+int transition_assemble(size_t dx, size_t du, size_t dw, double h2, const double *tv, const double *drift,
+                        const double *grad_drift, const double *ddiff, const double *grad_ddiff, double *prob,
+                        double *grad_prob, double *dt, double *grad_dt, double *space)
+{ /* nodeutil.c:267-406 */
+    return assemble_rates(dx, du, dw, h2, tv, NULL, drift, grad_drift, ddiff, grad_ddiff, prob, grad_prob, dt, grad_dt, space, 0);
+}
+
+int transition_assemble_old(size_t dx, size_t du, size_t dw, double h, const double *hvec, const double *drift,
+                            const double *grad_drift, const double *ddiff, const double *grad_ddiff, double *prob,
+                            double *grad_prob, double *dt, double *grad_dt, double *space)
+{ /* nodeutil.c:82-233: h is the minimum spacing, hvec the per-dimension spacings */
+    return assemble_rates(dx, du, dw, h * h, NULL, hvec, drift, grad_drift, ddiff, grad_ddiff, prob, grad_prob, dt, grad_dt, space, 1);
 }
 
 static size_t find_node(double x, size_t N, const double *grid)
@@ -1128,12 +1147,18 @@ void diag_destroy(struct Diag **head)
     if (head) *head = NULL;
 }
 
-void diag_append(struct Diag **diag, size_t iter, int type, double norm, double abs_diff, size_t dim, size_t *ranks, double frac)
-{
+struct Diag *diag_create(size_t iter, int type, double norm, double abs_diff, size_t dim, size_t *ranks, double frac)
+{ /* bellman.c:2437-2456: one unlinked record; ranks[0..dim] of the d+1 FT ranks are kept */
     struct Diag *n = xcalloc(1, sizeof(*n));
     n->iter = iter; n->type = type; n->norm = norm; n->abs_diff = abs_diff; n->dim = dim; n->frac = frac;
     n->ranks = xcalloc(dim + 1, sizeof(size_t));
     memcpy(n->ranks, ranks, (dim + 1) * sizeof(size_t));
+    return n;
+}
+
+void diag_append(struct Diag **diag, size_t iter, int type, double norm, double abs_diff, size_t dim, size_t *ranks, double frac)
+{
+    struct Diag *n = diag_create(iter, type, norm, abs_diff, dim, ranks, frac);
     if (*diag == NULL) { *diag = n; return; }
     struct Diag *cur = *diag;
     while (cur->next != NULL) cur = cur->next;

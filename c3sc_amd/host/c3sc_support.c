@@ -100,6 +100,17 @@ enum EBTYPE boundary_type_dim(const struct Boundary *b, size_t dim, int right)
     return b->type[dim];
 }
 
+double outer_bound_dim(const struct Boundary *b, size_t dim, double x, int *map)
+{ /* boundary.c:577-597: a point at or past a periodic face is sent to the opposite face (map 1: left->right, 2: right->left) */
+    *map = 0;
+    if (x <= b->lo[dim]) {
+        if (b->type[dim] == PERIODIC) { *map = 1; return b->hi[dim]; }
+    } else if (x >= b->hi[dim]) {
+        if (b->type[dim] == PERIODIC) { *map = 2; return b->lo[dim]; }
+    }
+    return x;
+}
+
 int boundary_in_obstacle(const struct Boundary *b, const double *x)
 {
     for (size_t i = 0; i < b->nobs; i++) {
@@ -142,6 +153,57 @@ int diff_eval(struct Diff *s, double t, const double *x, const double *u, double
 {
     if (s->f == NULL) { fprintf(stderr, "Warning: diff dynamics not yet specified\n"); return 1; }
     return s->f(t, x, u, out, grad, s->args);
+}
+
+/* dynamics.c:88-96, 183-192: copies share the callback and its argument pointer */
+struct Drift *drift_copy(struct Drift *o)
+{
+    if (o == NULL) return NULL;
+    struct Drift *b = drift_alloc(o->dx, o->du);
+    b->f = o->f; b->args = o->args;
+    return b;
+}
+struct Diff *diff_copy(struct Diff *o)
+{
+    if (o == NULL) return NULL;
+    struct Diff *s = diff_alloc(o->dx, o->du, o->dw);
+    s->f = o->f; s->args = o->args;
+    return s;
+}
+size_t drift_get_du(struct Drift *b) { return b->du; }
+
+/* dynamics.c:258-354: a (drift, diffusion) pair; dyn_alloc / dyn_init_ref borrow, *_deep own */
+struct Dyn { struct Drift *drift; struct Diff *diff; };
+struct Dyn *dyn_alloc(struct Drift *b, struct Diff *s)
+{
+    struct Dyn *d = xmalloc(sizeof(*d));
+    d->drift = b; d->diff = s;
+    return d;
+}
+struct Dyn *dyn_copy_deep(struct Dyn *o)
+{
+    if (o == NULL) return NULL;
+    return dyn_alloc(drift_copy(o->drift), diff_copy(o->diff));
+}
+void dyn_free(struct Dyn *d) { free(d); }
+void dyn_free_deep(struct Dyn *d)
+{
+    if (d == NULL) return;
+    drift_free(d->drift);
+    diff_free(d->diff);
+    free(d);
+}
+void dyn_init_ref(struct Dyn *d, struct Drift *b, struct Diff *s) { d->drift = b; d->diff = s; }
+size_t dyn_get_dx(struct Dyn *d) { return drift_get_dx(d->drift); }
+size_t dyn_get_dw(struct Dyn *d) { return diff_get_dw(d->diff); }
+size_t dyn_get_du(struct Dyn *d) { return drift_get_du(d->drift); }
+int dyn_eval(struct Dyn *d, double t, const double *x, const double *u, double *drift, double *jacdr, double *diff, double *jacdiff)
+{ /* dynamics.c:332-349: the diffusion is skipped when the drift callback fails */
+    int res = 0;
+    if (drift != NULL) res = drift_eval(d->drift, t, x, u, drift, jacdr);
+    if (res != 0) return res;
+    if (diff != NULL) res = diff_eval(d->diff, t, x, u, diff, jacdiff);
+    return res;
 }
 
 /* ------------------------------------------------------------------------------ memo (hashgrid.c) */

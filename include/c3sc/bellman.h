@@ -110,6 +110,7 @@ int c3control_simulate(struct C3Control *, const double *x0, double dt, size_t n
 struct ApproxArgs;
 struct Diag; /* bellman.c:2409-2514: per-iteration log */
 void diag_destroy(struct Diag **head);
+struct Diag *diag_create(size_t iter, int type, double norm, double abs_diff, size_t dim, size_t *ranks, double frac);
 void diag_append(struct Diag **diag, size_t iter, int type, double norm, double abs_diff, size_t dim, size_t *ranks,
                  double frac);
 void diag_print(struct Diag *head, FILE *fp);

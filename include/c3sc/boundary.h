@@ -17,6 +17,8 @@ size_t boundary_get_nobs(struct Boundary *b);
 double *boundary_obstacle_get_lb(struct Boundary *b, size_t i);
 double *boundary_obstacle_get_ub(struct Boundary *b, size_t i);
 enum EBTYPE boundary_type_dim(const struct Boundary *b, size_t dim, int right);  /* boundary.c:604-614 */
+/* boundary.c:577-597: x at/past a PERIODIC face -> the opposite face, *map = 1 (left->right) or 2 (right->left); else x, *map = 0 */
+double outer_bound_dim(const struct Boundary *b, size_t dim, double x, int *map);
 int boundary_in_obstacle(const struct Boundary *b, const double *x);             /* boundary.c:668-680 */
 size_t boundary_get_dim(const struct Boundary *b);
 #endif

@@ -9,6 +9,10 @@
 int transition_assemble(size_t dx, size_t du, size_t dw, double h, const double *hvec, const double *drift,
                         const double *grad_drift, const double *ddiff, const double *grad_ddiff, double *prob,
                         double *grad_prob, double *dt, double *grad_dt, double *space); /* nodeutil.c:267-406 */
+/* the earlier form (nodeutil.c:82-233): h = minimum spacing, hvec[m] = spacing of dimension m */
+int transition_assemble_old(size_t dx, size_t du, size_t dw, double h, const double *hvec, const double *drift,
+                            const double *grad_drift, const double *ddiff, const double *grad_ddiff, double *prob,
+                            double *grad_prob, double *dt, double *grad_dt, double *space);
 int convert_fiber_to_ind(size_t d, size_t N, const double *x, const size_t *Ngrid, double **xgrid, size_t *fixed_ind,
                          size_t *dim_vary);                                             /* nodeutil.c:437-470 */
 int process_fibers_neighbor(size_t d, const size_t *fixed_ind, size_t dim_vary, const double *x, int *absorbed,

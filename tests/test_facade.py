@@ -151,6 +151,120 @@ def test_host_transition_and_rhs_match_oracle(oracle):
     assert L.uniform_stride(C.c_size_t(51), C.c_size_t(5)) == 12 and L.uniform_stride(C.c_size_t(10), C.c_size_t(10)) == 0
 
 
+def test_old_assembly_dyn_pair_and_periodic_wrap(oracle):
+    """transition_assemble_old (nodeutil.c:82-233) against the oracle, including the doubled left update of its
+    zero-drift gradient branch; dyn_* (dynamics.c:258-354); outer_bound_dim (boundary.c:577-597); diag_create."""
+    import facade_lib
+
+    L = facade_lib.lib()
+    rng = np.random.default_rng(21)
+    L.transition_assemble_old.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_double] + [facade_lib.c_double_p] * 10
+    for dx, du in ((2, 1), (3, 2), (7, 3)):
+        for rep in range(40):
+            hv = rng.uniform(0.02, 0.3, dx)
+            hmin = float(hv.min())
+            drift = rng.uniform(-2, 2, dx)
+            drift[rng.integers(0, dx)] = 0.0
+            if rep % 5 == 0:
+                drift[:] = 0.0
+            diff = np.diag(rng.uniform(0.1, 1.0, dx)).ravel()
+            gd = rng.uniform(-1, 1, dx * du)
+            gd[rng.integers(0, dx * du)] = 0.0
+            gdiff = rng.uniform(-0.1, 0.1, dx * dx * du)
+            for grad in (True, False):
+                res0, p0, dt0, gp0, gdt0 = oracle.transition_assemble(dx, du, dx, hmin, hv, drift, diff, gd if grad else None,
+                                                                      gdiff if grad else None, old=True)
+                p = np.zeros(2 * dx + 1); gp = np.zeros((2 * dx + 1) * du); gdt = np.zeros(du); sp_ = np.zeros(du)
+                dt = C.c_double(0)
+                res = L.transition_assemble_old(dx, du, dx, hmin, facade_lib.dp(hv), facade_lib.dp(drift), facade_lib.dp(gd) if grad else None,
+                                                facade_lib.dp(diff), facade_lib.dp(gdiff) if grad else None, facade_lib.dp(p),
+                                                facade_lib.dp(gp) if grad else None, C.cast(C.byref(dt), facade_lib.c_double_p),
+                                                facade_lib.dp(gdt) if grad else None, facade_lib.dp(sp_) if grad else None)
+                assert res == res0
+                np.testing.assert_allclose(p, p0, rtol=0, atol=1e-16)
+                assert dt.value == pytest.approx(dt0, rel=1e-15)
+                if grad:
+                    np.testing.assert_allclose(gp, gp0, rtol=1e-14, atol=1e-15)
+                    np.testing.assert_allclose(gdt, gdt0, rtol=1e-14, atol=1e-18)
+    # stationary node: return 1 and leave the outputs alone (nodeutil.c:199-201)
+    p = np.full(5, 7.0)
+    dt = C.c_double(3.0)
+    z2 = np.zeros(2)
+    res = L.transition_assemble_old(2, 1, 2, 0.1, facade_lib.dp(np.array([0.1, 0.2])), facade_lib.dp(z2), None, facade_lib.dp(np.zeros(4)), None,
+                                    facade_lib.dp(p), None, C.cast(C.byref(dt), facade_lib.c_double_p), None, None)
+    assert res == 1 and dt.value == 3.0 and p[4] == 7.0
+
+    # drift + diffusion pair
+    for n in ("drift_copy", "diff_copy", "dyn_alloc", "dyn_copy_deep", "diag_create"):
+        getattr(L, n).restype = C.c_void_p
+    for n in ("dyn_get_dx", "dyn_get_du", "dyn_get_dw", "diag_count"):
+        getattr(L, n).restype = C.c_size_t
+    calls = []
+
+    def b(t, x, u, out, jac, args):
+        calls.append("b")
+        out[0], out[1] = x[1], u[0]
+        if jac:
+            jac[0], jac[1] = 0.0, 1.0
+        return 0
+
+    def bfail(t, x, u, out, jac, args):
+        calls.append("bfail")
+        return 5
+
+    def s(t, x, u, out, jac, args):
+        calls.append("s")
+        out[0], out[1], out[2], out[3] = 0.5, 0.0, 0.0, 0.25
+        return 0
+
+    bcb, bfcb, scb = facade_lib.DYN_FN(b), facade_lib.DYN_FN(bfail), facade_lib.DYN_FN(s)
+    dr = C.c_void_p(L.drift_alloc(C.c_size_t(2), C.c_size_t(1)))
+    df = C.c_void_p(L.diff_alloc(C.c_size_t(2), C.c_size_t(1), C.c_size_t(2)))
+    L.drift_add_func(dr, bcb, None)
+    L.diff_add_func(df, scb, None)
+    dyn = C.c_void_p(L.dyn_alloc(dr, df))
+    assert (L.dyn_get_dx(dyn), L.dyn_get_du(dyn), L.dyn_get_dw(dyn)) == (2, 1, 2)
+    deep = C.c_void_p(L.dyn_copy_deep(dyn))
+    x, u = np.array([0.3, -0.7]), np.array([0.9])
+    for h in (dyn, deep):
+        bo, jo, so = np.zeros(2), np.zeros(2), np.zeros(4)
+        assert L.dyn_eval(h, C.c_double(0.0), facade_lib.dp(x), facade_lib.dp(u), facade_lib.dp(bo), facade_lib.dp(jo), facade_lib.dp(so), None) == 0
+        assert list(bo) == [-0.7, 0.9] and list(jo) == [0.0, 1.0] and list(so) == [0.5, 0.0, 0.0, 0.25]
+    calls.clear()
+    so = np.zeros(4)
+    assert L.dyn_eval(dyn, C.c_double(0.0), facade_lib.dp(x), facade_lib.dp(u), None, None, facade_lib.dp(so), None) == 0 and calls == ["s"]
+    L.drift_add_func(dr, bfcb, None)  # a failing drift stops before the diffusion (dynamics.c:341-343)
+    calls.clear()
+    bo = np.zeros(2)
+    assert L.dyn_eval(dyn, C.c_double(0.0), facade_lib.dp(x), facade_lib.dp(u), facade_lib.dp(bo), None, facade_lib.dp(so), None) == 5
+    assert calls == ["bfail"]
+    L.dyn_free_deep(deep)
+    L.dyn_free(dyn)
+    L.drift_free(dr)
+    L.diff_free(df)
+
+    # periodic wrap
+    L.outer_bound_dim.restype = C.c_double
+    lb, ub = np.array([-1.0, 0.0]), np.array([2.0, 6.0])
+    bd = C.c_void_p(L.boundary_alloc(C.c_size_t(2), facade_lib.dp(lb), facade_lib.dp(ub)))
+    L.boundary_external_set_type(bd, C.c_size_t(1), b"periodic")
+    mp = C.c_int(-1)
+    for dim, xx, want, wmap in ((1, 0.0, 6.0, 1), (1, -0.5, 6.0, 1), (1, 6.0, 0.0, 2), (1, 7.5, 0.0, 2), (1, 3.0, 3.0, 0),
+                                (0, -1.0, -1.0, 0), (0, 2.5, 2.5, 0), (0, 0.0, 0.0, 0)):
+        got = L.outer_bound_dim(bd, C.c_size_t(dim), C.c_double(xx), C.byref(mp))
+        assert (got, mp.value) == (want, wmap)
+    L.boundary_free(bd)
+
+    # one unlinked Diag record
+    rk = np.array([1, 4, 5, 1], dtype=np.uintp)
+    dg = C.c_void_p(L.diag_create(C.c_size_t(3), C.c_int(1), C.c_double(2.0), C.c_double(0.5), C.c_size_t(3), facade_lib.sp(rk), C.c_double(0.1)))
+    assert L.diag_count(dg) == 1
+    L.diag_append(C.byref(dg), C.c_size_t(4), C.c_int(1), C.c_double(2.0), C.c_double(0.25), C.c_size_t(3), facade_lib.sp(rk), C.c_double(0.1))
+    assert L.diag_count(dg) == 2
+    L.diag_destroy(C.byref(dg))
+    assert dg.value is None
+
+
 def _callbacks(w):
     """Host callbacks with the reference's signatures, evaluated in Python (dubins: dubinscar.c:40-121)."""
     import math

@@ -663,28 +663,28 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 
 static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, const double *x_in, double *out, int fast)
 {
-    const double t_begin = now_s();
     struct ControlParams *cp = vi->cp;
     struct MCAparam *mca = cp->mca;
     const size_t dx = mca->dx, N = mca->ngrid[k0];
-    struct c3sc_hip_ctx *ctx = sync_device(vi);
+    struct c3sc_hip_ctx *ctx = sync_device(vi); /* first call: creates the device context and uploads the cores */
+    const double t_begin = now_s();
     struct HTable *ht = workspace_get_vi_htable(cp->work);
     struct FastMemo *fm = workspace_get_vi_fastmemo(cp->work);
     size_t *ser = workspace_get_ind_to_serialize(cp->work);
     const size_t vi_iter = workspace_get_vi_iter(cp->work);
     char key[256];
-    uint64_t fk[4];
+    struct FmFiber ff;
     unsigned char *need = xcalloc(F, 1), *hit = xcalloc(F * N, 1);
     for (size_t f = 0; f < F; f++) {
         for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
         ser[dx] = 0;           /* bellman.c:1337 */
         ser[dx + 1] = vi_iter; /* bellman.c:1338 */
+        if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, 0, vi_iter);
         for (size_t j = 0; j < N; j++) { /* memo lookup, bellman.c:1341-1353 */
             double v = 0.0;
             int found;
             if (fast) {
-                fastmemo_key(dx, idx + f * dx, k0, j, 0, vi_iter, fk);
-                found = fastmemo_get(fm, fk, &v);
+                found = fastmemo_fiber_get(fm, &ff, j, &v);
             } else {
                 ser[k0] = j;
                 size_t_a_to_char(ser, dx + 2, key);
@@ -748,12 +748,12 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
             ser[dx] = 0;
             ser[dx + 1] = vi_iter;
+            if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, 0, vi_iter);
             for (size_t j = 0; j < N; j++) {
                 if (hit[f * N + j]) continue;
                 out[f * N + j] = rout[r * N + j];
                 if (fast) {
-                    fastmemo_key(dx, idx + f * dx, k0, j, 0, vi_iter, fk);
-                    fastmemo_put(fm, fk, out[f * N + j]);
+                    fastmemo_fiber_put(fm, &ff, j, out[f * N + j]);
                 } else {
                     ser[k0] = j;
                     size_t_a_to_char(ser, dx + 2, key);
@@ -848,7 +848,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
     size_t *ser = workspace_get_ind_to_serialize(cp->work);
     const size_t pi_iter = workspace_get_pi_iter(cp->work), pi_sub = workspace_get_pi_subiter(cp->work);
     char key1[256], key2[256];
-    uint64_t fk[4];
+    struct FmFiber ff;
     const int have_model = dp_has_device_model(dp);
     const int brute = c3opt_is_bruteforce(cp->opt);
     const size_t pw = brute ? 1 : c3opt_get_d(cp->opt); /* cached policy per node: candidate index, or the control itself */
@@ -867,6 +867,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
         process_fibers_neighbor(dx, fi, k0, x + f * N * dx, absorbed, nv, nf, mca->ngrid, dp->bound);
         ser[dx] = pi_iter;    /* bellman.c:1759 */
         ser[dx + 1] = pi_sub; /* :1760 */
+        if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, pi_iter, 0);
         for (size_t j = 0; j < N; j++) {
             if (!fast) {
                 ser[k0] = j;
@@ -882,8 +883,8 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
             int found = 1;
             if (fast) {
                 for (size_t q = 0; q < pw && found; q++) {
-                    fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, q, fk);
-                    found = fastmemo_get(fm, fk, &polv[(f * N + j) * pw + q]);
+                    fastmemo_fiber_counter(&ff, pi_iter, q);
+                    found = fastmemo_fiber_get(fm, &ff, j, &polv[(f * N + j) * pw + q]);
                 }
             } else {
                 size_t nb = 0;
@@ -936,6 +937,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
             if (!need[f]) continue;
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
             ser[dx] = pi_iter;
+            if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, pi_iter, 0);
             for (size_t j = 0; j < N; j++) {
                 if (!miss[f * N + j]) continue;
                 double *pv = &polv[(f * N + j) * pw];
@@ -944,8 +946,8 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
                 else memcpy(pv, &ruo[(r * N + j) * pw], pw * sizeof(double));
                 if (fast) {
                     for (size_t q = 0; q < pw; q++) {
-                        fastmemo_key(dx, idx + f * dx, k0, j, pi_iter, q, fk);
-                        fastmemo_put(fm, fk, pv[q]);
+                        fastmemo_fiber_counter(&ff, pi_iter, q);
+                        fastmemo_fiber_put(fm, &ff, j, pv[q]);
                     }
                 } else {
                     ser[k0] = j;

@@ -27,6 +27,16 @@
 
 /* ------------------------------------------------------------------------------ small dense kernels */
 
+/* dot product with four independent partial sums (the compiler may not reassociate a single one) */
+static inline double dotn(const double *x, const double *y, size_t n)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) { s0 += x[i] * y[i]; s1 += x[i + 1] * y[i + 1]; s2 += x[i + 2] * y[i + 2]; s3 += x[i + 3] * y[i + 3]; }
+    for (; i < n; i++) s0 += x[i] * y[i];
+    return (s0 + s1) + (s2 + s3);
+}
+
 /* Householder QR of the m x n (m >= n) column-major matrix A: on exit A holds the thin orthonormal Q (m x n),
  * R (n x n, column-major, upper triangular) is written if not NULL.  Works for rank-deficient A (Q stays
  * orthonormal). */
@@ -37,9 +47,7 @@ static void qr_thin(size_t m, size_t n, double *A, double *R)
     double *Rf = xcalloc(n * n, sizeof(double));
     for (size_t k = 0; k < n; k++) {
         double *a = A + k * m;
-        double nrm = 0.0;
-        for (size_t i = k; i < m; i++) nrm += a[i] * a[i];
-        nrm = sqrt(nrm);
+        const double nrm = sqrt(dotn(a + k, a + k, m - k));
         double *v = V + k * m;
         if (nrm == 0.0) { /* zero column below the diagonal: reflect e_k onto itself */
             Rf[k + k * n] = 0.0;
@@ -48,14 +56,11 @@ static void qr_thin(size_t m, size_t n, double *A, double *R)
         const double alpha = a[k] >= 0.0 ? -nrm : nrm;
         for (size_t i = k; i < m; i++) v[i] = a[i];
         v[k] -= alpha;
-        double vn = 0.0;
-        for (size_t i = k; i < m; i++) vn += v[i] * v[i];
-        vn = sqrt(vn);
+        const double vn = sqrt(dotn(v + k, v + k, m - k));
         if (vn > 0.0) for (size_t i = k; i < m; i++) v[i] /= vn;
         for (size_t j = k; j < n; j++) { /* apply H = I - 2 v v^T to the trailing columns */
-            double *c = A + j * m, s = 0.0;
-            for (size_t i = k; i < m; i++) s += v[i] * c[i];
-            s *= 2.0;
+            double *c = A + j * m;
+            const double s = 2.0 * dotn(v + k, c + k, m - k);
             for (size_t i = k; i < m; i++) c[i] -= s * v[i];
         }
         for (size_t j = k; j < n; j++) Rf[k + j * n] = A[k + j * m];
@@ -69,13 +74,10 @@ static void qr_thin(size_t m, size_t n, double *A, double *R)
     }
     for (size_t kk = n; kk-- > 0;) {
         const double *v = V + kk * m;
-        double vn = 0.0;
-        for (size_t i = kk; i < m; i++) vn += v[i] * v[i];
-        if (vn == 0.0) continue;
+        if (dotn(v + kk, v + kk, m - kk) == 0.0) continue;
         for (size_t j = 0; j < n; j++) {
-            double *q = A + j * m, s = 0.0;
-            for (size_t i = kk; i < m; i++) s += v[i] * q[i];
-            s *= 2.0;
+            double *q = A + j * m;
+            const double s = 2.0 * dotn(v + kk, q + kk, m - kk);
             for (size_t i = kk; i < m; i++) q[i] -= s * v[i];
         }
     }
@@ -84,44 +86,41 @@ static void qr_thin(size_t m, size_t n, double *A, double *R)
     free(Rf);
 }
 
-/* Solve X S = Q for X (m x r) where S = Q[rows] is r x r: Gaussian elimination with partial pivoting on S^T. */
+/* X = Q inv(S) (m x r) where S = Q[rows] is r x r: invert S by Gauss-Jordan with partial pivoting, then r^2
+ * axpys over contiguous columns of Q. */
 static void right_solve(size_t m, size_t r, const double *Q, const size_t *rows, double *X)
 {
-    /* X S = Q  <=>  S^T X^T = Q^T.  Factor T = S^T (r x r) and solve for the m right-hand sides. */
-    double *T = xcalloc(r * r, sizeof(double));
-    size_t *piv = xcalloc(r, sizeof(size_t));
-    for (size_t i = 0; i < r; i++)
-        for (size_t j = 0; j < r; j++) T[i + j * r] = Q[rows[j] + i * m]; /* T[i][j] = S[j][i] */
-    double *B = xcalloc(r * m, sizeof(double)); /* Q^T, r x m col-major */
-    for (size_t c = 0; c < m; c++)
-        for (size_t i = 0; i < r; i++) B[i + c * r] = Q[c + i * m];
+    double *T = xcalloc(r * 2 * r, sizeof(double)); /* [S | I], row-major, 2r per row */
+    for (size_t i = 0; i < r; i++) {
+        for (size_t j = 0; j < r; j++) T[i * 2 * r + j] = Q[rows[i] + j * m];
+        T[i * 2 * r + r + i] = 1.0;
+    }
     for (size_t k = 0; k < r; k++) {
         size_t p = k;
-        for (size_t i = k + 1; i < r; i++) if (fabs(T[i + k * r]) > fabs(T[p + k * r])) p = i;
-        piv[k] = p;
-        if (p != k) {
-            for (size_t j = 0; j < r; j++) { double t = T[k + j * r]; T[k + j * r] = T[p + j * r]; T[p + j * r] = t; }
-            for (size_t c = 0; c < m; c++) { double t = B[k + c * r]; B[k + c * r] = B[p + c * r]; B[p + c * r] = t; }
-        }
-        const double d = T[k + k * r];
-        if (d == 0.0) continue; /* singular pivot: leave (maxvol never selects dependent rows of an orthonormal Q) */
-        for (size_t i = k + 1; i < r; i++) {
-            const double f = T[i + k * r] / d;
+        for (size_t i = k + 1; i < r; i++) if (fabs(T[i * 2 * r + k]) > fabs(T[p * 2 * r + k])) p = i;
+        if (p != k) for (size_t j = 0; j < 2 * r; j++) { const double t = T[k * 2 * r + j]; T[k * 2 * r + j] = T[p * 2 * r + j]; T[p * 2 * r + j] = t; }
+        const double dg = T[k * 2 * r + k];
+        if (dg == 0.0) continue; /* singular pivot: leave (maxvol never selects dependent rows of an orthonormal Q) */
+        const double inv = 1.0 / dg;
+        for (size_t j = 0; j < 2 * r; j++) T[k * 2 * r + j] *= inv;
+        for (size_t i = 0; i < r; i++) {
+            if (i == k) continue;
+            const double f = T[i * 2 * r + k];
             if (f == 0.0) continue;
-            for (size_t j = k; j < r; j++) T[i + j * r] -= f * T[k + j * r];
-            for (size_t c = 0; c < m; c++) B[i + c * r] -= f * B[k + c * r];
+            for (size_t j = 0; j < 2 * r; j++) T[i * 2 * r + j] -= f * T[k * 2 * r + j];
         }
     }
-    for (size_t c = 0; c < m; c++) {
-        double *b = B + c * r;
-        for (size_t ii = r; ii-- > 0;) {
-            double s = b[ii];
-            for (size_t j = ii + 1; j < r; j++) s -= T[ii + j * r] * b[j];
-            b[ii] = (T[ii + ii * r] != 0.0) ? s / T[ii + ii * r] : 0.0;
+    for (size_t j = 0; j < r; j++) {
+        double *xj = X + j * m;
+        for (size_t c = 0; c < m; c++) xj[c] = 0.0;
+        for (size_t i = 0; i < r; i++) {
+            const double w = T[i * 2 * r + r + j]; /* inv(S)[i][j] */
+            if (w == 0.0) continue;
+            const double *qi = Q + i * m;
+            for (size_t c = 0; c < m; c++) xj[c] += w * qi[c];
         }
-        for (size_t i = 0; i < r; i++) X[c + i * m] = b[i];
     }
-    free(T); free(piv); free(B);
+    free(T);
 }
 
 /* maxvol: r rows of the m x r matrix Q (full column rank) whose submatrix has (locally) maximal volume;
@@ -141,11 +140,13 @@ static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
         used[p] = 1;
         const double d = W[p + k * m];
         if (d == 0.0) continue;
-        for (size_t i = 0; i < m; i++) {
-            if (used[i]) continue;
-            const double f = W[i + k * m] / d;
-            if (f == 0.0) continue;
-            for (size_t j = k; j < r; j++) W[i + j * m] -= f * W[p + j * m];
+        double *fk = W + k * m; /* column k becomes the multipliers (rows already used keep 0) */
+        for (size_t i = 0; i < m; i++) fk[i] = used[i] ? 0.0 : fk[i] / d;
+        for (size_t j = k + 1; j < r; j++) {
+            double *wj = W + j * m;
+            const double pj = wj[p];
+            if (pj == 0.0) continue;
+            for (size_t i = 0; i < m; i++) wj[i] -= fk[i] * pj;
         }
     }
     free(W);
@@ -182,8 +183,7 @@ static void svd_jacobi(size_t m, size_t n, double *A, double *S, double *V)
         for (size_t p = 0; p + 1 < n; p++)
             for (size_t q = p + 1; q < n; q++) {
                 double *ap = A + p * m, *aq = A + q * m;
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (size_t i = 0; i < m; i++) { alpha += ap[i] * ap[i]; beta += aq[i] * aq[i]; gamma += ap[i] * aq[i]; }
+                const double alpha = dotn(ap, ap, m), beta = dotn(aq, aq, m), gamma = dotn(ap, aq, m);
                 if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
                 off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
                 const double zeta = (beta - alpha) / (2.0 * gamma);
@@ -404,10 +404,69 @@ static struct tt *tt_diff(const struct tt *a, const struct tt *b)
     return t;
 }
 
-/* continuous L2 norm of the piecewise-multilinear interpolant of a nodal TT: weight every core along its node
- * index with L^T, M = L L^T the (tridiagonal) mass matrix of the hat functions on that grid, then the plain
- * Frobenius norm via orthogonalisation (no Gram-matrix cancellation: the error is eps*||T||, not eps*||T||^2). */
-static double tt_norm_l2(const struct tt *src, double **grid)
+/* <a, b> = sum over all nodes of a*b, by carrying the r^a_k x r^b_k Gram matrix through the cores.  Cheap (two small
+ * matrix products per core) but a difference of such products resolves ||a - b|| only down to ~1e-7 ||a||: callers
+ * use it when the answer is far above that and fall back to orthogonalisation otherwise. */
+static double tt_dot(const struct tt *a, const struct tt *b)
+{
+    const size_t d = a->d;
+    size_t rmax = 1;
+    for (size_t k = 0; k <= d; k++) { if (a->r[k] > rmax) rmax = a->r[k]; if (b->r[k] > rmax) rmax = b->r[k]; }
+    size_t nmax = 1;
+    for (size_t k = 0; k < d; k++) if (a->N[k] > nmax) nmax = a->N[k];
+    double *M = xcalloc(rmax * rmax, sizeof(double)), *Mn = xcalloc(rmax * rmax, sizeof(double));
+    double *P = xcalloc(rmax * nmax * rmax, sizeof(double));
+    M[0] = 1.0;
+    for (size_t k = 0; k < d; k++) {
+        const size_t N = a->N[k], ra0 = a->r[k], ra1 = a->r[k + 1], rb0 = b->r[k], rb1 = b->r[k + 1];
+        const size_t cols = N * rb1, ld = ra0 * N;
+        /* P (ra0 x N rb1) = M (ra0 x rb0) * B_k (rb0 x N rb1) */
+        for (size_t c = 0; c < cols; c++) {
+            double *pc = P + c * ra0;
+            const double *bc = b->G[k] + c * rb0;
+            for (size_t i = 0; i < ra0; i++) pc[i] = 0.0;
+            for (size_t q = 0; q < rb0; q++) {
+                const double w = bc[q];
+                const double *mq = M + q * ra0;
+                for (size_t i = 0; i < ra0; i++) pc[i] += mq[i] * w;
+            }
+        }
+        /* M' (ra1 x rb1) = A_k^T P with both seen as (ra0 N) x r matrices */
+        for (size_t be = 0; be < rb1; be++)
+            for (size_t al = 0; al < ra1; al++) {
+                const double *x = a->G[k] + al * ld, *y = P + be * ld;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                size_t i = 0;
+                for (; i + 4 <= ld; i += 4) { s0 += x[i] * y[i]; s1 += x[i + 1] * y[i + 1]; s2 += x[i + 2] * y[i + 2]; s3 += x[i + 3] * y[i + 3]; }
+                for (; i < ld; i++) s0 += x[i] * y[i];
+                Mn[al + be * ra1] = (s0 + s1) + (s2 + s3);
+            }
+        double *t = M; M = Mn; Mn = t;
+    }
+    const double res = M[0];
+    free(M); free(Mn); free(P);
+    return res;
+}
+
+/* ||a - b|| / ||a|| in the nodal Frobenius norm; nb2 = <b, b> if the caller has it (else < 0); *na2 returns <a, a> */
+static double tt_rel_change(const struct tt *a, const struct tt *b, double nb2, double *na2, double tol)
+{
+    const double aa = tt_dot(a, a), ab = tt_dot(a, b), bb = nb2 >= 0.0 ? nb2 : tt_dot(b, b);
+    *na2 = aa;
+    if (!(aa > 0.0)) return sqrt(bb > 0.0 ? bb : 0.0);
+    const double d2 = aa - 2.0 * ab + bb, floor2 = 1e-10 * (aa > bb ? aa : bb);
+    if (d2 > floor2 || tol * tol >= floor2 / aa) return sqrt(d2 > 0.0 ? d2 : 0.0) / sqrt(aa); /* far above the cancellation level, or the tolerance is */
+    struct tt *df = tt_diff(a, b);
+    if (df->d > 1) tt_orthogonalize_rl(df);
+    const double dn = tt_frob_of_core0(df);
+    tt_free(df);
+    return dn / sqrt(aa);
+}
+
+/* continuous L2 inner products of the piecewise-multilinear interpolants of nodal TTs: weight every core along its
+ * node index with L^T, M = L L^T the (tridiagonal) mass matrix of the hat functions on that grid; nodal sums of
+ * the weighted TTs are then integrals. */
+static struct tt *tt_weight_l2(const struct tt *src, double **grid)
 {
     struct tt *t = tt_copy(src);
     for (size_t k = 0; k < t->d; k++) {
@@ -431,10 +490,35 @@ static double tt_norm_l2(const struct tt *src, double **grid)
                 }
         free(dg); free(lo);
     }
-    if (t->d > 1) tt_orthogonalize_rl(t);
-    const double nrm = tt_frob_of_core0(t);
+    return t;
+}
+
+/* ||src||_L2.  A norm has no cancellation, so the Gram recursion is exact to rounding. */
+static double tt_norm_l2(const struct tt *src, double **grid)
+{
+    struct tt *t = tt_weight_l2(src, grid);
+    const double n2 = tt_dot(t, t);
     tt_free(t);
-    return nrm;
+    return sqrt(n2 > 0.0 ? n2 : 0.0);
+}
+
+/* ||a - b||_L2: Gram recursion while the answer is far above its cancellation level (1e-5 of the larger norm),
+ * otherwise through the orthogonalised difference (error eps*||.||, not sqrt(eps)*||.||) */
+static double tt_norm2diff_l2(const struct tt *a, const struct tt *b, double **grid)
+{
+    struct tt *wa = tt_weight_l2(a, grid), *wb = tt_weight_l2(b, grid);
+    const double aa = tt_dot(wa, wa), bb = tt_dot(wb, wb), ab = tt_dot(wa, wb);
+    const double d2 = aa - 2.0 * ab + bb;
+    double n;
+    if (d2 > 1e-10 * (aa > bb ? aa : bb)) n = sqrt(d2);
+    else {
+        struct tt *df = tt_diff(wa, wb);
+        if (df->d > 1) tt_orthogonalize_rl(df);
+        n = tt_frob_of_core0(df);
+        tt_free(df);
+    }
+    tt_free(wa); tt_free(wb);
+    return n;
 }
 
 static double **unit_grid(size_t d, const size_t *N)
@@ -461,11 +545,10 @@ double valuef_norm2diff(struct ValueF *a, struct ValueF *b)
 { /* valuefunc.c:324-335 */
     assert(a->d == b->d);
     struct tt *ta = tt_from_valuef(a), *tb = tt_from_valuef(b);
-    struct tt *td = tt_diff(ta, tb);
     double **g = a->grid ? a->grid : (b->grid ? b->grid : unit_grid(a->d, a->N));
-    const double n = tt_norm_l2(td, g);
+    const double n = tt_norm2diff_l2(ta, tb, g);
     if (!a->grid && !b->grid) { for (size_t k = 0; k < a->d; k++) free(g[k]); free(g); }
-    tt_free(ta); tt_free(tb); tt_free(td);
+    tt_free(ta); tt_free(tb);
     return n;
 }
 
@@ -519,6 +602,7 @@ struct cross {
     int **I, **J;   /* I[k]: r[k] tuples over dims 0..k-1; J[k]: r[k+1] tuples over dims k+1..d-1 */
     size_t nfibers; /* fibers requested so far */
     int verbose;
+    int deficient;  /* a core step of the current cross iteration saw an (exactly) rank-deficient fiber matrix */
 };
 
 /* evaluate the core tensor C[a + r_k*(j + N_k*b)] = f(I_k[a], j, J_k[b]): r_k r_{k+1} fibers along dim k */
@@ -569,6 +653,21 @@ static double *cross_eval_core(struct cross *c, size_t k)
     return C;
 }
 
+/* C3SC_PROFILE=1: where the driver's own time goes (printed at the end of an interpolation) */
+#include <time.h>
+static double g_tc[6]; /* callback+gather, qr, maxvol, convergence check, rounding, total */
+static double tnow(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define TIMED(slot, stmt) do { const double t__ = tnow(); stmt; g_tc[slot] += tnow() - t__; } while (0)
+
+/* exact rank deficiency of the matrix just factored (duplicate index tuples, mirror-image rows of a symmetric
+ * function, a function of lower rank than asked for): the pivots chosen in the null directions carry no information */
+static int r_is_deficient(size_t n, const double *R)
+{
+    double mx = 0.0, mn = INFINITY;
+    for (size_t k = 0; k < n; k++) { const double a = fabs(R[k + k * n]); if (a > mx) mx = a; if (a < mn) mn = a; }
+    return !(mn > 1e-12 * mx);
+}
+
 /* left-to-right half sweep: new left index sets, interpolatory cores; returns the TT */
 static struct tt *cross_sweep_lr(struct cross *c)
 {
@@ -576,12 +675,16 @@ static struct tt *cross_sweep_lr(struct cross *c)
     struct tt *t = tt_alloc(d, c->N, c->r);
     for (size_t k = 0; k < d; k++) {
         const size_t N = c->N[k], r0 = c->r[k], r1 = c->r[k + 1], m = r0 * N;
-        double *C = cross_eval_core(c, k);
+        double *C;
+        TIMED(0, C = cross_eval_core(c, k));
         if (k == d - 1) { memcpy(t->G[k], C, m * r1 * sizeof(double)); free(C); break; }
         assert(m >= r1);
-        qr_thin(m, r1, C, NULL);
+        double *Rk = xcalloc(r1 * r1, sizeof(double));
+        TIMED(1, qr_thin(m, r1, C, Rk));
+        if (r_is_deficient(r1, Rk)) c->deficient = 1;
+        free(Rk);
         size_t *rows = xcalloc(r1, sizeof(size_t));
-        maxvol(m, r1, C, rows, t->G[k]);
+        TIMED(2, maxvol(m, r1, C, rows, t->G[k]));
         /* I_{k+1}[b] = (I_k[a], j) with row = a + r0*j */
         int *In = xcalloc(r1 * (k + 1), sizeof(int));
         for (size_t b = 0; b < r1; b++) {
@@ -603,16 +706,20 @@ static struct tt *cross_sweep_rl(struct cross *c)
     struct tt *t = tt_alloc(d, c->N, c->r);
     for (size_t k = d; k-- > 0;) {
         const size_t N = c->N[k], r0 = c->r[k], r1 = c->r[k + 1], cols = N * r1;
-        double *C = cross_eval_core(c, k);
+        double *C;
+        TIMED(0, C = cross_eval_core(c, k));
         if (k == 0) { memcpy(t->G[0], C, r0 * cols * sizeof(double)); free(C); break; }
         assert(cols >= r0);
         double *Ct = xcalloc(cols * r0, sizeof(double)); /* (N r1) x r0 */
         for (size_t cc = 0; cc < cols; cc++)
             for (size_t a = 0; a < r0; a++) Ct[cc + a * cols] = C[a + r0 * cc];
-        qr_thin(cols, r0, Ct, NULL);
+        double *Rk = xcalloc(r0 * r0, sizeof(double));
+        TIMED(1, qr_thin(cols, r0, Ct, Rk));
+        if (r_is_deficient(r0, Rk)) c->deficient = 1;
+        free(Rk);
         size_t *rows = xcalloc(r0, sizeof(size_t));
         double *B = xcalloc(cols * r0, sizeof(double));
-        maxvol(cols, r0, Ct, rows, B);
+        TIMED(2, maxvol(cols, r0, Ct, rows, B));
         for (size_t cc = 0; cc < cols; cc++)
             for (size_t a = 0; a < r0; a++) t->G[k][a + r0 * cc] = B[cc + a * cols];
         /* J_{k-1}[a] = (j, J_k[b]) with col = j + N*b */
@@ -695,38 +802,51 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     if (verbose > 0) { printf("Starting Ranks: "); for (size_t k = 0; k <= d; k++) printf("%zu ", c.r[k]); printf("\n"); }
 
     struct tt *best = NULL;
+    const double t_all = tnow();
     for (int round = 0; round < 50; round++) {
         struct tt *prev = NULL, *cur = NULL;
-        double rel = 1.0;
+        double rel = 1.0, prev2 = -1.0; /* prev2 = <prev, prev> once known */
         for (size_t it = 0; it < maxiter; it++) {
+            c.deficient = 0;
             struct tt *t1 = cross_sweep_lr(&c);
             struct tt *t2 = cross_sweep_rl(&c);
             tt_free(t1);
             tt_free(cur);
             cur = t2;
+            const double t_conv = tnow();
+            double cur2 = -1.0;
             if (prev != NULL) {
-                struct tt *df = tt_diff(cur, prev);
-                if (df->d > 1) tt_orthogonalize_rl(df);
-                const double dn = tt_frob_of_core0(df);
-                struct tt *cc = tt_copy(cur);
-                if (cc->d > 1) tt_orthogonalize_rl(cc);
-                const double cn = tt_frob_of_core0(cc);
-                tt_free(df); tt_free(cc);
-                rel = cn > 0.0 ? dn / cn : dn;
+                rel = tt_rel_change(cur, prev, prev2, &cur2, cross_tol);
                 if (verbose > 1) printf("  cross sweep %zu: relative change %.3e (fibers so far %zu)\n", it + 1, rel, c.nfibers);
             }
             tt_free(prev);
             prev = tt_copy(cur);
+            prev2 = cur2;
+            g_tc[3] += tnow() - t_conv;
             if (rel < cross_tol) break;
         }
         tt_free(prev);
         /* rounding; if a rank survives untouched and may still grow, kick it and cross again */
         struct tt *rounded = tt_copy(cur);
-        tt_round(rounded, round_tol);
+        TIMED(4, tt_round(rounded, round_tol));
         int kicked = 0;
         if (adapt == 1) {
+            /* Rounding dropped every rank, so the rule below would stop here.  If the last cross iteration worked on
+             * exactly rank-deficient fiber matrices, the drop may come from degenerate index sets (e.g. mirror-image
+             * nodes of a symmetric function picked in a null direction) and not from the function: accept only once
+             * a round with kicked ranks reproduces the result, otherwise kick every rank that can still grow. */
+            int confirm = 0;
+            if (c.deficient) {
+                int dropped = 1, room = 0;
+                for (size_t k = 1; k < d; k++) { if (rounded->r[k] >= c.r[k]) dropped = 0; if (c.r[k] < maxrank) room = 1; }
+                if (dropped && room) {
+                    double r2 = 0.0;
+                    const double accept = 10.0 * (cross_tol > round_tol ? cross_tol : round_tol);
+                    confirm = best == NULL || tt_rel_change(rounded, best, -1.0, &r2, accept) > accept;
+                }
+            }
             for (size_t k = 1; k < d; k++)
-                if (rounded->r[k] >= c.r[k] && c.r[k] < maxrank) {
+                if ((rounded->r[k] >= c.r[k] || confirm) && c.r[k] < maxrank) {
                     const size_t rn = (c.r[k] + kick) >= maxrank ? maxrank : c.r[k] + kick;
                     int *In = resize_tuples(c.I[k], c.r[k], rn, k, N, 3 + round);
                     int *Jn = resize_tuples(c.J[k - 1], c.r[k], rn, d - k, N + k, 5 + round);
@@ -744,6 +864,12 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     }
     if (verbose > 0) { printf("Final Ranks: "); for (size_t k = 0; k <= d; k++) printf("%zu ", best->r[k]); printf("\n"); }
     struct ValueF *vf = valuef_from_tt(best, grid);
+    if (getenv("C3SC_PROFILE")) {
+        g_tc[5] = tnow() - t_all;
+        fprintf(stderr, "c3sc cross profile: total %.2f ms = fibers (callback + gather) %.2f, qr %.2f, maxvol %.2f, convergence check %.2f, rounding %.2f\n",
+                1e3 * g_tc[5], 1e3 * g_tc[0], 1e3 * g_tc[1], 1e3 * g_tc[2], 1e3 * g_tc[3], 1e3 * g_tc[4]);
+    }
+    memset(g_tc, 0, sizeof(g_tc));
     {
         size_t *nl = xcalloc(d, sizeof(size_t)), *nr = xcalloc(d, sizeof(size_t));
         for (size_t k = 0; k < d; k++) { nl[k] = c.r[k]; nr[k] = c.r[k + 1]; }

@@ -436,11 +436,11 @@ int c3opt_minimize(struct c3Opt *o, double *x, double *val)
  * packed into integers instead of printed into a string: same keys (node index + iteration counters), same hits
  * and misses, ~20x cheaper than snprintf + strcmp.  Used by the index-based batch entry points the solver loops
  * drive; the string-keyed HTable (bit-identical to hashgrid.c) stays behind the coordinate-based callbacks. */
+struct FmEntry { uint64_t k[4]; double v; uint32_t epoch, pad; }; /* 48 bytes: key, value and liveness in one place */
 struct FastMemo {
     size_t cap, used; /* cap is a power of two */
-    uint64_t *keys;   /* cap x 4 */
-    double *vals;
-    unsigned char *full;
+    struct FmEntry *e;
+    uint32_t epoch;   /* entries of older epochs are empty: clearing is O(1) */
 };
 
 static uint64_t mix64(uint64_t x)
@@ -448,53 +448,63 @@ static uint64_t mix64(uint64_t x)
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
-static uint64_t key_hash(const uint64_t k[4]) { return mix64(k[0] ^ mix64(k[1] ^ mix64(k[2] ^ mix64(k[3])))); }
+/* linear in the key words before the final mix, so a fiber can advance it per node with one multiply-add */
+static const uint64_t FM_P[4] = {0x9e3779b97f4a7c15ULL, 0xc2b2ae3d27d4eb4fULL, 0x165667b19e3779f9ULL, 0xd6e8feb86659fd93ULL};
+static uint64_t key_pre(const uint64_t k[4]) { return k[0] * FM_P[0] + k[1] * FM_P[1] + k[2] * FM_P[2] + k[3] * FM_P[3]; }
 
+#define FM_CAP0 (1u << 16)
 struct FastMemo *fastmemo_create(void)
 {
     struct FastMemo *m = xmalloc(sizeof(*m));
-    m->cap = 1u << 16; m->used = 0;
-    m->keys = xmalloc(m->cap * 4 * sizeof(uint64_t));
-    m->vals = xmalloc(m->cap * sizeof(double));
-    m->full = calloc(m->cap, 1);
+    m->cap = FM_CAP0; m->used = 0; m->epoch = 1;
+    m->e = calloc(m->cap, sizeof(*m->e));
+    if (m->e == NULL) { fprintf(stderr, "c3sc: out of memory\n"); exit(1); }
     return m;
 }
-void fastmemo_free(struct FastMemo *m) { if (m) { free(m->keys); free(m->vals); free(m->full); free(m); } }
-void fastmemo_clear(struct FastMemo *m) { memset(m->full, 0, m->cap); m->used = 0; }
+void fastmemo_free(struct FastMemo *m) { if (m) { free(m->e); free(m); } }
+void fastmemo_clear(struct FastMemo *m)
+{
+    m->used = 0;
+    if (++m->epoch == 0) { memset(m->e, 0, m->cap * sizeof(*m->e)); m->epoch = 1; } /* wrapped: really empty it */
+}
 size_t fastmemo_size(const struct FastMemo *m) { return m->used; }
 
-static size_t fm_find(const struct FastMemo *m, const uint64_t k[4])
+static size_t fm_find_pre(const struct FastMemo *m, uint64_t pre, const uint64_t k[4])
 {
-    size_t i = (size_t)key_hash(k) & (m->cap - 1);
-    while (m->full[i] && memcmp(m->keys + 4 * i, k, 4 * sizeof(uint64_t)) != 0) i = (i + 1) & (m->cap - 1);
+    size_t i = (size_t)mix64(pre) & (m->cap - 1);
+    while (m->e[i].epoch == m->epoch && memcmp(m->e[i].k, k, 4 * sizeof(uint64_t)) != 0) i = (i + 1) & (m->cap - 1);
     return i;
+}
+static void fm_put_pre(struct FastMemo *m, uint64_t pre, const uint64_t k[4], double val);
+static void fm_grow(struct FastMemo *m)
+{
+    struct FastMemo old = *m;
+    m->cap *= 2; m->used = 0; m->epoch = 1;
+    m->e = calloc(m->cap, sizeof(*m->e));
+    if (m->e == NULL) { fprintf(stderr, "c3sc: out of memory\n"); exit(1); }
+    for (size_t i = 0; i < old.cap; i++)
+        if (old.e[i].epoch == old.epoch) fm_put_pre(m, key_pre(old.e[i].k), old.e[i].k, old.e[i].v);
+    free(old.e);
+}
+static void fm_put_pre(struct FastMemo *m, uint64_t pre, const uint64_t k[4], double val)
+{ /* like htable_add_element, a repeated key is not checked by the callers; here the first value stays */
+    if (2 * (m->used + 1) > m->cap) fm_grow(m);
+    struct FmEntry *e = &m->e[fm_find_pre(m, pre, k)];
+    if (e->epoch == m->epoch) return;
+    memcpy(e->k, k, 4 * sizeof(uint64_t));
+    e->v = val;
+    e->epoch = m->epoch;
+    m->used++;
 }
 int fastmemo_get(const struct FastMemo *m, const uint64_t k[4], double *val)
 {
-    const size_t i = fm_find(m, k);
-    if (!m->full[i]) return 0;
-    *val = m->vals[i];
+    const struct FmEntry *e = &m->e[fm_find_pre(m, key_pre(k), k)];
+    if (e->epoch != m->epoch) return 0;
+    *val = e->v;
     return 1;
 }
-void fastmemo_put(struct FastMemo *m, const uint64_t k[4], double val)
-{ /* like htable_add_element, a repeated key is not checked by the callers; here the first value stays */
-    if (2 * (m->used + 1) > m->cap) {
-        struct FastMemo old = *m;
-        m->cap *= 2; m->used = 0;
-        m->keys = xmalloc(m->cap * 4 * sizeof(uint64_t));
-        m->vals = xmalloc(m->cap * sizeof(double));
-        m->full = calloc(m->cap, 1);
-        for (size_t i = 0; i < old.cap; i++)
-            if (old.full[i]) fastmemo_put(m, old.keys + 4 * i, old.vals[i]);
-        free(old.keys); free(old.vals); free(old.full);
-    }
-    const size_t i = fm_find(m, k);
-    if (m->full[i]) return;
-    memcpy(m->keys + 4 * i, k, 4 * sizeof(uint64_t));
-    m->vals[i] = val;
-    m->full[i] = 1;
-    m->used++;
-}
+void fastmemo_put(struct FastMemo *m, const uint64_t k[4], double val) { fm_put_pre(m, key_pre(k), k, val); }
+
 /* grid multi-index (16 bits per dimension, d <= 12) + two counters */
 void fastmemo_key(size_t d, const int32_t *idx, size_t kdim, size_t j, uint64_t c0, uint64_t c1, uint64_t key[4])
 {
@@ -504,6 +514,37 @@ void fastmemo_key(size_t d, const int32_t *idx, size_t kdim, size_t j, uint64_t 
         key[m / 4] |= v << (16 * (m % 4));
     }
     key[3] = (c0 << 32) ^ c1;
+}
+
+/* the nodes of one fiber: the key and its pre-hash are built once, each node patches the 16 bits of the varying
+ * dimension and adds j * (that field's weight) to the pre-hash */
+void fastmemo_fiber_begin(struct FmFiber *ff, size_t d, const int32_t *idx, size_t kdim, uint64_t c0, uint64_t c1)
+{
+    fastmemo_key(d, idx, kdim, 0, c0, c1, ff->key);
+    ff->word = (unsigned)(kdim / 4);
+    ff->shift = (unsigned)(16 * (kdim % 4));
+    ff->base = ff->key[ff->word];
+    ff->pre0 = key_pre(ff->key);
+    ff->step = FM_P[ff->word] << ff->shift;
+}
+void fastmemo_fiber_counter(struct FmFiber *ff, uint64_t c0, uint64_t c1)
+{ /* change the two counters of the current fiber (e.g. the component of a stored vector) */
+    const uint64_t nw = (c0 << 32) ^ c1;
+    ff->pre0 += (nw - ff->key[3]) * FM_P[3];
+    ff->key[3] = nw;
+}
+int fastmemo_fiber_get(const struct FastMemo *m, struct FmFiber *ff, size_t j, double *val)
+{
+    ff->key[ff->word] = ff->base | ((uint64_t)(j & 0xffffu) << ff->shift);
+    const struct FmEntry *e = &m->e[fm_find_pre(m, ff->pre0 + (uint64_t)(j & 0xffffu) * ff->step, ff->key)];
+    if (e->epoch != m->epoch) return 0;
+    *val = e->v;
+    return 1;
+}
+void fastmemo_fiber_put(struct FastMemo *m, struct FmFiber *ff, size_t j, double val)
+{
+    ff->key[ff->word] = ff->base | ((uint64_t)(j & 0xffffu) << ff->shift);
+    fm_put_pre(m, ff->pre0 + (uint64_t)(j & 0xffffu) * ff->step, ff->key, val);
 }
 
 /* ------------------------------------------------------------------------------ Workspace */

@@ -101,6 +101,12 @@ size_t fastmemo_size(const struct FastMemo *);
 int fastmemo_get(const struct FastMemo *, const uint64_t key[4], double *val);
 void fastmemo_put(struct FastMemo *, const uint64_t key[4], double val);
 void fastmemo_key(size_t d, const int32_t *idx, size_t kdim, size_t j, uint64_t c0, uint64_t c1, uint64_t key[4]);
+/* the same keys for the nodes j of one fiber along kdim, built incrementally */
+struct FmFiber { uint64_t key[4], base, pre0, step; unsigned word, shift; };
+void fastmemo_fiber_begin(struct FmFiber *ff, size_t d, const int32_t *idx, size_t kdim, uint64_t c0, uint64_t c1);
+void fastmemo_fiber_counter(struct FmFiber *ff, uint64_t c0, uint64_t c1);
+int fastmemo_fiber_get(const struct FastMemo *, struct FmFiber *ff, size_t j, double *val);
+void fastmemo_fiber_put(struct FastMemo *, struct FmFiber *ff, size_t j, double val);
 struct FastMemo *workspace_get_vi_fastmemo(const struct Workspace *);
 struct FastMemo *workspace_get_pi_prob_fastmemo(const struct Workspace *);
 /* new: the MI355X engine this workspace drives (created on first use; aborts if no GPU) */

@@ -133,3 +133,58 @@ def test_continuous_norms_and_offgrid_eval():
     assert L.valuef_norm2diff(vb, vb2) == pytest.approx(1e-9 * exact, rel=1e-4)
     for v in (vf, vb, vb2):
         L.valuef_destroy(v)
+
+
+def test_rank_adaptation_survives_degenerate_index_sets(oracle):
+    """T(V0) of the symmetric 2-D LQG problem has mirror-image rows and columns, so a cross step at a rank above the
+    number of distinct ones factors an exactly rank-deficient matrix and picks pivots in null directions; rounding then
+    drops a rank although the function needs more, and which way it goes depends on rounding noise in the fiber values.
+    The driver must not stop there: with 1e-16 relative noise on the fiber values every run has to reach the rounding
+    accuracy at all nodes (CPU only: fibers from the oracle)."""
+    sys.path.insert(0, ROOT)
+    from c3sc_amd import workloads as wl
+
+    w = wl.c1_lqg2d().scaled(ngrid=(19, 17))
+    import facade_lib as fl
+
+    L = fl.lib()
+    for n in ("valuef_interp", "valuef_create_nodal"):
+        getattr(L, n).restype = C.c_void_p
+    L.valuef_eval_ind.restype = C.c_double
+    L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+    cores = [np.full((w.ngrid[0], 1), 0.2), np.ones((w.ngrid[1], 1))]
+    wr = wl.Workload(w.name, w.model, w.params, w.dx, w.du, w.lb, w.ub, w.ngrid, (1, 1, 1), w.discount, w.bc, list(w.obstacles), w.cands)
+    P = oracle.Problem(wr, cores)
+    idx = np.zeros((w.ngrid[1], 2), dtype=np.int32)
+    idx[:, 1] = np.arange(w.ngrid[1])
+    want = P.bellman_fibers(0, idx)[0].T  # T(V0) at every node
+    xg = [np.linspace(w.lb[m], w.ub[m], w.ngrid[m]) for m in range(2)]
+    gs = [fl.f64(g) for g in xg]
+    gp = fl.ptrs(gs)
+    Ng = np.array(w.ngrid, dtype=np.uintp)
+    v0 = C.c_void_p(L.valuef_create_nodal(C.c_size_t(2), fl.sp(Ng), fl.sp(np.array([1, 1, 1], dtype=np.uintp)), fl.ptrs([fl.f64(c) for c in cores])))
+    worst = 0.0
+    for seed in range(8):
+        rng = np.random.default_rng(seed)
+
+        def fiber(n, x, out, a):
+            X = np.ctypeslib.as_array(x, shape=(n, 2)).copy()
+            v = P.bellman_vi(X, use_memo=False)[0]
+            np.ctypeslib.as_array(out, shape=(n,))[:] = v * (1.0 + 1e-16 * rng.standard_normal(n))
+            return 0
+
+        cb = FIBER_FN(fiber)
+        aa = C.c_void_p(L.approx_args_init())
+        L.approx_args_set_cross_tol(aa, C.c_double(1e-10))
+        L.approx_args_set_round_tol(aa, C.c_double(1e-9))
+        L.approx_args_set_kickrank(aa, C.c_size_t(3))
+        L.approx_args_set_startrank(aa, C.c_size_t(3))
+        L.approx_args_set_maxrank(aa, C.c_size_t(17))
+        vf = C.c_void_p(L.valuef_interp(C.c_size_t(2), cb, None, fl.sp(Ng), gp, v0, aa, 0))  # warm start from rank 1, as step_vi does
+        got = np.array([[L.valuef_eval_ind(vf, fl.sp(np.array([i, j], dtype=np.uintp))) for j in range(w.ngrid[1])] for i in range(w.ngrid[0])])
+        worst = max(worst, np.abs(got - want).max())
+        L.valuef_destroy(vf)
+        L.approx_args_free(aa)
+    L.valuef_destroy(v0)
+    print("worst nodal error over noise seeds:", worst)
+    assert worst <= 2e-8 * np.abs(want).max()

@@ -265,6 +265,56 @@ def test_old_assembly_dyn_pair_and_periodic_wrap(oracle):
     assert dg.value is None
 
 
+def test_integer_memo_fiber_keys_agree_with_node_keys():
+    """The integer-keyed twin of the node memo: a node stored through a fiber along one dimension is found through a
+    fiber along another and through the plain per-node key (the property the string keys of bellman.c:1333-1344 have);
+    growth keeps every entry; clearing forgets them."""
+    import facade_lib
+
+    L = facade_lib.lib()
+    L.fastmemo_create.restype = C.c_void_p
+    L.fastmemo_size.restype = C.c_size_t
+
+    class FmFiber(C.Structure):
+        _fields_ = [("key", C.c_uint64 * 4), ("base", C.c_uint64), ("pre0", C.c_uint64), ("step", C.c_uint64), ("word", C.c_uint), ("shift", C.c_uint)]
+
+    m = C.c_void_p(L.fastmemo_create())
+    rng = np.random.default_rng(5)
+    d, N = 7, 41
+    ff, key, val = FmFiber(), (C.c_uint64 * 4)(), C.c_double(0)
+    truth = {}
+    for _ in range(4000):  # 4000 x 41 nodes: several doublings of the initial 65536 slots
+        idx = rng.integers(0, N, d).astype(np.int32)
+        k = int(rng.integers(0, d))
+        L.fastmemo_fiber_begin(C.byref(ff), C.c_size_t(d), idx.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(k), C.c_uint64(0), C.c_uint64(3))
+        for j in range(N):
+            node = tuple(int(v) for v in idx[:k]) + (j,) + tuple(int(v) for v in idx[k + 1:])
+            v = float(rng.standard_normal())
+            L.fastmemo_fiber_put(m, C.byref(ff), C.c_size_t(j), C.c_double(v))
+            truth.setdefault(node, v)  # a repeated key keeps its first value
+    assert L.fastmemo_size(m) == len(truth)
+    nodes = list(truth)
+    for t in rng.permutation(len(nodes))[:3000]:
+        node = nodes[t]
+        idx = np.array(node, dtype=np.int32)
+        k = int(rng.integers(0, d))  # look it up along any dimension
+        L.fastmemo_fiber_begin(C.byref(ff), C.c_size_t(d), idx.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(k), C.c_uint64(0), C.c_uint64(3))
+        assert L.fastmemo_fiber_get(m, C.byref(ff), C.c_size_t(node[k]), C.byref(val)) == 1 and val.value == truth[node]
+        L.fastmemo_key(C.c_size_t(d), idx.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(k), C.c_size_t(node[k]), C.c_uint64(0), C.c_uint64(3), key)
+        assert L.fastmemo_get(m, key, C.byref(val)) == 1 and val.value == truth[node]
+        # another counter is another key
+        L.fastmemo_fiber_counter(C.byref(ff), C.c_uint64(0), C.c_uint64(4))
+        assert L.fastmemo_fiber_get(m, C.byref(ff), C.c_size_t(node[k]), C.byref(val)) == 0
+    L.fastmemo_clear(m)
+    assert L.fastmemo_size(m) == 0
+    idx = np.array(nodes[0], dtype=np.int32)
+    L.fastmemo_key(C.c_size_t(d), idx.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(0), C.c_size_t(nodes[0][0]), C.c_uint64(0), C.c_uint64(3), key)
+    assert L.fastmemo_get(m, key, C.byref(val)) == 0
+    L.fastmemo_put(m, key, C.c_double(2.5))
+    assert L.fastmemo_get(m, key, C.byref(val)) == 1 and val.value == 2.5 and L.fastmemo_size(m) == 1
+    L.fastmemo_free(m)
+
+
 def _callbacks(w):
     """Host callbacks with the reference's signatures, evaluated in Python (dubins: dubinscar.c:40-121)."""
     import math

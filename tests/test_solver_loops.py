@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 FIBER_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 
-def _setup(w, maxrank=12):
+def _setup(w, maxrank=12, startrank=3, round_tol=1e-9):
     import facade_lib
 
     L = facade_lib.lib()
@@ -32,9 +32,9 @@ def _setup(w, maxrank=12):
     ctl = facade_lib.Control(w)
     aa = C.c_void_p(L.approx_args_init())
     L.approx_args_set_cross_tol(aa, C.c_double(1e-10))
-    L.approx_args_set_round_tol(aa, C.c_double(1e-9))
+    L.approx_args_set_round_tol(aa, C.c_double(round_tol))
     L.approx_args_set_kickrank(aa, C.c_size_t(3))
-    L.approx_args_set_startrank(aa, C.c_size_t(3))
+    L.approx_args_set_startrank(aa, C.c_size_t(startrank))
     L.approx_args_set_maxrank(aa, C.c_size_t(maxrank))
     return L, facade_lib, ctl, aa
 
@@ -54,8 +54,10 @@ def _all_values(L, fl, vf, w):
 
 
 def test_value_iteration_gpu_path_matches_cpu_path(oracle):
-    # maxrank >= min N: the cross approximation can become exact, so the two paths may only differ by rounding
-    # (with a truncated rank they differ by the truncation error, through pivot choices -- not a parity statement)
+    # maxrank >= min N: rank adaptation runs until rounding (1e-9) drops a rank, so the two paths agree to the
+    # truncation error whatever pivots they pick (1e-16 differences in the fiber values can flip pivot choices; the
+    # driver's confirmation round keeps such a flip from ending the adaptation early, see
+    # test_cross_driver.py::test_rank_adaptation_survives_degenerate_index_sets)
     w = wl.c1_lqg2d().scaled(ngrid=(19, 17))
     L, fl, ctl, aa = _setup(w, maxrank=17)
     const = FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.2), 0)[1])
@@ -92,8 +94,8 @@ def test_value_iteration_gpu_path_matches_cpu_path(oracle):
         assert ne.value > 0
     a, b = _all_values(L, fl, v_gpu, w), _all_values(L, fl, v_cpu, w)
     print("gpu-vs-cpu path, max nodal difference after 4 sweeps:", np.abs(a - b).max(), "scale", np.abs(b).max())
-    assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
-    assert L.valuef_norm2diff(v_gpu, v_cpu) <= 1e-6 * L.valuef_norm(v_cpu)
+    assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max())  # SURVEY 8d (iii) asks for 1e-6
+    assert L.valuef_norm2diff(v_gpu, v_cpu) <= 1e-7 * L.valuef_norm(v_cpu)
     L.valuef_destroy(v_gpu)
     L.valuef_destroy(v_cpu)
     L.approx_args_free(aa)

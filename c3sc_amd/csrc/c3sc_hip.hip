@@ -834,7 +834,7 @@ int c3sc_hip_get_status(c3sc_hip_ctx *c, unsigned *flags, int clear)
     if (!c || !flags) return C3SC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(flags, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (clear) HIPCHK(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
+    if (clear && *flags) HIPCHK(c, hipMemset(c->d_status, 0, sizeof(unsigned))); /* nothing to clear otherwise */
     return C3SC_OK;
 }
 

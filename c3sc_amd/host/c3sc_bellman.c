@@ -835,14 +835,21 @@ size_t pi_param_get_niter_node_evals(const struct PIparam *p) { return p->niter_
  * which the device recomputes the rates.  Counters follow the reference: every node of every call counts as an
  * iteration evaluation (its value memo is never filled -- SURVEY.md 9 Q2; the lookup is kept, the mis-keyed 1-element
  * entries it pushes into the prob table are not), npol_evals counts nodes whose policy had to be computed. */
+static double g_tp[4]; /* C3SC_PROFILE: core upload, flags + policy cache lookup, policy pass, evaluation pass */
+static size_t g_np;
+
 static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, const double *x_in, double *out, int fast)
 {
     struct ControlParams *cp = pi->cp;
     struct MCAparam *mca = cp->mca;
     struct DPparam *dp = cp->dp;
     const size_t dx = mca->dx, N = mca->ngrid[k0];
+    const double t_sync = now_s();
     struct c3sc_hip_ctx *ctx_it = sync_device_ctx(cp, workspace_get_hip_ctx(cp->work), pi->vf_iteration);
     struct c3sc_hip_ctx *ctx_pol = sync_device_ctx(cp, workspace_get_hip_ctx_policy(cp->work), pi->vf_policy);
+    const double t_begin = now_s();
+    g_tp[0] += t_begin - t_sync;
+    g_np++;
     struct HTable *ht_prob = workspace_get_pi_prob_htable(cp->work), *ht_iter = workspace_get_pi_htable(cp->work);
     struct FastMemo *fm = workspace_get_pi_prob_fastmemo(cp->work);
     size_t *ser = workspace_get_ind_to_serialize(cp->work);
@@ -903,6 +910,8 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
         costs2 = xcalloc(F * N * 2, sizeof(double));
         for (size_t f = 0; f < F; f++) eval_callback_tables(cp, k0, idx + f * dx, N, x + f * N * dx, tables + f * N * U * S, costs2 + f * N * 2);
     }
+    const double t_looked = now_s();
+    g_tp[1] += t_looked - t_begin;
     /* policy pass: fibers with a node whose policy is not cached yet -> greedy control for vf_policy (:1832-1846) */
     size_t nrun = 0;
     for (size_t f = 0; f < F; f++) nrun += need[f];
@@ -959,6 +968,8 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
         }
         free(ridx); free(rui); free(rout); free(ruo);
     }
+    const double t_pol = now_s();
+    g_tp[2] += t_pol - t_looked;
     /* evaluation pass on vf_iteration with the policy applied (:1807-1815, :1857-1865) */
     double *eout = xcalloc(F * N, sizeof(double));
     int32_t *policy = xcalloc(F * N, sizeof(int32_t));
@@ -975,6 +986,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
     if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
     for (size_t i = 0; i < F * N; i++)
         if (!stored[i]) out[i] = eout[i];
+    g_tp[3] += now_s() - t_pol;
     free(eout); free(tables); free(costs2); free(x_own);
     free(policy); free(polv); free(absorbed); free(nv); free(need); free(stored); free(miss); free(has);
     return 0;
@@ -1107,6 +1119,11 @@ void c3control_begin_pi_step(struct C3Control *c, struct PIparam *pi, struct Val
 
 void c3control_end_pi_step(struct C3Control *c, struct PIparam *pi, size_t *niter_evals)
 {
+    if (getenv("C3SC_PROFILE")) {
+        fprintf(stderr, "c3sc profile (policy evaluation): %zu batch calls, core upload %.2f ms, flags + policy cache %.2f ms, policy pass %.2f ms, evaluation pass %.2f ms\n",
+                g_np, 1e3 * g_tp[0], 1e3 * g_tp[1], 1e3 * g_tp[2], 1e3 * g_tp[3]);
+        g_np = 0; memset(g_tp, 0, sizeof(g_tp));
+    }
     if (niter_evals) *niter_evals = pi->niter_node_evals;
     control_params_destroy(c->cp_active);
     c->cp_active = NULL;

@@ -476,7 +476,9 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         // the winner -- nine dependent f64 divisions per node are the longest chain of the scan otherwise.
         // Scan order and strict '<' are kept; a different winner is possible only between candidates whose
         // values agree to rounding.
-        double bnum = 0.0, bq = 1.0;
+        // best so far as the fraction bnum/bq; +inf loses to the first candidate that is not skipped
+        double bnum = __builtin_inf(), bq = 1.0;
+        bool anybad = false;
         constexpr unsigned UCm = Model::UCONST_MASK;
         constexpr bool ALLC = (UCm == UM) && !Model::STAGE_UDEP && Model::NCF == 0; // nothing per candidate needs x
         // CGD candidates per trip: one candidate is a chain of ~10 dependent f64 operations and with two
@@ -541,18 +543,19 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
             for (int q = 0; q < CGD; q++) {
                 if (CGD == 1 || c0 + q < nc) { // wave-uniform
                     const bool okc = !(Qq[q] < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
-                    if (!okc & (ab == 0)) st |= C3SC_STATUS_STATIONARY;
+                    anybad |= !okc;
                     double lhs = numq[q] * bq, rhs = bnum * Qq[q];
                     pin_vgpr(lhs); // evaluated unconditionally: the compiler must not wrap them in a divergent branch
                     pin_vgpr(rhs);
                     const bool better = lhs < rhs;
-                    const bool take = okc & (forced ? (c0 + q == fu) : ((ui < 0) | better));
+                    const bool take = okc & (forced ? (c0 + q == fu) : better);
                     bnum = take ? numq[q] : bnum;
                     bq = take ? Qq[q] : bq;
                     ui = take ? c0 + q : ui;
                 }
             }
         }
+        if (anybad & (ab == 0)) st |= C3SC_STATUS_STATIONARY;
         {
             const double inv = 1.0 / bq;
             const double pself = fma(-bq, inv, 1.0);

@@ -158,11 +158,11 @@ def main():
     traffic, traffic_src = None, None
     try:
         if args.workload == "car7d" and F == (1 << 17):
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_e_fiber_pair_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_fiber_pair_pmc.json")))
             ks = [v for kname, v in pm["kernels"].items() if "k_fiber_pair" in kname]
             if ks and "fiber_pair" in eng.last_kernel():
                 traffic = float(np.mean([v["fetch_bytes_x2_gfx950_correction"] + v["write_bytes_per_launch"] for v in ks]))
-                traffic_src = "profiles/r01_e_fiber_pair_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2)"
+                traffic_src = "profiles/r01_f_fiber_pair_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2)"
     except (OSError, KeyError, ValueError):
         pass
     kern = eng.last_kernel()

@@ -110,6 +110,9 @@ struct ValueF *valuef_copy(struct ValueF *vf)
     return c;
 }
 size_t *valuef_get_ranks(struct ValueF *vf) { return vf->ranks; }
+/* valuefunc.c:218-221 hands out C3's left cross-index sets; here the handle is this library's own tuple sets
+ * (isl[k]: nisl[k] tuples over dims 0..k-1, or NULL before the first interpolation) -- opaque to callers */
+struct CrossIndex **valuef_get_isl(const struct ValueF *vf) { return (struct CrossIndex **)vf->isl; }
 size_t valuef_get_dim(const struct ValueF *vf) { return vf->d; }
 const size_t *valuef_get_N(const struct ValueF *vf) { return vf->N; }
 double **valuef_get_cores(struct ValueF *vf) { return vf->cores; }

@@ -111,6 +111,90 @@ double outer_bound_dim(const struct Boundary *b, size_t dim, double x, int *map)
     return x;
 }
 
+/* ---- BoundInfo: where a state sits relative to the faces and obstacles (boundary.c:491-801) */
+struct BoundInfo {
+    size_t d;
+    enum BOUNDRESULT *br;
+    enum EBTYPE *type;
+    double *xmap;       /* periodic images */
+    int absorb_overall; /* on an absorbing face or inside an obstacle */
+    int in_obstacle;    /* index of the obstacle, -1 if none */
+};
+
+struct BoundInfo *bound_info_alloc(size_t d)
+{
+    struct BoundInfo *bi = xmalloc(sizeof(*bi));
+    bi->d = d;
+    bi->br = xmalloc(d * sizeof(*bi->br));
+    bi->type = xmalloc(d * sizeof(*bi->type));
+    bi->xmap = xmalloc(d * sizeof(double));
+    for (size_t i = 0; i < d; i++) { bi->br[i] = IN; bi->type[i] = EB_NONE; bi->xmap[i] = 0.0; }
+    bi->absorb_overall = 0;
+    bi->in_obstacle = -1;
+    return bi;
+}
+void bound_info_free(struct BoundInfo *bi)
+{
+    if (bi == NULL) return;
+    free(bi->br); free(bi->type); free(bi->xmap); free(bi);
+}
+int bound_info_set_dim(struct BoundInfo *bi, enum BOUNDRESULT br, enum EBTYPE type, size_t dim)
+{ /* boundary.c:550-565: 1 = periodic, the caller still owes the image; -1 = unknown type */
+    bi->br[dim] = br;
+    bi->type[dim] = type;
+    if (type == ABSORB) bi->absorb_overall = 1;
+    else if (type == PERIODIC) return 1;
+    else if (type != EB_NONE && type != REFLECT) return -1;
+    return 0;
+}
+int bound_info_set_xmap_dim(struct BoundInfo *bi, double x, size_t dim) { bi->xmap[dim] = x; return 0; }
+int bound_info_onbound(const struct BoundInfo *bi)
+{
+    if (bi->in_obstacle > -1) return 1;
+    for (size_t i = 0; i < bi->d; i++) if (bi->br[i] != IN) return 1;
+    return 0;
+}
+int bound_info_onbound_dim(const struct BoundInfo *bi, size_t dim) { return bi->in_obstacle > -1 || bi->br[dim] != IN; }
+int bound_info_absorb(const struct BoundInfo *bi) { return bi->absorb_overall == 1; }
+static int on_face_of_type(const struct BoundInfo *bi, enum EBTYPE t)
+{
+    for (size_t i = 0; i < bi->d; i++) if (bi->br[i] != IN && bi->type[i] == t) return 1;
+    return 0;
+}
+int bound_info_period(const struct BoundInfo *bi) { return on_face_of_type(bi, PERIODIC); }
+int bound_info_reflect(const struct BoundInfo *bi) { return on_face_of_type(bi, REFLECT); }
+int bound_info_period_dim_dir(const struct BoundInfo *bi, size_t dim)
+{ /* -1 on the left face, 1 otherwise, 0 if the dimension is not periodic (boundary.c:746-757) */
+    if (bi->type[dim] != PERIODIC) return 0;
+    return bi->br[dim] == LEFT ? -1 : 1;
+}
+int bound_info_reflect_dim_dir(const struct BoundInfo *bi, size_t dim)
+{
+    if (bi->type[dim] != REFLECT) return 0;
+    return bi->br[dim] == LEFT ? -1 : 1;
+}
+double bound_info_period_xmap(const struct BoundInfo *bi, size_t dim) { return bi->xmap[dim]; }
+int bound_info_get_in_obstacle(const struct BoundInfo *bi) { return bi->in_obstacle; }
+
+static int in_box(const struct Box *bx, size_t d, const double *x)
+{
+    for (size_t m = 0; m < d; m++) if (x[m] < bx->lb[m] || x[m] > bx->ub[m]) return 0;
+    return 1;
+}
+
+struct BoundInfo *boundary_type(const struct Boundary *b, double time, const double *x)
+{ /* boundary.c:619-662: faces are closed (x <= lo, x >= hi), the first obstacle containing x wins */
+    (void)time;
+    struct BoundInfo *bi = bound_info_alloc(b->d);
+    for (size_t m = 0; m < b->d; m++) {
+        if (x[m] <= b->lo[m]) { if (bound_info_set_dim(bi, LEFT, b->type[m], m) == 1) bi->xmap[m] = b->hi[m]; }
+        else if (x[m] >= b->hi[m]) { if (bound_info_set_dim(bi, RIGHT, b->type[m], m) == 1) bi->xmap[m] = b->lo[m]; }
+    }
+    for (size_t i = 0; i < b->nobs; i++)
+        if (in_box(&b->obs[i], b->d, x)) { bi->in_obstacle = (int)i; bi->absorb_overall = 1; break; }
+    return bi;
+}
+
 int boundary_in_obstacle(const struct Boundary *b, const double *x)
 {
     for (size_t i = 0; i < b->nobs; i++) {
@@ -547,6 +631,151 @@ void fastmemo_fiber_put(struct FastMemo *m, struct FmFiber *ff, size_t j, double
     fm_put_pre(m, ff->pre0 + (uint64_t)(j & 0xffffu) * ff->step, ff->key, val);
 }
 
+/* ------------------------------------------------------------------------------ small helpers of util.h */
+int c3sc_check_bounds(size_t dx, double *lbx, double *ubx, const double *x)
+{ /* util.c:225-241: 0 inside (or no bounds), -(i+1) below the lower bound of dim i, +(i+1) above its upper bound */
+    if (lbx == NULL || ubx == NULL) return 0;
+    for (size_t i = 0; i < dx; i++) {
+        if (x[i] < lbx[i]) return -(int)(i + 1);
+        if (x[i] > ubx[i]) return (int)(i + 1);
+    }
+    return 0;
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+    const double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+double *c3sc_combine_and_sort(size_t Nx, double *x, size_t Ny, double *y, size_t *Ntot)
+{ /* util.c:254-274: sorted union, values within 1e-15 of the last kept one are dropped; the caller frees */
+    const size_t n = Nx + Ny;
+    double *all = xmalloc((n ? n : 1) * sizeof(double));
+    if (Nx) memcpy(all, x, Nx * sizeof(double));
+    if (Ny) memcpy(all + Nx, y, Ny * sizeof(double));
+    qsort(all, n, sizeof(double), cmp_double);
+    size_t kept = 0;
+    for (size_t i = 0; i < n; i++)
+        if (kept == 0 || fabs(all[i] - all[kept - 1]) > 1e-15) all[kept++] = all[i];
+    for (size_t i = kept; i < n; i++) all[i] = 0.0;
+    *Ntot = kept;
+    return all;
+}
+
+struct ProbInd { double p; size_t ind; };
+static int cmp_probind(const void *a, const void *b)
+{
+    const double x = ((const struct ProbInd *)a)->p, y = ((const struct ProbInd *)b)->p;
+    return (x > y) - (x < y);
+}
+
+size_t c3sc_sample_discrete_rv(size_t n, double *probs, double sample)
+{ /* util.c:299-331: sort ascending, overwrite probs with the running sums, first bin whose sum reaches the sample */
+    if (n > 1000) { fprintf(stderr, "Not enough memory allocate in discrete_sample\n"); exit(1); }
+    struct ProbInd sc[1000];
+    for (size_t i = 0; i < n; i++) { sc[i].p = probs[i]; sc[i].ind = i; }
+    qsort(sc, n, sizeof(sc[0]), cmp_probind);
+    double run = 0.0;
+    for (size_t i = 0; i < n; i++) { run = (i == 0) ? sc[0].p : sc[i].p + run; probs[i] = run; }
+    for (size_t i = 0; i < n; i++) if (sample <= probs[i]) return sc[i].ind;
+    fprintf(stderr, "Warning: problem with gen. sample\nUniform sample is %G\n", sample);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------ HashGrid: grid value -> node index
+ * (util.c:352-657).  The reference keys on C3's text serialisation of the double, i.e. on the exact value; here the
+ * key is the bit pattern (-0.0 folded into +0.0), chained per bucket like the original. */
+struct HGNode { uint64_t bits; size_t ind; struct HGNode *next; };
+struct HashGrid { size_t size; struct HGNode **table; };
+
+static uint64_t hg_bits(double v)
+{
+    if (v == 0.0) v = 0.0;
+    uint64_t b;
+    memcpy(&b, &v, sizeof(b));
+    return b;
+}
+
+struct HashGrid *hash_grid_create(size_t size)
+{
+    if (size < 1) return NULL;
+    struct HashGrid *h = xmalloc(sizeof(*h));
+    h->size = size;
+    h->table = xcalloc(size, sizeof(*h->table));
+    return h;
+}
+void hash_grid_free(struct HashGrid *h)
+{
+    if (h == NULL) return;
+    for (size_t i = 0; i < h->size; i++)
+        for (struct HGNode *n = h->table[i]; n != NULL;) { struct HGNode *nx = n->next; free(n); n = nx; }
+    free(h->table);
+    free(h);
+}
+static struct HGNode *hg_find(const struct HashGrid *h, uint64_t bits)
+{
+    for (struct HGNode *n = h->table[mix64(bits) % h->size]; n != NULL; n = n->next)
+        if (n->bits == bits) return n;
+    return NULL;
+}
+int hash_grid_add_element(struct HashGrid *h, size_t ind, double val)
+{ /* 0 added, 2 the value is already there (util.c:527-563) */
+    const uint64_t bits = hg_bits(val);
+    if (hg_find(h, bits) != NULL) return 2;
+    struct HGNode *n = xmalloc(sizeof(*n));
+    n->bits = bits; n->ind = ind;
+    struct HGNode **head = &h->table[mix64(bits) % h->size];
+    n->next = *head;
+    *head = n;
+    return 0;
+}
+size_t hash_grid_get_ind(struct HashGrid *h, double val, int *exists)
+{ /* index of the value, *exists = 1; a missing value gives 0 with *exists = 0 (util.c:589-615) */
+    const struct HGNode *n = hg_find(h, hg_bits(val));
+    *exists = n != NULL;
+    return n ? n->ind : 0;
+}
+struct HashGrid *hash_grid_create_grid(size_t size, const struct c3Vector *grid)
+{
+    struct HashGrid *h = hash_grid_create(size);
+    for (size_t i = 0; h != NULL && i < grid->size; i++) hash_grid_add_element(h, i, grid->elem[i]);
+    return h;
+}
+struct HashGrid **hash_grid_create_ndgrid(size_t size, size_t d, struct c3Vector **grid)
+{
+    struct HashGrid **hs = xcalloc(d, sizeof(*hs));
+    for (size_t m = 0; m < d; m++) hs[m] = hash_grid_create_grid(size, grid[m]);
+    return hs;
+}
+void hash_grid_free_ndgrid(size_t d, struct HashGrid **hs)
+{
+    if (hs == NULL) return;
+    for (size_t m = 0; m < d; m++) hash_grid_free(hs[m]);
+    free(hs);
+}
+int hash_grid_ndgrid_get_ind(struct HashGrid **hs, size_t dim, const double *x, size_t *out)
+{ /* 0 every coordinate found, 1 otherwise (stops at the first miss, util.c:623-641) */
+    for (size_t m = 0; m < dim; m++) {
+        int ok = 0;
+        out[m] = hash_grid_get_ind(hs[m], x[m], &ok);
+        if (!ok) return 1;
+    }
+    return 0;
+}
+void hash_grid_print(struct HashGrid *h, FILE *fp)
+{ /* one line per occupied bucket (util.c:566-580) */
+    for (size_t i = 0; i < h->size; i++) {
+        if (h->table[i] == NULL) continue;
+        for (const struct HGNode *n = h->table[i]; n != NULL; n = n->next) {
+            double v;
+            memcpy(&v, &n->bits, sizeof(v));
+            fprintf(fp, "ind=%zu,val = %3.15G ", i, v);
+        }
+        fprintf(fp, "\n");
+    }
+}
+
 /* ------------------------------------------------------------------------------ Workspace */
 struct Workspace {
     size_t dx, du, dw, N;
@@ -554,6 +783,7 @@ struct Workspace {
     double *slab;   /* N nodes x off[10] doubles */
     double *costs;  /* N x (2dx+1) */
     int *absorbed;
+    size_t *absorbed_no, *absorbed_yes; /* util.c:702-703: index lists nobody reads any more */
     size_t *ind_to_serialize;
     struct HTable *vi_htable;
     size_t vi_iter;
@@ -577,6 +807,8 @@ struct Workspace *workspace_alloc(size_t dx, size_t du, size_t dw, size_t N)
     w->slab = xmalloc(N * w->off[10] * sizeof(double));
     w->costs = xmalloc(N * (2 * dx + 1) * sizeof(double));
     w->absorbed = xmalloc(N * sizeof(int));
+    w->absorbed_no = xcalloc(N, sizeof(size_t));
+    w->absorbed_yes = xcalloc(N, sizeof(size_t));
     w->ind_to_serialize = xmalloc((dx + 3) * sizeof(size_t));
     w->vi_htable = htable_create(NBUCKET);
     w->keys = xmalloc(N * sizeof(char *));
@@ -597,7 +829,7 @@ void workspace_free(struct Workspace *w)
     htable_destroy(w->pi_prob_htable); htable_destroy(w->pi_htable);
     fastmemo_free(w->vi_fast); fastmemo_free(w->pi_prob_fast);
     if (w->hip_policy) { c3sc_forget_ctx(w->hip_policy); c3sc_hip_ctx_destroy(w->hip_policy); }
-    free(w->keys); free(w->slab); free(w->costs); free(w->absorbed); free(w->ind_to_serialize);
+    free(w->keys); free(w->slab); free(w->costs); free(w->absorbed); free(w->absorbed_no); free(w->absorbed_yes); free(w->ind_to_serialize);
     htable_destroy(w->vi_htable);
     if (w->hip) { c3sc_forget_ctx(w->hip); c3sc_hip_ctx_destroy(w->hip); }
     free(w);
@@ -633,6 +865,8 @@ double *workspace_get_u(struct Workspace *w, size_t n) { return slot(w, n, 10); 
 double *workspace_get_costs(struct Workspace *w, size_t n) { return w->costs + n * (2 * w->dx + 1); }
 int *workspace_get_absorbed(struct Workspace *w, size_t n) { return w->absorbed + n; }
 size_t *workspace_get_ind_to_serialize(struct Workspace *w) { return w->ind_to_serialize; }
+size_t *workspace_get_absorbed_no(struct Workspace *w) { return w->absorbed_no; }
+size_t *workspace_get_absorbed_yes(struct Workspace *w) { return w->absorbed_yes; }
 char **workspace_get_saved_keys(struct Workspace *w) { return w->keys; }
 char **workspace_get_saved_keys2(struct Workspace *w) { return w->keys2; }
 void workspace_reset_pi_prob_htable(struct Workspace *w)

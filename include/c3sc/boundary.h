@@ -1,6 +1,5 @@
-/* boundary.h -- external boundary types and box obstacles (mirrors src/boundary.h:42-66 of the
- * reference for the part the Bellman path reads; the BoundInfo machinery, boundary.c:491-801, is
- * only used by the dead process_fibers and is out of scope). */
+/* boundary.h -- external boundary types, box obstacles and the BoundInfo query (mirrors src/boundary.h:42-87 of the
+ * reference; the Bellman path reads boundary_type_dim / boundary_in_obstacle only). */
 #ifndef C3SC_BOUNDARY_H
 #define C3SC_BOUNDARY_H
 #include <stddef.h>
@@ -21,4 +20,22 @@ enum EBTYPE boundary_type_dim(const struct Boundary *b, size_t dim, int right); 
 double outer_bound_dim(const struct Boundary *b, size_t dim, double x, int *map);
 int boundary_in_obstacle(const struct Boundary *b, const double *x);             /* boundary.c:668-680 */
 size_t boundary_get_dim(const struct Boundary *b);
+
+/* where a state sits relative to the faces / obstacles (boundary.c:491-801) */
+enum BOUNDRESULT { IN, LEFT, RIGHT };
+struct BoundInfo;
+struct BoundInfo *boundary_type(const struct Boundary *b, double time, const double *x);  /* caller frees: bound_info_free */
+struct BoundInfo *bound_info_alloc(size_t d);
+void bound_info_free(struct BoundInfo *);
+int bound_info_set_dim(struct BoundInfo *, enum BOUNDRESULT, enum EBTYPE, size_t dim); /* 0 ok, 1 periodic (image owed), -1 unknown */
+int bound_info_set_xmap_dim(struct BoundInfo *, double x, size_t dim);
+int bound_info_onbound(const struct BoundInfo *);
+int bound_info_onbound_dim(const struct BoundInfo *, size_t dim);
+int bound_info_absorb(const struct BoundInfo *);
+int bound_info_period(const struct BoundInfo *);
+int bound_info_period_dim_dir(const struct BoundInfo *, size_t dim);   /* -1 left face, 1 right, 0 not periodic */
+double bound_info_period_xmap(const struct BoundInfo *, size_t dim);
+int bound_info_reflect(const struct BoundInfo *);
+int bound_info_reflect_dim_dir(const struct BoundInfo *, size_t dim);
+int bound_info_get_in_obstacle(const struct BoundInfo *);              /* obstacle index or -1 */
 #endif

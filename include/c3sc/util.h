@@ -1,4 +1,4 @@
-/* util.h -- ApproxArgs, Workspace (mirrors src/util.h:49-125 for what the Bellman path uses) and the
+/* util.h -- ApproxArgs, HashGrid, Workspace (mirrors src/util.h:49-125) and the
  * minimal brute-force optimiser object that stands where C3's c3Opt stands in the reference. */
 #ifndef C3SC_UTIL_H
 #define C3SC_UTIL_H
@@ -27,6 +27,25 @@ size_t approx_args_get_startrank(const struct ApproxArgs *);
 void approx_args_set_adapt(struct ApproxArgs *, int);
 int approx_args_get_adapt(const struct ApproxArgs *);
 size_t uniform_stride(size_t N, size_t M); /* util.c:995-1006 */
+
+#include <stdio.h>
+int c3sc_check_bounds(size_t dx, double *lbx, double *ubx, const double *x);                   /* util.c:225-241 */
+size_t c3sc_sample_discrete_rv(size_t n, double *probs, double sample);                       /* util.c:299-331; probs is overwritten */
+double *c3sc_combine_and_sort(size_t Nx, double *x, size_t Ny, double *y, size_t *Ntot);      /* util.c:254-274; caller frees */
+
+/* C3's array.h vector (size, elem) as far as the HashGrid constructors read it */
+struct c3Vector { size_t size; double *elem; };
+/* grid value -> node index by exact value (util.c:352-657) */
+struct HashGrid;
+struct HashGrid *hash_grid_create(size_t size);
+struct HashGrid *hash_grid_create_grid(size_t size, const struct c3Vector *grid);
+struct HashGrid **hash_grid_create_ndgrid(size_t size, size_t d, struct c3Vector **grid);
+void hash_grid_free_ndgrid(size_t d, struct HashGrid **);
+int hash_grid_add_element(struct HashGrid *, size_t ind, double val);                        /* 0 added, 2 already present */
+void hash_grid_print(struct HashGrid *, FILE *);
+size_t hash_grid_get_ind(struct HashGrid *, double val, int *exists);
+int hash_grid_ndgrid_get_ind(struct HashGrid **, size_t dim, const double *x, size_t *out);  /* 0 found, 1 not */
+void hash_grid_free(struct HashGrid *);
 
 /* ---- brute-force c3Opt subset (C3 lib_optimization.h names, own implementation) ---- */
 enum c3opt_alg { BFGS = 0, LBFGS = 1, BATCHGRAD = 2, BRUTEFORCE = 3 };
@@ -80,6 +99,8 @@ double *workspace_get_u(struct Workspace *, size_t node);
 double *workspace_get_costs(struct Workspace *, size_t node);
 int *workspace_get_absorbed(struct Workspace *, size_t node);
 size_t *workspace_get_ind_to_serialize(struct Workspace *);
+size_t *workspace_get_absorbed_no(struct Workspace *);  /* N-entry scratch lists (util.c:946-954) */
+size_t *workspace_get_absorbed_yes(struct Workspace *);
 char **workspace_get_saved_keys(struct Workspace *);
 char **workspace_get_saved_keys2(struct Workspace *);
 /* policy iteration state (util.c:700-715, 766-779, 930-964) */

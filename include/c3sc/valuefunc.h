@@ -13,6 +13,8 @@ struct ValueF *valuef_create_nodal(size_t d, const size_t *N, const size_t *rank
 void valuef_destroy(struct ValueF *);
 struct ValueF *valuef_copy(struct ValueF *);
 size_t *valuef_get_ranks(struct ValueF *);
+struct CrossIndex;                                     /* opaque: the left index sets of the last interpolation */
+struct CrossIndex **valuef_get_isl(const struct ValueF *);   /* valuefunc.c:218-221 */
 size_t valuef_get_dim(const struct ValueF *);
 const size_t *valuef_get_N(const struct ValueF *);
 double **valuef_get_cores(struct ValueF *);

@@ -315,6 +315,106 @@ def test_integer_memo_fiber_keys_agree_with_node_keys():
     L.fastmemo_free(m)
 
 
+def test_boundinfo_hashgrid_and_small_helpers():
+    """The remaining public helpers of boundary.h / util.h: BoundInfo queries (boundary.c:491-801), HashGrid
+    (util.c:352-657), c3sc_check_bounds / combine_and_sort / sample_discrete_rv (util.c:225-331)."""
+    import facade_lib
+
+    L = facade_lib.lib()
+    for n in ("boundary_type", "hash_grid_create", "hash_grid_create_grid", "hash_grid_create_ndgrid", "bound_info_alloc"):
+        getattr(L, n).restype = C.c_void_p
+    L.bound_info_period_xmap.restype = C.c_double
+    L.hash_grid_get_ind.restype = C.c_size_t
+    L.c3sc_sample_discrete_rv.restype = C.c_size_t
+    L.c3sc_combine_and_sort.restype = facade_lib.c_double_p
+
+    # ---- BoundInfo
+    lb, ub = np.array([-1.0, 0.0, -2.0]), np.array([1.0, 6.0, 2.0])
+    bd = C.c_void_p(L.boundary_alloc(C.c_size_t(3), facade_lib.dp(lb), facade_lib.dp(ub)))  # all absorbing
+    L.boundary_external_set_type(bd, C.c_size_t(1), b"periodic")
+    L.boundary_external_set_type(bd, C.c_size_t(2), b"reflect")
+    L.boundary_add_obstacle(bd, facade_lib.dp(np.array([0.0, 3.0, 0.0])), facade_lib.dp(np.array([0.5, 0.5, 0.5])))
+
+    def info(x):
+        bi = C.c_void_p(L.boundary_type(bd, C.c_double(0.0), facade_lib.dp(f64(x))))
+        r = dict(on=L.bound_info_onbound(bi), absorb=L.bound_info_absorb(bi), period=L.bound_info_period(bi),
+                 reflect=L.bound_info_reflect(bi), obs=L.bound_info_get_in_obstacle(bi),
+                 ondim=[L.bound_info_onbound_dim(bi, C.c_size_t(m)) for m in range(3)],
+                 pdir=L.bound_info_period_dim_dir(bi, C.c_size_t(1)), rdir=L.bound_info_reflect_dim_dir(bi, C.c_size_t(2)),
+                 xmap=L.bound_info_period_xmap(bi, C.c_size_t(1)))
+        L.bound_info_free(bi)
+        return r
+
+    f64 = facade_lib.f64
+    r = info([0.5, 1.0, 1.0])
+    assert (r["on"], r["absorb"], r["period"], r["reflect"], r["obs"], r["ondim"]) == (0, 0, 0, 0, -1, [0, 0, 0])
+    r = info([-1.0, 1.0, 1.0])  # on the absorbing left face of dim 0 (faces are closed)
+    assert (r["on"], r["absorb"], r["ondim"]) == (1, 1, [1, 0, 0])
+    r = info([0.5, 6.5, 1.0])  # past the periodic right face: image is the left bound
+    assert (r["on"], r["absorb"], r["period"], r["pdir"], r["xmap"]) == (1, 0, 1, 1, 0.0)
+    r = info([0.5, 0.0, 1.0])
+    assert (r["period"], r["pdir"], r["xmap"]) == (1, -1, 6.0)
+    r = info([0.5, 1.0, -2.0])
+    assert (r["on"], r["absorb"], r["reflect"], r["rdir"], r["ondim"]) == (1, 0, 1, -1, [0, 0, 1])
+    r = info([0.1, 3.2, -0.2])  # inside the obstacle: absorbed, every dimension reports "on boundary"
+    assert (r["on"], r["absorb"], r["obs"], r["ondim"]) == (1, 1, 0, [1, 1, 1])
+    bi = C.c_void_p(L.bound_info_alloc(C.c_size_t(2)))
+    assert L.bound_info_set_dim(bi, C.c_int(1), C.c_int(2), C.c_size_t(0)) == 1  # LEFT, PERIODIC: image still owed
+    assert L.bound_info_set_dim(bi, C.c_int(2), C.c_int(3), C.c_size_t(1)) == 0  # RIGHT, REFLECT
+    assert L.bound_info_set_dim(bi, C.c_int(2), C.c_int(7), C.c_size_t(1)) == -1
+    L.bound_info_free(bi)
+    L.boundary_free(bd)
+
+    # ---- HashGrid
+    class Vec(C.Structure):
+        _fields_ = [("size", C.c_size_t), ("elem", facade_lib.c_double_p)]
+
+    g0, g1 = np.linspace(-1.0, 1.0, 41), np.linspace(0.0, 2 * np.pi, 101)
+    v0, v1 = Vec(41, facade_lib.dp(g0)), Vec(101, facade_lib.dp(g1))
+    hg = C.c_void_p(L.hash_grid_create_grid(C.c_size_t(17), C.byref(v0)))  # fewer buckets than values: chains
+    ex = C.c_int(-1)
+    for i in (0, 7, 20, 40):
+        assert L.hash_grid_get_ind(hg, C.c_double(g0[i]), C.byref(ex)) == i and ex.value == 1
+    assert L.hash_grid_get_ind(hg, C.c_double(np.nextafter(g0[7], 1.0)), C.byref(ex)) == 0 and ex.value == 0  # exact values only
+    assert L.hash_grid_get_ind(hg, C.c_double(-0.0), C.byref(ex)) == 20 and ex.value == 1
+    assert L.hash_grid_add_element(hg, C.c_size_t(99), C.c_double(g0[3])) == 2
+    assert L.hash_grid_add_element(hg, C.c_size_t(41), C.c_double(5.0)) == 0
+    assert L.hash_grid_get_ind(hg, C.c_double(5.0), C.byref(ex)) == 41
+    L.hash_grid_free(hg)
+    vecs = (C.POINTER(Vec) * 2)(C.pointer(v0), C.pointer(v1))
+    nd = C.c_void_p(L.hash_grid_create_ndgrid(C.c_size_t(1000), C.c_size_t(2), vecs))
+    out = np.zeros(2, dtype=np.uintp)
+    assert L.hash_grid_ndgrid_get_ind(nd, C.c_size_t(2), facade_lib.dp(np.array([g0[5], g1[77]])), facade_lib.sp(out)) == 0
+    assert list(out) == [5, 77]
+    assert L.hash_grid_ndgrid_get_ind(nd, C.c_size_t(2), facade_lib.dp(np.array([g0[5], 0.123])), facade_lib.sp(out)) == 1
+    L.hash_grid_free_ndgrid(C.c_size_t(2), nd)
+    assert L.hash_grid_create(C.c_size_t(0)) is None
+
+    # ---- small helpers
+    lo, hi = np.array([0.0, 0.0, 0.0]), np.array([1.0, 2.0, 3.0])
+    chk = lambda x: L.c3sc_check_bounds(C.c_size_t(3), facade_lib.dp(lo), facade_lib.dp(hi), facade_lib.dp(f64(x)))
+    assert (chk([0.5, 1, 1]), chk([0.5, -1e-9, 5]), chk([0.5, 2, 3.5]), chk([0, 2, 3])) == (0, -2, 3, 0)
+    assert L.c3sc_check_bounds(C.c_size_t(3), None, facade_lib.dp(hi), facade_lib.dp(f64([9, 9, 9]))) == 0
+    x, y, nt = np.array([3.0, 1.0, 2.0]), np.array([2.0, 0.5, 3.0 + 1e-16, 4.0]), C.c_size_t(0)
+    p = L.c3sc_combine_and_sort(C.c_size_t(3), facade_lib.dp(x), C.c_size_t(4), facade_lib.dp(y), C.byref(nt))
+    assert nt.value == 5 and list(np.ctypeslib.as_array(p, shape=(5,))) == [0.5, 1.0, 2.0, 3.0, 4.0]
+    C.CDLL(None).free(p)
+    pr = np.array([0.5, 0.1, 0.4])  # ascending: 0.1 (ind 1), 0.4 (ind 2), 0.5 (ind 0) -> sums 0.1, 0.5, 1.0
+    picks = []
+    for u in (0.05, 0.1, 0.3, 0.5, 0.75, 1.0):
+        q = pr.copy()
+        picks.append(L.c3sc_sample_discrete_rv(C.c_size_t(3), facade_lib.dp(q), C.c_double(u)))
+    assert picks == [1, 1, 2, 2, 0, 0] and np.allclose(q, [0.1, 0.5, 1.0])
+
+    # ---- cross index handle / workspace scratch lists exist
+    L.valuef_get_isl.restype = C.c_void_p
+    L.workspace_get_absorbed_no.restype = C.c_void_p
+    L.workspace_get_absorbed_yes.restype = C.c_void_p
+    w = C.c_void_p(L.workspace_alloc(C.c_size_t(2), C.c_size_t(1), C.c_size_t(2), C.c_size_t(11)))
+    assert L.workspace_get_absorbed_no(w) and L.workspace_get_absorbed_yes(w)
+    L.workspace_free(w)
+
+
 def _callbacks(w):
     """Host callbacks with the reference's signatures, evaluated in Python (dubins: dubinscar.c:40-121)."""
     import math

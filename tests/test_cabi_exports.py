@@ -39,6 +39,34 @@ def test_signatures_are_plain_c():
                                "-o", os.path.join(td, "t.o")])
 
 
+def test_reference_api_headers_exported_and_plain_c():
+    """The host library: every function include/c3sc/*.h declares (the reference's public names) is
+    exported by libc3sc.so, and the umbrella header compiles as C99."""
+    import glob
+    import subprocess
+    import tempfile
+
+    so = os.path.join(ROOT, "c3sc_amd", "host", "libc3sc.so")
+    syms = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", so], text=True).splitlines() if l.strip()}
+    declared = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "c3sc", "*.h")):
+        txt = open(h).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"\(\s*\*\s*\w+\s*\)\s*\(", "(", txt)  # function-pointer parameters and typedefs are not functions
+        declared |= set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\(", txt))
+    declared -= {"defined", "sizeof", "double", "int", "void", "size_t"}  # return types of function-pointer parameters
+    assert len(declared) > 200
+    missing = sorted(n for n in declared if n not in syms)
+    assert not missing, missing
+    # names the reference declares that are deliberately not provided (INTEGRATION.md, section A)
+    assert not ({"process_fibers", "workspace_get_active", "workspace_set_active"} & syms)
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "t.c")
+        open(src, "w").write('#include "c3sc/c3sc.h"\nint main(void){return 0;}\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src,
+                               "-o", os.path.join(td, "t.o")])
+
+
 def test_fails_loudly_without_gpu():
     import torch
 

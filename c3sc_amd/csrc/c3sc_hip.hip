@@ -238,6 +238,14 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
 
 extern "C" {
 
+int c3sc_hip_max_rank(int model, int d)
+{ // largest FT rank any compiled kernel of this (model, state dimension) serves; 0 = none
+    int rp = 0;
+    for (const auto &e : kernel_registry())
+        if (e.model == model && e.d == d && e.rp > rp) rp = e.rp;
+    return rp;
+}
+
 int c3sc_hip_device_count(void)
 {
     int n = 0;

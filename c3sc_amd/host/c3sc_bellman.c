@@ -1216,11 +1216,41 @@ struct ValueF *c3control_init_value(struct C3Control *c, int (*f)(size_t, const 
     return valuef_interp(c->dx, f, args, c->ngrid, c->xgrid, NULL, aargs, verbose);
 }
 
+/* The compiled kernels end at some FT rank per (model, dimension); the reference has no such limit, so a user's
+ * maxrank above it is clamped for the interpolation (a copy: the caller's ApproxArgs is borrowed) with one warning,
+ * instead of dying in the middle of a solve when the rank adaptation gets there. */
+static struct ApproxArgs *device_rank_cap(struct C3Control *c, struct ApproxArgs *in)
+{
+    struct ApproxArgs *a = approx_args_init();
+    approx_args_set_function_class(a, approx_args_get_function_class(in));
+    approx_args_set_cross_tol(a, approx_args_get_cross_tol(in));
+    approx_args_set_round_tol(a, approx_args_get_round_tol(in));
+    approx_args_set_kickrank(a, approx_args_get_kickrank(in));
+    approx_args_set_startrank(a, approx_args_get_startrank(in));
+    approx_args_set_maxrank(a, approx_args_get_maxrank(in));
+    approx_args_set_adapt(a, approx_args_get_adapt(in));
+    const int cap = c3sc_hip_max_rank(dp_has_device_model(c->dp) ? c->dp->model : C3SC_MODEL_TABLE, (int)c->dx);
+    if (cap > 0 && approx_args_get_maxrank(a) > (size_t)cap) {
+        static int warned = 0;
+        size_t minN = c->ngrid[0];
+        for (size_t m = 0; m < c->dx; m++) if (c->ngrid[m] < minN) minN = c->ngrid[m];
+        if (!warned && minN > (size_t)cap) {
+            fprintf(stderr, "c3sc: maxrank %zu exceeds the largest rank compiled for this model and dimension (%d); using %d\n",
+                    approx_args_get_maxrank(a), cap, cap);
+            warned = 1;
+        }
+        approx_args_set_maxrank(a, (size_t)cap);
+    }
+    return a;
+}
+
 struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct ApproxArgs *apargs, struct c3Opt *opt, int verbose,
                                  size_t *nevals)
 { /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
     struct VIparam *vi = c3control_begin_vi(c, vf, opt);
-    struct ValueF *next = valuef_interp_idx(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, apargs, verbose);
+    struct ApproxArgs *aa = device_rank_cap(c, apargs);
+    struct ValueF *next = valuef_interp_idx(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose);
+    approx_args_free(aa);
     c3control_end_vi(c, vi, nevals);
     return next;
 }
@@ -1229,7 +1259,9 @@ struct ValueF *c3control_step_pi(struct C3Control *c, struct ValueF *vf, struct 
                                  struct c3Opt *opt, int verbose, size_t *niter_evals)
 { /* bellman.c:2214-2262 */
     c3control_begin_pi_step(c, poli, vf, opt);
-    struct ValueF *next = valuef_interp_idx(c->dx, bellman_pi_batch_idx, poli, c->ngrid, c->xgrid, vf, apargs, verbose);
+    struct ApproxArgs *aa = device_rank_cap(c, apargs);
+    struct ValueF *next = valuef_interp_idx(c->dx, bellman_pi_batch_idx, poli, c->ngrid, c->xgrid, vf, aa, verbose);
+    approx_args_free(aa);
     c3control_end_pi_step(c, poli, niter_evals);
     return next;
 }

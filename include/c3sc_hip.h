@@ -74,6 +74,9 @@ int c3sc_hip_ctx_create(int device, c3sc_hip_ctx **out);
 void c3sc_hip_ctx_destroy(c3sc_hip_ctx *ctx);
 const char *c3sc_hip_last_error(const c3sc_hip_ctx *ctx);
 int c3sc_hip_device_count(void);
+/* largest FT rank the compiled kernels serve for (model id, state dimension d); 0 if none.  The reference has no such
+ * limit (valuefunc.c:625-631 only clamps maxrank to min N); a caller clamps ApproxArgs.maxrank with it. */
+int c3sc_hip_max_rank(int model, int d);
 
 /* c3control_create's grid (bellman.c:1972-1986): ngrid[d], xgrid[m] host arrays of ngrid[m] doubles */
 int c3sc_hip_set_grid(c3sc_hip_ctx *ctx, int d, const size_t *ngrid, const double *const *xgrid);

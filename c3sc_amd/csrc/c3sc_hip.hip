@@ -113,6 +113,9 @@ struct c3sc_hip_ctx {
     // scratch for the *_host convenience calls
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // pinned, device-mapped host block for small *_host batches (read and written by the kernel in place)
+    void *pinned = nullptr, *pinned_dev = nullptr;
+    size_t pinned_bytes = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                    \
@@ -233,6 +236,8 @@ static int pick_rp(int d, int maxrank)
 }
 
 static int ensure_scratch(c3sc_hip_ctx *c, size_t bytes);
+static int ensure_pinned(c3sc_hip_ctx *c, size_t bytes);
+static bool zero_copy_batch(size_t bytes);
 static size_t align256(size_t x);
 static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model);
 
@@ -278,6 +283,7 @@ void c3sc_hip_ctx_destroy(c3sc_hip_ctx *c)
     if (c->arena) (void)hipFree(c->arena);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -587,7 +593,27 @@ static int box_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, cons
     const size_t N = c->ngrid[k], du = c->box_du;
     const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * sizeof(double)),
                  b_u = align256(F * N * du * sizeof(double)), b_i = align256(F * N * sizeof(int32_t));
-    int rc = ensure_scratch(c, b_idx + b_out + b_u + b_i);
+    int rc;
+    if (zero_copy_batch(b_idx + b_out + b_u + b_i)) {
+        if ((rc = ensure_pinned(c, b_idx + b_out + b_u + b_i)) != C3SC_OK) return rc;
+        char *hb = (char *)c->pinned, *db = (char *)c->pinned_dev;
+        memcpy(hb, h_idx, F * c->d * sizeof(int32_t));
+        double *zu = (double *)(db + b_idx + b_out);
+        int32_t *zab = h_absorbed ? (int32_t *)(db + b_idx + b_out + b_u) : nullptr;
+        if (h_policy_u) {
+            memcpy(hb + b_idx + b_out, h_policy_u, F * N * du * sizeof(double));
+            rc = c3sc_hip_policy_fibers_box(c, k, F, (int32_t *)db, zu, (double *)(db + b_idx), zab, nullptr);
+        } else {
+            rc = c3sc_hip_bellman_fibers_box(c, k, F, (int32_t *)db, (double *)(db + b_idx), h_uopt ? zu : nullptr, zab, nullptr);
+        }
+        if (rc != C3SC_OK) return rc;
+        HIPCHK(c, hipStreamSynchronize(nullptr));
+        memcpy(h_out, hb + b_idx, F * N * sizeof(double));
+        if (h_uopt && !h_policy_u) memcpy(h_uopt, hb + b_idx + b_out, F * N * du * sizeof(double));
+        if (h_absorbed) memcpy(h_absorbed, hb + b_idx + b_out + b_u, F * N * sizeof(int32_t));
+        return C3SC_OK;
+    }
+    rc = ensure_scratch(c, b_idx + b_out + b_u + b_i);
     if (rc != C3SC_OK) return rc;
     char *base = (char *)c->scratch;
     int32_t *d_idx = (int32_t *)base;
@@ -745,6 +771,29 @@ static int ensure_scratch(c3sc_hip_ctx *c, size_t bytes)
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Small batches of the *_host entry points (a cross-approximation core step: ~100 fibers, 3 KB in, 33 KB out) skip
+// the staging copies: indices are placed in a pinned host block the device maps, the kernel reads them and writes its
+// rows there, and the call is launch + stream synchronise.  The two hipMemcpy calls they replace cost 25 us of a
+// 53 us call (tools/call_latency.py).  Large batches keep the copies: PCIe would bound the kernel.
+static constexpr size_t ZERO_COPY_MAX_BYTES = (size_t)1 << 20;
+static bool zero_copy_batch(size_t bytes)
+{
+    static const bool off = getenv("C3SC_NO_ZEROCOPY") != nullptr;
+    return !off && bytes <= ZERO_COPY_MAX_BYTES;
+}
+static int ensure_pinned(c3sc_hip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->pinned_bytes) return C3SC_OK;
+    if (c->pinned) HIPCHK(c, hipHostFree(c->pinned));
+    c->pinned = c->pinned_dev = nullptr;
+    c->pinned_bytes = 0;
+    const size_t cap = bytes < ((size_t)256 << 10) ? ((size_t)256 << 10) : bytes;
+    HIPCHK(c, hipHostMalloc(&c->pinned, cap, hipHostMallocMapped | hipHostMallocPortable));
+    HIPCHK(c, hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0));
+    c->pinned_bytes = cap;
+    return C3SC_OK;
+}
+
 int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t *h_idx, double *h_out, int32_t *h_uidx,
                                  int32_t *h_absorbed)
 {
@@ -754,7 +803,21 @@ int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t
     const size_t N = c->ngrid[k];
     const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * sizeof(double)),
                  b_i = align256(F * N * sizeof(int32_t));
-    int rc = ensure_scratch(c, b_idx + b_out + 2 * b_i);
+    int rc;
+    if (zero_copy_batch(b_idx + b_out + 2 * b_i)) {
+        if ((rc = ensure_pinned(c, b_idx + b_out + 2 * b_i)) != C3SC_OK) return rc;
+        char *hb = (char *)c->pinned, *db = (char *)c->pinned_dev;
+        memcpy(hb, h_idx, F * c->d * sizeof(int32_t));
+        rc = c3sc_hip_bellman_fibers(c, k, F, (int32_t *)db, (double *)(db + b_idx), h_uidx ? (int32_t *)(db + b_idx + b_out) : nullptr,
+                                     h_absorbed ? (int32_t *)(db + b_idx + b_out + b_i) : nullptr, nullptr);
+        if (rc != C3SC_OK) return rc;
+        HIPCHK(c, hipStreamSynchronize(nullptr));
+        memcpy(h_out, hb + b_idx, F * N * sizeof(double));
+        if (h_uidx) memcpy(h_uidx, hb + b_idx + b_out, F * N * sizeof(int32_t));
+        if (h_absorbed) memcpy(h_absorbed, hb + b_idx + b_out + b_i, F * N * sizeof(int32_t));
+        return C3SC_OK;
+    }
+    rc = ensure_scratch(c, b_idx + b_out + 2 * b_i);
     if (rc != C3SC_OK) return rc;
     char *base = (char *)c->scratch;
     int32_t *d_idx = (int32_t *)base;
@@ -779,7 +842,21 @@ int c3sc_hip_policy_fibers_host(c3sc_hip_ctx *c, int k, size_t F, const int32_t 
     const size_t N = c->ngrid[k];
     const size_t b_idx = align256(F * c->d * sizeof(int32_t)), b_out = align256(F * N * sizeof(double)),
                  b_i = align256(F * N * sizeof(int32_t));
-    int rc = ensure_scratch(c, b_idx + b_out + 2 * b_i);
+    int rc;
+    if (zero_copy_batch(b_idx + b_out + 2 * b_i)) {
+        if ((rc = ensure_pinned(c, b_idx + b_out + 2 * b_i)) != C3SC_OK) return rc;
+        char *hb = (char *)c->pinned, *db = (char *)c->pinned_dev;
+        memcpy(hb, h_idx, F * c->d * sizeof(int32_t));
+        memcpy(hb + b_idx + b_out, h_policy, F * N * sizeof(int32_t));
+        rc = c3sc_hip_policy_fibers(c, k, F, (int32_t *)db, (int32_t *)(db + b_idx + b_out), (double *)(db + b_idx),
+                                    h_absorbed ? (int32_t *)(db + b_idx + b_out + b_i) : nullptr, nullptr);
+        if (rc != C3SC_OK) return rc;
+        HIPCHK(c, hipStreamSynchronize(nullptr));
+        memcpy(h_out, hb + b_idx, F * N * sizeof(double));
+        if (h_absorbed) memcpy(h_absorbed, hb + b_idx + b_out + b_i, F * N * sizeof(int32_t));
+        return C3SC_OK;
+    }
+    rc = ensure_scratch(c, b_idx + b_out + 2 * b_i);
     if (rc != C3SC_OK) return rc;
     char *base = (char *)c->scratch;
     int32_t *d_idx = (int32_t *)base;

@@ -664,6 +664,16 @@ static double g_t_lookup, g_t_device, g_t_store;
 static size_t g_n_calls;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+/* transition_assemble's "stationary node" outcome (nodeutil.c:365-367; bellman.c:452 asserts on it) comes back as a
+ * device flag.  The public per-fiber entry points read it after every call; the index-based batch entry points of the
+ * solver loops read it once per sweep (c3control_end_vi / end_pi_step) -- a status read is a device round trip. */
+static void die_if_stationary(struct c3sc_hip_ctx *ctx)
+{
+    unsigned st = 0;
+    hipok(ctx, c3sc_hip_get_status(ctx, &st, 1), "c3sc_hip_get_status");
+    if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+}
+
 static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, const double *x_in, double *out, int fast)
 {
     struct ControlParams *cp = vi->cp;
@@ -739,9 +749,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
             free(tables);
             free(costs2);
         }
-        unsigned st = 0;
-        hipok(ctx, c3sc_hip_get_status(ctx, &st, 1), "c3sc_hip_get_status");
-        if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+        if (!fast) die_if_stationary(ctx);
         const double t_dev = now_s();
         g_t_device += t_dev - t_looked;
         r = 0;
@@ -941,9 +949,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
                   "c3sc_hip_bellman_fibers_tables_host");
             free(rt); free(rc2);
         }
-        unsigned st = 0;
-        hipok(ctx_pol, c3sc_hip_get_status(ctx_pol, &st, 1), "c3sc_hip_get_status");
-        if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+        if (!fast) die_if_stationary(ctx_pol);
         r = 0;
         for (size_t f = 0; f < F; f++) {
             if (!need[f]) continue;
@@ -984,9 +990,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
     else if (have_model) hipok(ctx_it, c3sc_hip_policy_fibers_host(ctx_it, (int)k0, F, idx, policy, eout, NULL), "c3sc_hip_policy_fibers_host");
     else hipok(ctx_it, c3sc_hip_policy_fibers_tables_host(ctx_it, (int)k0, F, idx, tables, costs2, policy, eout, NULL),
                "c3sc_hip_policy_fibers_tables_host");
-    unsigned st = 0;
-    hipok(ctx_it, c3sc_hip_get_status(ctx_it, &st, 1), "c3sc_hip_get_status");
-    if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
+    if (!fast) die_if_stationary(ctx_it);
     for (size_t i = 0; i < F * N; i++)
         if (!stored[i]) out[i] = eout[i];
     g_tp[3] += now_s() - t_pol;
@@ -1122,6 +1126,8 @@ void c3control_begin_pi_step(struct C3Control *c, struct PIparam *pi, struct Val
 
 void c3control_end_pi_step(struct C3Control *c, struct PIparam *pi, size_t *niter_evals)
 {
+    if (workspace_peek_hip_ctx(c->work)) die_if_stationary(workspace_peek_hip_ctx(c->work));
+    if (workspace_peek_hip_ctx_policy(c->work)) die_if_stationary(workspace_peek_hip_ctx_policy(c->work));
     if (getenv("C3SC_PROFILE")) {
         fprintf(stderr, "c3sc profile (policy evaluation): %zu batch calls, core upload %.2f ms, flags + policy cache %.2f ms, policy pass %.2f ms, evaluation pass %.2f ms\n",
                 g_np, 1e3 * g_tp[0], 1e3 * g_tp[1], 1e3 * g_tp[2], 1e3 * g_tp[3]);
@@ -1135,6 +1141,7 @@ void c3control_end_pi_step(struct C3Control *c, struct PIparam *pi, size_t *nite
 
 void c3control_end_vi(struct C3Control *c, struct VIparam *vi, size_t *nevals)
 {
+    if (workspace_peek_hip_ctx(c->work)) die_if_stationary(workspace_peek_hip_ctx(c->work));
     if (getenv("C3SC_PROFILE")) {
         fprintf(stderr, "c3sc profile: %zu batch calls, memo lookup %.2f ms, device calls %.2f ms, memo store %.2f ms\n", g_n_calls,
                 1e3 * g_t_lookup, 1e3 * g_t_device, 1e3 * g_t_store);

@@ -895,6 +895,10 @@ static struct c3sc_hip_ctx *make_ctx(void)
     return ctx;
 }
 
+/* the contexts if they exist already (no creation): for end-of-sweep status checks */
+struct c3sc_hip_ctx *workspace_peek_hip_ctx(struct Workspace *w) { return w->hip; }
+struct c3sc_hip_ctx *workspace_peek_hip_ctx_policy(struct Workspace *w) { return w->hip_policy; }
+
 struct c3sc_hip_ctx *workspace_get_hip_ctx(struct Workspace *w)
 {
     if (w->hip == NULL) w->hip = make_ctx();

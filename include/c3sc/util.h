@@ -134,4 +134,6 @@ struct FastMemo *workspace_get_pi_prob_fastmemo(const struct Workspace *);
 struct c3sc_hip_ctx;
 struct c3sc_hip_ctx *workspace_get_hip_ctx(struct Workspace *);
 struct c3sc_hip_ctx *workspace_get_hip_ctx_policy(struct Workspace *); /* holds the policy's value function */
+struct c3sc_hip_ctx *workspace_peek_hip_ctx(struct Workspace *);        /* NULL until the first device call */
+struct c3sc_hip_ctx *workspace_peek_hip_ctx_policy(struct Workspace *);
 #endif

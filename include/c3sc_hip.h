@@ -175,7 +175,10 @@ int c3sc_hip_stencil_fibers_nb_host(c3sc_hip_ctx *ctx, int k, size_t F, const in
                                     const int32_t *h_nb_fixed, const int32_t *h_nb_vary, double *h_costs,
                                     int32_t *h_absorbed);
 
-/* Convenience for host callers (the C facade's bellman_vi): host buffers, synchronous. */
+/* Convenience for host callers (the C facade's bellman_vi): host buffers, synchronous.  Batches whose buffers total
+ * <= 1 MiB (a cross-approximation core step) are served from a pinned, device-mapped block of the context -- the kernel
+ * reads the indices and writes its rows in place, no hipMemcpy; larger ones are staged through device scratch.
+ * C3SC_NO_ZEROCOPY=1 in the environment forces the staged path. */
 int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, double *h_out,
                                  int32_t *h_uidx, int32_t *h_absorbed);
 int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, double *h_costs,

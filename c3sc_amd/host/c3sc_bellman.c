@@ -692,7 +692,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
         for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
         ser[dx] = 0;           /* bellman.c:1337 */
         ser[dx + 1] = vi_iter; /* bellman.c:1338 */
-        if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, 0, vi_iter);
+        if (fast) { fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, 0, vi_iter); fastmemo_fiber_prefetch(fm, &ff, N); }
         for (size_t j = 0; j < N; j++) { /* memo lookup, bellman.c:1341-1353 */
             double v = 0.0;
             int found;
@@ -759,7 +759,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
             ser[dx] = 0;
             ser[dx + 1] = vi_iter;
-            if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, 0, vi_iter);
+            if (fast) { fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, 0, vi_iter); fastmemo_fiber_prefetch(fm, &ff, N); }
             for (size_t j = 0; j < N; j++) {
                 if (hit[f * N + j]) continue;
                 out[f * N + j] = rout[r * N + j];
@@ -885,7 +885,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
         process_fibers_neighbor(dx, fi, k0, x + f * N * dx, absorbed, nv, nf, mca->ngrid, dp->bound);
         ser[dx] = pi_iter;    /* bellman.c:1759 */
         ser[dx + 1] = pi_sub; /* :1760 */
-        if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, pi_iter, 0);
+        if (fast) { fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, pi_iter, 0); fastmemo_fiber_prefetch(fm, &ff, N); }
         for (size_t j = 0; j < N; j++) {
             if (!fast) {
                 ser[k0] = j;
@@ -955,7 +955,7 @@ static int pi_core(struct PIparam *pi, size_t F, size_t k0, const int32_t *idx, 
             if (!need[f]) continue;
             for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
             ser[dx] = pi_iter;
-            if (fast) fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, pi_iter, 0);
+            if (fast) { fastmemo_fiber_begin(&ff, dx, idx + f * dx, k0, pi_iter, 0); fastmemo_fiber_prefetch(fm, &ff, N); }
             for (size_t j = 0; j < N; j++) {
                 if (!miss[f * N + j]) continue;
                 double *pv = &polv[(f * N + j) * pw];

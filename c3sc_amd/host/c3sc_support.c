@@ -617,6 +617,11 @@ void fastmemo_fiber_counter(struct FmFiber *ff, uint64_t c0, uint64_t c1)
     ff->pre0 += (nw - ff->key[3]) * FM_P[3];
     ff->key[3] = nw;
 }
+void fastmemo_fiber_prefetch(const struct FastMemo *m, const struct FmFiber *ff, size_t n)
+{ /* the n home slots of the fiber's nodes are independent cache misses: start them all before the first probe */
+    for (size_t j = 0; j < n; j++)
+        __builtin_prefetch(&m->e[(size_t)mix64(ff->pre0 + (uint64_t)(j & 0xffffu) * ff->step) & (m->cap - 1)]);
+}
 int fastmemo_fiber_get(const struct FastMemo *m, struct FmFiber *ff, size_t j, double *val)
 {
     ff->key[ff->word] = ff->base | ((uint64_t)(j & 0xffffu) << ff->shift);

@@ -126,6 +126,7 @@ void fastmemo_key(size_t d, const int32_t *idx, size_t kdim, size_t j, uint64_t 
 struct FmFiber { uint64_t key[4], base, pre0, step; unsigned word, shift; };
 void fastmemo_fiber_begin(struct FmFiber *ff, size_t d, const int32_t *idx, size_t kdim, uint64_t c0, uint64_t c1);
 void fastmemo_fiber_counter(struct FmFiber *ff, uint64_t c0, uint64_t c1);
+void fastmemo_fiber_prefetch(const struct FastMemo *, const struct FmFiber *ff, size_t n); /* warm the n home slots */
 int fastmemo_fiber_get(const struct FastMemo *, struct FmFiber *ff, size_t j, double *val);
 void fastmemo_fiber_put(struct FastMemo *, struct FmFiber *ff, size_t j, double val);
 struct FastMemo *workspace_get_vi_fastmemo(const struct Workspace *);

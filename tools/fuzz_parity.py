@@ -72,6 +72,23 @@ while time.time() - t0 < budget:
                       "variant", variant, eng.last_kernel(), "k", k, "F", F, "err", err, "absorbed mismatches", bad_ab, flush=True)
     st = eng.status()
     if st: print("status flags", st, name, ngrid, ranks)
+    # the batched valuef_eval_fiber_ind_nn (stencil of neighbour values) on its own
+    if rng.random() < 0.3:
+        for k in range(d):
+            idx = wl.synth_fibers(w, k, int(rng.choice([1, 30])), seed=int(rng.integers(1 << 30))); idx[:, k] = 0
+            try:
+                eng.set_variant(0)
+                costs, ab = eng.stencil_fibers_host(k, idx)
+            except C3scHipError as e:
+                if "no kernel instantiation" in str(e) or "no stencil" in str(e): continue
+                raise
+            ref, rab = P.stencil_fibers(k, idx)
+            nrun += 1
+            err = np.abs(costs - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, err)
+            if err > 1e-11 or (ab != rab).any():
+                nfail += 1
+                print("FAIL stencil", name, "ngrid", ngrid, "ranks", ranks, "bc", bc, "k", k, "err", err, "absorbed mismatches", int((ab != rab).sum()), flush=True)
     # policy evaluation (bellman_pi): greedy policy of a second value function applied to this one; the oracle's own
     # argmin is forced on the device so that ties cannot matter
     if rng.random() < 0.5:

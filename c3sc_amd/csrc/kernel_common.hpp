@@ -585,14 +585,21 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
             Model::sigma(A.prm, x, u, s);
             const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
             double Q = Q0, PV = PV0;
+            constexpr unsigned UCg = Model::UCONST_MASK;
 #pragma unroll
             for (int m = 0; m < D; m++) {
                 if ((UM >> m) & 1u) {
-                    const double half = t2l[m] * (s[m] * s[m]) / 2.0;
-                    // branch-free upwinding with the +-1e-14 dead zone of nodeutil.c:300-305
-                    const double tb = tl[m] * b[m];
-                    const double pm = (b[m] < -1e-14) ? half - tb : half;
-                    const double pp = (b[m] > 1e-14) ? half + tb : half;
+                    double pm, pp;
+                    if ((UCg >> m) & 1u) { // the rates of this dim are constants of the candidate (table built with the candidates)
+                        pm = cr.get_rpm(CandRegs<Model>::ucslot(m), c);
+                        pp = cr.get_rpp(CandRegs<Model>::ucslot(m), c);
+                    } else {
+                        const double half = t2l[m] * (s[m] * s[m]) / 2.0;
+                        // branch-free upwinding with the +-1e-14 dead zone of nodeutil.c:300-305
+                        const double tb = tl[m] * b[m];
+                        pm = (b[m] < -1e-14) ? half - tb : half;
+                        pp = (b[m] > 1e-14) ? half + tb : half;
+                    }
                     Q += pm;
                     Q += pp;
                     PV = fma(pm, V[2 * m], PV);

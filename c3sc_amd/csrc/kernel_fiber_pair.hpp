@@ -28,6 +28,9 @@
 #ifndef FPP_PIPE2
 #define FPP_PIPE2 1
 #endif
+#ifndef FPP_CG
+#define FPP_CG 1 // candidates in flight in the discounted scan (one division + exp chain each); 1 where registers are tight
+#endif
 #ifndef FPP_NV
 #define FPP_NV 4 // vectors per pass over a staged matrix in the folding phase (2: 0.361 ms, 3: 0.343, 4: 0.340 on car7d)
 #endif
@@ -506,7 +509,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             // FORCED (policy evaluation) is a separate instantiation: as a run-time flag it costs the minimising kernel 4 %
             int fu = -1;
             if constexpr (FORCED) fu = A.forced[(size_t)f * N + jn];
-            const double val = node_backup<Model, 1, FPP_CGD, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, FORCED, fu);
+            const double val = node_backup<Model, FPP_CG, FPP_CGD, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, FORCED, fu);
             FPP_STAMP(9) // control scan
             // lanes past the last fiber duplicate fiber F-1 and store the same numbers to the same place: no
             // divergent branch in the node loop (see node_backup on spilled lane tables)

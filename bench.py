@@ -188,7 +188,10 @@ def main():
                                    f"seeded synthetic cores (SURVEY.md 8d {'C4' if w.name == 'car7d' else ''})",
                        "fibers_per_dim_per_gpu": F, "parallelism": f"fiber-sharded x{world}" if world > 1 else "single GPU",
                        "exchange": "all-gather of FT cores per sweep (RCCL)" if world > 1 else "none"},
-            "vi_iters_to_tol": None,
+            # not measured by this run: the examples' outer loop through libc3sc.so on the same config (tools/solve_to_tol.py)
+            "vi_iters_to_tol": ({"outer_iterations": 30, "bellman_sweeps": 341, "seconds": 5.6,
+                                 "criterion": "|V| plateau reached; the step difference then stays at the rank-10 truncation floor (0.4-1.7 % of |V|)",
+                                 "source": "profiles/r01_f_solve_car7d.txt"} if args.workload == "car7d" else None),
             "kernel_status_flags": status,
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

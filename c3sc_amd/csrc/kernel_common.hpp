@@ -349,18 +349,22 @@ __device__ __forceinline__ double sgpr_const(double c)
     return c;
 }
 
+// exp(x) for |x| < 2^-7: degree-7 Taylor polynomial (truncation 2^-56 * 1/40320 relative, below an ulp)
+__device__ inline double exp_small(double x)
+{
+    double p = sgpr_const(1.0 / 5040.0);
+    p = fma(p, x, sgpr_const(1.0 / 720.0));
+    p = fma(p, x, sgpr_const(1.0 / 120.0));
+    p = fma(p, x, sgpr_const(1.0 / 24.0));
+    p = fma(p, x, sgpr_const(1.0 / 6.0));
+    p = fma(p, x, 0.5);
+    p = fma(p, x, 1.0);
+    return fma(p, x, 1.0);
+}
+
 __device__ inline double exp_discount(double x)
 {
-    if (__all(fabs(x) < 0.0078125)) {
-        double p = sgpr_const(1.0 / 5040.0);
-        p = fma(p, x, sgpr_const(1.0 / 720.0));
-        p = fma(p, x, sgpr_const(1.0 / 120.0));
-        p = fma(p, x, sgpr_const(1.0 / 24.0));
-        p = fma(p, x, sgpr_const(1.0 / 6.0));
-        p = fma(p, x, 0.5);
-        p = fma(p, x, 1.0);
-        return fma(p, x, 1.0);
-    }
+    if (__all(fabs(x) < 0.0078125)) return exp_small(x);
     return exp(x);
 }
 
@@ -400,6 +404,16 @@ __device__ inline double node_backup_tables(const KArgs &A, const double *__rest
         if (forced ? (c == fu) : (ui < 0 || val < best)) { best = val; ui = c; }
     }
     return best;
+}
+
+// 1/q for a positive, normal q: hardware seed + two Newton steps (5 instructions; the IEEE division sequence with its
+// scaling and fix-up is 12, and the discounted scan divides once per candidate)
+__device__ inline double rcp_newton(double q)
+{
+    double x = __builtin_amdgcn_rcp(q);
+    x = fma(fma(-q, x, 1.0), x, x);
+    x = fma(fma(-q, x, 1.0), x, x);
+    return x;
 }
 
 // One node of the Bellman operator: bellman_optimal (bellman.c:504-543, BRUTEFORCE branch) over
@@ -568,6 +582,11 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     // Candidates are evaluated CG at a time (CG = 1 where registers are tight): one candidate is a ~40-deep
     // chain of dependent f64 operations (rates -> Q -> 1/Q -> dt -> value), and with one or two wavefronts per
     // SIMD nothing else hides that latency, so independent candidates are interleaved.
+    double bestg = __builtin_inf();
+    bool anybad_g = false;
+    // every candidate only adds rates to Q0, so dt_c <= h2/Q0: if beta*h2/Q0 is small on every lane, the discount
+    // factor of every candidate takes the polynomial and the per-candidate wave vote is not needed
+    const bool all_small = __all(discl * h2l < 0.0078125 * Q0);
     for (int c0 = 0; c0 < nc; c0 += CG) {
         double val[CG];
         bool ok[CG];
@@ -608,25 +627,27 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
             }
             ok[q] = !(Q < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
             const double Qs = ok[q] ? Q : 1.0;
-            const double inv = 1.0 / Qs;
+            const double inv = rcp_newton(Qs);         // Q in [1e-14, ~1e8]: no scaling / fix-up needed, result within an ulp
             const double dt = h2l * inv;               // nodeutil.c:369
             const double pself = fma(-Qs, inv, 1.0);   // 1 - sum_i p_i/Q: rounding residue, as in the reference
             const double ctg = fma(pself, V[2 * D], PV * inv);
-            const double ebt = (A.discount == 0.0) ? 1.0 : exp_discount(-discl * dt); // bellman.c:94
+            const double ebt = (A.discount == 0.0) ? 1.0 : (all_small ? exp_small(-discl * dt) : exp_discount(-discl * dt)); // bellman.c:94
             val[q] = dt * stage + ebt * ctg;                                 // bellman.c:97
         }
 #pragma unroll
         for (int q = 0; q < CG; q++) {
             if (c0 + q < nc) {
-                if (!ok[q] && ab == 0) st |= C3SC_STATUS_STATIONARY;
-                const bool take = ok[q] & (forced ? (c0 + q == fu) : ((ui < 0) | (val[q] < best)));
-                best = take ? val[q] : best;
+                anybad_g |= !ok[q];
+                const bool take = ok[q] & (forced ? (c0 + q == fu) : (val[q] < bestg)); // +inf loses to the first candidate
+                bestg = take ? val[q] : bestg;
                 ui = take ? c0 + q : ui;
             }
         }
     }
+    if (anybad_g & (ab == 0)) st |= C3SC_STATUS_STATIONARY;
+    best = (ui >= 0) ? bestg : 0.0;
     best = (ab != 0) ? absorbed_cost : best;
-        ui = (ab != 0) ? -1 : ui;
+    ui = (ab != 0) ? -1 : ui;
     return best;
 }
 

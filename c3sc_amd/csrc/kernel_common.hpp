@@ -541,13 +541,16 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
                                 pm = (b[m] < -1e-14) ? half - tb : half;
                                 pp = (b[m] > 1e-14) ? half + tb : half;
                             }
-                            Qa += pm;
-                            Qb += pp;
+                            if constexpr (UCm != UM) { // otherwise the sum of the candidate's rates is a table entry
+                                Qa += pm;
+                                Qb += pp;
+                            }
                             PVa = fma(pm, V[2 * m], PVa);
                             PVb = fma(pp, V[2 * m + 1], PVb);
                         }
                     }
-                    Q = Q0 + (Qa + Qb);
+                    if constexpr (UCm == UM) Q = Q0 + cr.get_qab(c);
+                    else Q = Q0 + (Qa + Qb);
                     num = fma(h2l, stage, PV0 + (PVa + PVb));
                 }
                 Qq[q] = Q;
@@ -619,12 +622,15 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
                         pm = (b[m] < -1e-14) ? half - tb : half;
                         pp = (b[m] > 1e-14) ? half + tb : half;
                     }
-                    Q += pm;
-                    Q += pp;
+                    if constexpr (UCg != UM) { // otherwise the sum of the candidate's rates is a table entry
+                        Q += pm;
+                        Q += pp;
+                    }
                     PV = fma(pm, V[2 * m], PV);
                     PV = fma(pp, V[2 * m + 1], PV);
                 }
             }
+            if constexpr (UCg == UM) Q = Q0 + cr.get_qab(c);
             ok[q] = !(Q < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
             const double Qs = ok[q] ? Q : 1.0;
             const double inv = rcp_newton(Qs);         // Q in [1e-14, ~1e8]: no scaling / fix-up needed, result within an ulp

@@ -17,6 +17,7 @@ BASES = ["lqg2d", "dubins3d", "lqg6d", "car7d", "quad10d", "scar4d"]
 MAXN = {"lqg2d": 128, "dubins3d": 128, "lqg6d": 40, "car7d": 48, "quad10d": 28, "scar4d": 64}
 MAXR = {"lqg2d": 20, "dubins3d": 20, "lqg6d": 8, "car7d": 10, "quad10d": 16, "scar4d": 20}
 t0 = time.time(); ncase = nfail = nrun = 0
+last_note = t0
 worst = 0.0
 while time.time() - t0 < budget:
     name = BASES[rng.integers(len(BASES))]
@@ -46,6 +47,9 @@ while time.time() - t0 < budget:
     except (C3scHipError, AssertionError) as e:
         print("skip", name, ngrid, ranks, str(e)[:80]); continue
     ncase += 1
+    if time.time() - last_note > 30.0:  # a silent GPU job is taken to be hung
+        print(f"... {ncase} problems, {nrun} kernel runs, {nfail} failures, {time.time() - t0:.0f} s", flush=True)
+        last_note = time.time()
     for variant in (0, 1, 3):
         for k in range(d):
             F = int(rng.choice([1, 3, 64, 65, 200]))

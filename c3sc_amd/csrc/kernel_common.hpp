@@ -212,6 +212,15 @@ struct NodeRegs {
 // plus the upwind rates of the dims whose drift and diffusion depend on the control alone (Model::UCONST_MASK):
 // those are constants of the candidate (nodeutil.c:289-309 with b = b(u), sigma = sigma(u)), computed once per
 // wave with the very arithmetic the node loop would use and broadcast by v_readlane in the scan.
+// models whose stage cost splits as stage_x(x) + stage_u(u) (and have no control features, NCF == 0) keep stage_u in the
+// otherwise unused feature slot of the candidate table
+template <class Model>
+constexpr bool stage_usep()
+{
+    if constexpr (requires { Model::STAGE_USEP; }) return Model::STAGE_USEP && Model::NCF == 0;
+    else return false;
+}
+
 template <class Model>
 struct CandRegs {
     static constexpr unsigned UC = Model::UCONST_MASK;
@@ -245,6 +254,7 @@ struct CandRegs {
 #pragma unroll
         for (int i = 0; i < Model::DU; i++) u[i] = ro[A.cands_off + c * Model::DU + i];
         cf[0] = 0.0;
+        if constexpr (stage_usep<Model>()) cf[0] = Model::stage_u(A.prm, u);
 #pragma unroll
         for (int i = 0; i < Model::NCF; i++) cf[i] = ro[A.cfeat_off + c * Model::NCF + i];
         rpm[0] = rpp[0] = qab = 0.0;
@@ -468,6 +478,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         Model::drift(A.prm, nd, x, u, cf0, b);
         Model::sigma(A.prm, x, u, s);
         if constexpr (!Model::STAGE_UDEP) stage0 = Model::stage(A.prm, x, u);
+        else if constexpr (stage_usep<Model>()) stage0 = Model::stage_x(A.prm, x); // + the candidate's stage_u below
 #pragma unroll
         for (int m = 0; m < D; m++) {
             if (!((UM >> m) & 1u)) {
@@ -526,7 +537,9 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
                     double b[D], sg[D];
                     Model::drift(A.prm, nd, x, u, cf, b);
                     Model::sigma(A.prm, x, u, sg);
-                    const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
+                    double stage = stage0;
+                    if constexpr (stage_usep<Model>()) stage = stage0 + cr.get_cf(0, c);
+                    else if constexpr (Model::STAGE_UDEP) stage = Model::stage(A.prm, x, u);
                     double Qa = 0.0, Qb = 0.0, PVa = 0.0, PVb = 0.0; // two short chains instead of one long one
 #pragma unroll
                     for (int m = 0; m < D; m++) {
@@ -605,7 +618,9 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
             double b[D], s[D];
             Model::drift(A.prm, nd, x, u, cf, b);
             Model::sigma(A.prm, x, u, s);
-            const double stage = Model::STAGE_UDEP ? Model::stage(A.prm, x, u) : stage0;
+            double stage = stage0;
+            if constexpr (stage_usep<Model>()) stage = stage0 + cr.get_cf(0, c);
+            else if constexpr (Model::STAGE_UDEP) stage = Model::stage(A.prm, x, u);
             double Q = Q0, PV = PV0;
             constexpr unsigned UCg = Model::UCONST_MASK;
 #pragma unroll

@@ -160,6 +160,22 @@ struct LqgNd {
         for (int i = 0; i < DU; i++) s += u[i] * u[i];
         return s;
     }
+    // stage = stage_x(x) + stage_u(u): the control's share is a constant of the candidate (kept in the candidate table)
+    static constexpr bool STAGE_USEP = true;
+    __device__ static inline double stage_x(const double *, const double (&x)[D])
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) s += x[i] * x[i];
+        return s;
+    }
+    __device__ static inline double stage_u(const double *, const double *u)
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < DU; i++) s += u[i] * u[i];
+        return s;
+    }
     __device__ static inline double boundcost(const double *, const double (&)[D]) { return 100.0; }
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
 };

@@ -372,6 +372,16 @@ __device__ inline double exp_small(double x)
     return fma(p, x, 1.0);
 }
 
+// exp(x) for |x| < 2^-10: degree 4 (truncation x^5/120 < 2^-56, below an ulp)
+__device__ inline double exp_tiny(double x)
+{
+    double p = sgpr_const(1.0 / 24.0);
+    p = fma(p, x, sgpr_const(1.0 / 6.0));
+    p = fma(p, x, 0.5);
+    p = fma(p, x, 1.0);
+    return fma(p, x, 1.0);
+}
+
 __device__ inline double exp_discount(double x)
 {
     if (__all(fabs(x) < 0.0078125)) return exp_small(x);
@@ -603,6 +613,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     // every candidate only adds rates to Q0, so dt_c <= h2/Q0: if beta*h2/Q0 is small on every lane, the discount
     // factor of every candidate takes the polynomial and the per-candidate wave vote is not needed
     const bool all_small = __all(discl * h2l < 0.0078125 * Q0);
+    const bool all_tiny = __all(discl * h2l < 0.0009765625 * Q0); // 2^-10: four terms are exact to an ulp
     for (int c0 = 0; c0 < nc; c0 += CG) {
         double val[CG];
         bool ok[CG];
@@ -652,7 +663,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
             const double dt = h2l * inv;               // nodeutil.c:369
             const double pself = fma(-Qs, inv, 1.0);   // 1 - sum_i p_i/Q: rounding residue, as in the reference
             const double ctg = fma(pself, V[2 * D], PV * inv);
-            const double ebt = (A.discount == 0.0) ? 1.0 : (all_small ? exp_small(-discl * dt) : exp_discount(-discl * dt)); // bellman.c:94
+            const double ebt = (A.discount == 0.0) ? 1.0 : (all_tiny ? exp_tiny(-discl * dt) : (all_small ? exp_small(-discl * dt) : exp_discount(-discl * dt))); // bellman.c:94
             val[q] = dt * stage + ebt * ctg;                                 // bellman.c:97
         }
 #pragma unroll

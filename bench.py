@@ -59,7 +59,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="car7d")
-    ap.add_argument("--fibers", type=int, default=1 << 17, help="fibers per varying dimension per GPU per step")
+    ap.add_argument("--fibers", type=int, default=None,
+                    help="fibers per varying dimension per GPU per step (default: 2^20 for car7d, the roofline batch of "
+                         "SURVEY.md 8d; 2^17 for the other workloads)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -91,7 +93,7 @@ def main():
     if args.variant:
         eng.set_variant(args.variant)
 
-    F = args.fibers
+    F = args.fibers if args.fibers is not None else ((1 << 20) if args.workload == "car7d" else (1 << 17))
     d = w.dx
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
@@ -157,12 +159,13 @@ def main():
     # process, so the committed summary of the same command is read (profiles/README.md says how it was made).
     traffic, traffic_src = None, None
     try:
-        if args.workload == "car7d" and F == (1 << 17):
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_fiber_pair_pmc.json")))
+        pmc_file = {1 << 17: "r01_f_fiber_pair_pmc.json", 1 << 20: "r01_g_fiber_pair_pmc.json"}.get(F)
+        if args.workload == "car7d" and pmc_file:
+            pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             ks = [v for kname, v in pm["kernels"].items() if "k_fiber_pair" in kname]
             if ks and "fiber_pair" in eng.last_kernel():
                 traffic = float(np.mean([v["fetch_bytes_x2_gfx950_correction"] + v["write_bytes_per_launch"] for v in ks]))
-                traffic_src = "profiles/r01_f_fiber_pair_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2)"
+                traffic_src = "profiles/" + pmc_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2)"
     except (OSError, KeyError, ValueError):
         pass
     kern = eng.last_kernel()

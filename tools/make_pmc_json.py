@@ -2,7 +2,9 @@
 usage: python tools/make_pmc_json.py out.json dir1 dir2 ...   (per-dispatch averages per kernel)"""
 import collections, csv, glob, json, re, sys
 
-NODES = 5373952
+import os
+
+NODES = int(os.environ.get("C3SC_PMC_NODES", 5373952))  # node backups per launch of the profiled run (F x N)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[2:]:
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):

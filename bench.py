@@ -30,30 +30,54 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 vector = FP64 matrix (SURVEY.md
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(w, cores, budget_s=12.0):
-    """Oracle (CPU restatement of the reference algorithm, 1 thread) timed on this box's host
-    cores on a bounded sample of the same workload.  The oracle is only the checker/baseline
-    here -- never the thing measured as the product."""
+def _cpu_worker(workload, budget_s, wid):
+    """One host core's share of the CPU baseline: runs in its own process (no torch, no GPU), prints one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from c3sc_amd import workloads as wl
 
-    if not os.path.exists(os.path.join(ROOT, "oracle", "libc3sc_oracle.so")):
-        oracle_lib.build()
-    P = oracle_lib.Problem(w, cores)
+    w = wl.WORKLOADS[workload]()
+    P = oracle_lib.Problem(w, wl.synth_cores(w))
     nodes, t0, chunk, k = 0, time.perf_counter(), 256, 0
     while time.perf_counter() - t0 < budget_s:
-        idx = wl.synth_fibers(w, k % w.dx, chunk, seed=0xBA5E + k)
+        idx = wl.synth_fibers(w, k % w.dx, chunk, seed=0xBA5E + 7919 * wid + k)
         P.bellman_fibers(k % w.dx, idx, want_absorbed=False)
         nodes += chunk * w.ngrid[k % w.dx]
         k += 1
-    dt = time.perf_counter() - t0
-    return {"value": nodes / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
-            "sample": f"{nodes} node backups ({k} chunks of {chunk} random fibers, dims round-robin) in {dt:.1f} s, "
-                      f"oracle/c3sc_oracle.c -O2 single thread, {os.cpu_count()} host cores visible"}
+    print(json.dumps({"nodes": nodes, "seconds": time.perf_counter() - t0, "chunks": k}), flush=True)
+
+
+def cpu_baseline(w, cores, budget_s=12.0, nproc=None):
+    """Oracle (CPU restatement of the reference algorithm) timed on this box's host cores on a bounded sample of the
+    same workload: `nproc` single-threaded worker processes, each on its own fibers for `budget_s` seconds (fibers are
+    independent, so this is the fiber-parallel CPU path of SURVEY.md 8d).  The oracle is only the checker / baseline
+    here -- never the thing measured as the product."""
+    import subprocess
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libc3sc_oracle.so")):
+        oracle_lib.build()
+    if nproc is None:
+        nproc = max(1, min(16, os.cpu_count() or 1))  # the GPU box's CPU share for one GPU
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", w.name, str(budget_s), str(i)],
+                              stdout=subprocess.PIPE, env=env) for i in range(nproc)]
+    outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
+    nodes = sum(o["nodes"] for o in outs)
+    wall = max(o["seconds"] for o in outs)
+    per_core = float(np.mean([o["nodes"] / o["seconds"] for o in outs]))
+    return {"value": nodes / wall, "unit": "nodes/s", "cores": nproc, "kind": "port", "per_core": per_core,
+            "sample": f"{nodes} node backups ({sum(o['chunks'] for o in outs)} chunks of 256 random fibers, dims round-robin) in "
+                      f"{wall:.1f} s on {nproc} single-threaded worker processes, oracle/c3sc_oracle.c -O2, "
+                      f"{os.cpu_count()} host cores visible"}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline: before anything touches torch / the GPU
+        _cpu_worker(sys.argv[2], float(sys.argv[3]), int(sys.argv[4]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -65,6 +89,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--cpu-procs", type=int, default=None, help="worker processes of the CPU baseline (default min(16, cores))")
     args = ap.parse_args()
 
     import torch
@@ -208,7 +233,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(w, cores, args.cpu_budget)
+            res["cpu_baseline"] = cpu_baseline(w, cores, args.cpu_budget, args.cpu_procs)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

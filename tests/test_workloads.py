@@ -42,3 +42,16 @@ def test_smooth_cores_are_exact():
             v = v @ G
         want = sum(c * xg[m][ind[m]] ** 2 for m, c in enumerate([1.0, 2.0, 3.0]))
         assert abs(v[0] - want) < 1e-13
+
+
+def test_bench_cpu_baseline_worker_runs_without_gpu():
+    """bench.py's cpu_baseline leg: one worker process (oracle, no torch / GPU) returns its node count and time."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--cpu-worker", "car7d", "0.5", "3"], timeout=120)
+    r = json.loads(out.decode().strip().splitlines()[-1])
+    assert r["nodes"] > 0 and r["nodes"] % 41 == 0 and 0.5 <= r["seconds"] < 30 and r["chunks"] >= 1

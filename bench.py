@@ -102,12 +102,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # C3SC_BENCH_FORCE_DIST=1 takes the RCCL path (process group, all-gather, barrier, max-reduce) with a single rank too:
+    # a rehearsal of the multi-GPU code on a one-GPU box
+    use_dist = world > 1 or os.environ.get("C3SC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)  # RCCL
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -147,12 +153,12 @@ def main():
                 e1.record(stream)
                 ev.append((k, e0, e1))
         # end of sweep: exchange the updated cores and re-stage them for the next sweep
-        gathered = allgather_cores(shard, world) if world > 1 else flat_t
+        gathered = allgather_cores(shard, world, force=use_dist) if use_dist else flat_t
         eng.upload_value_device(w.ranks, core_views(gathered), sp)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -165,7 +171,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
     status = eng.status()
@@ -237,7 +243,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

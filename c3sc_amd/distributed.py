@@ -31,13 +31,13 @@ def padded_len(n: int, world: int) -> int:
     return ((n + world - 1) // world) * world
 
 
-def allgather_cores(shard_t, world: int):
+def allgather_cores(shard_t, world: int, force: bool = False):
     """All-gather equal-size shards of the flattened cores; returns the full (padded) flat tensor."""
     import torch
     import torch.distributed as dist
 
     full = torch.empty(shard_t.numel() * world, dtype=shard_t.dtype, device=shard_t.device)
-    if world == 1:
+    if world == 1 and not force:  # force: go through the collective with a single rank too (rehearsal)
         full.copy_(shard_t)
     else:
         dist.all_gather_into_tensor(full, shard_t.contiguous())

@@ -282,6 +282,7 @@ void c3sc_hip_ctx_destroy(c3sc_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->arena) (void)hipFree(c->arena);
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_dbg) (void)hipFree(c->d_dbg);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -507,11 +508,11 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
     for (int i = 0; i < 2 * c->d; i++) A.t[i] = c->t[i];
     for (int i = 0; i < C3SC_MAX_PARAMS; i++) A.prm[i] = c->prm[i];
     A.status = c->d_status;
-    if (!c->d_dbg) { HIPCHK(c, hipMalloc((void **)&c->d_dbg, 65536 * 8 * sizeof(unsigned long long))); }
-    A.dbgbuf = c->d_dbg;
     { // ablation switches of the diagnostic build (make STAMPS=1); read once
         static const int dbg_env = [] { const char *e = getenv("C3SC_DBG"); return e ? atoi(e) : 0; }();
         A.dbg = dbg_env;
+        if (dbg_env && !c->d_dbg) { HIPCHK(c, hipMalloc((void **)&c->d_dbg, 65536 * 8 * sizeof(unsigned long long))); } // stamp buffer
+        A.dbgbuf = c->d_dbg;
         if (A.dbg & 8) A.ncand = 1;
         if (A.dbg & 16) A.ncand = 3;
     }

@@ -379,3 +379,38 @@ def test_large_core_not_staged_in_lds(oracle):
     eng3 = _engine(w3, cores3)
     for k in (0, 1, 2):
         _check(eng3, P3, w3, k, wl.synth_fibers(w3, k, 9))
+
+
+@pytest.mark.gpu
+def test_c_abi_error_behaviour():
+    """The boundary reports, it does not crash: bad arguments and missing state give C3SC_ERR_ARG, a rank no kernel
+    serves C3SC_ERR_UNSUPPORTED, each with text in c3sc_hip_last_error; F = 0 is a no-op; the context stays usable."""
+    import ctypes as C
+
+    from c3sc_amd.engine import BellmanEngine, C3scHipError, load_library
+
+    L = load_library()
+    w = wl.c2_dubins().scaled(ngrid=(11, 9, 13), rank=4)
+    cores = wl.synth_cores(w)
+    eng = BellmanEngine(0)
+    idx = wl.synth_fibers(w, 0, 8)
+    out = np.zeros((8, w.ngrid[0]))
+    # nothing configured yet
+    rc = L.c3sc_hip_bellman_fibers_host(eng.h, 0, C.c_size_t(8), idx.ctypes.data, out.ctypes.data, None, None)
+    assert rc == 1 and len(L.c3sc_hip_last_error(eng.h)) > 0
+    eng.configure(w, cores)
+    for k_bad in (-1, 3):
+        assert L.c3sc_hip_bellman_fibers_host(eng.h, k_bad, C.c_size_t(8), idx.ctypes.data, out.ctypes.data, None, None) == 1
+    assert L.c3sc_hip_bellman_fibers_host(eng.h, 0, C.c_size_t(0), None, None, None, None) == 0  # empty batch
+    assert L.c3sc_hip_bellman_fibers(eng.h, 0, C.c_size_t(8), None, None, None, None, None) == 1  # null device buffers
+    assert L.c3sc_hip_get_status(None, None, 0) == 1
+    assert L.c3sc_hip_max_rank(w.model, 3) >= 16 and L.c3sc_hip_max_rank(w.model, 9) == 0 and L.c3sc_hip_max_rank(12345, 3) == 0
+    # a rank above every compiled kernel of this model
+    big = wl.c2_dubins().scaled(ngrid=(11, 9, 13), rank=24)
+    with pytest.raises(C3scHipError) as ei:
+        eng.upload_value(big.ranks, wl.synth_cores(big))
+    assert "code 3" in str(ei.value)
+    # still usable afterwards
+    eng.upload_value(w.ranks, cores)
+    got, _, _ = eng.bellman_fibers_host(0, idx)
+    assert np.isfinite(got).all() and eng.status() == 0

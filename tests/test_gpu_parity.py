@@ -414,3 +414,19 @@ def test_c_abi_error_behaviour():
     eng.upload_value(w.ranks, cores)
     got, _, _ = eng.bellman_fibers_host(0, idx)
     assert np.isfinite(got).all() and eng.status() == 0
+
+
+@pytest.mark.gpu
+def test_host_entry_zero_copy_and_staged_paths_agree():
+    """c3sc_hip_bellman_fibers_host serves batches up to 1 MiB from a pinned device-mapped block and larger ones through
+    device scratch: the same fibers must come back bit for bit (values, argmin, absorbed flags) either way."""
+    w = wl.c4_car7d().scaled(ngrid=(11,) * 7, rank=10)
+    cores = wl.synth_cores(w)
+    eng = _engine(w, cores, 0)
+    for k in (0, 3, 6):
+        big = wl.synth_fibers(w, k, 9000)  # 9000 x (28 + 88 + 88) B > 1 MiB: staged
+        small = big[:100].copy()           # zero-copy
+        o1, u1, a1 = eng.bellman_fibers_host(k, small)
+        o2, u2, a2 = eng.bellman_fibers_host(k, big)
+        assert np.array_equal(o1, o2[:100]) and np.array_equal(u1, u2[:100]) and np.array_equal(a1, a2[:100])
+    assert eng.status() == 0

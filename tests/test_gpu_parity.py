@@ -430,3 +430,32 @@ def test_host_entry_zero_copy_and_staged_paths_agree():
         o2, u2, a2 = eng.bellman_fibers_host(k, big)
         assert np.array_equal(o1, o2[:100]) and np.array_equal(u1, u2[:100]) and np.array_equal(a1, a2[:100])
     assert eng.status() == 0
+
+
+@pytest.mark.gpu
+def test_device_api_on_a_side_stream_and_repeatable():
+    """c3sc_hip_upload_value_device / c3sc_hip_bellman_fibers enqueue on the stream they are given (a non-default HIP stream
+    here, ordered against nothing else), and the kernels are deterministic: the same launch twice gives the same bits."""
+    import torch
+
+    w = wl.c4_car7d().scaled(ngrid=(13,) * 7, rank=10)
+    cores = wl.synth_cores(w)
+    eng = _engine(w, cores, 3)  # fiber-pair
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    k = 2
+    idx = wl.synth_fibers(w, k, 20000)
+    ref, _, _ = eng.bellman_fibers_host(k, idx)  # default stream, host buffers
+    with torch.cuda.stream(side):
+        core_t = [torch.from_numpy(np.ascontiguousarray(c)).to(dev, non_blocking=False) for c in cores]
+        idx_t = torch.from_numpy(idx).to(dev)
+        out1 = torch.empty((idx.shape[0], w.ngrid[k]), dtype=torch.float64, device=dev)
+        out2 = torch.empty_like(out1)
+        eng.upload_value_device(w.ranks, core_t, side.cuda_stream)
+        eng.bellman_fibers(k, idx_t, out1, stream_ptr=side.cuda_stream)
+        eng.bellman_fibers(k, idx_t, out2, stream_ptr=side.cuda_stream)
+    side.synchronize()
+    a, b = out1.cpu().numpy(), out2.cpu().numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, ref)
+    assert eng.status() == 0

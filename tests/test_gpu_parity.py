@@ -459,3 +459,28 @@ def test_device_api_on_a_side_stream_and_repeatable():
     assert np.array_equal(a, b)
     assert np.array_equal(a, ref)
     assert eng.status() == 0
+
+
+@pytest.mark.gpu
+def test_one_workgroup_per_tile_launch_path(oracle):
+    """Above 8 tiles per resident workgroup slot the pair kernel is launched with one workgroup per tile instead of
+    persistent workgroups (launch_fpp.hpp).  600 000 fibers on a small grid take that path: every row must equal the per-wave
+    kernel's, and a sample of rows the oracle's."""
+    w = wl.c4_car7d().scaled(ngrid=(11,) * 7, rank=4)
+    cores = wl.synth_cores(w)
+    eng = _engine(w, cores, 0)
+    P = oracle.Problem(w, cores)
+    F = 600_000  # 9375 tiles >= 8 x 1024
+    for k in (0, 4):
+        idx = wl.synth_fibers(w, k, F)
+        eng.set_variant(3)
+        a, ua, aa = eng.bellman_fibers_host(k, idx)
+        assert "fiber_pair" in eng.last_kernel()
+        eng.set_variant(1)
+        b, ub, ab = eng.bellman_fibers_host(k, idx)
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= REL_TOL * scale and np.array_equal(aa, ab)
+        pick = np.random.default_rng(k).choice(F, 300, replace=False)
+        ref, _, rab = P.bellman_fibers(k, idx[pick])
+        assert np.abs(a[pick] - ref).max() <= REL_TOL * scale and np.array_equal(aa[pick], rab)
+    assert eng.status() == 0

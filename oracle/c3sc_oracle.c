@@ -1204,3 +1204,20 @@ int orc_stencil_fibers(struct orc_problem *p, size_t k, size_t F, const int *idx
     free(ab);
     return res;
 }
+
+/* ---- the two fiber callbacks in the ABI the cross approximation calls (valuefunc.c:615-616:
+ * int f(size_t N, const double *x, double *out, void *args)), so that a test can hand them to a cross driver as the
+ * black box, the way c3control_step_vi / step_pi do (bellman.c:2201, 2254).  args = struct orc_cb_args. ---- */
+int orc_cb_bellman_vi(size_t N, const double *x, double *out, void *args)
+{
+    struct orc_cb_args *a = args;
+    a->ncalls++;
+    return orc_bellman_vi(a->p, N, x, out, NULL, a->use_memo);
+}
+
+int orc_cb_bellman_pi(size_t N, const double *x, double *out, void *args)
+{
+    struct orc_cb_args *a = args;
+    a->ncalls++;
+    return orc_bellman_pi(a->p, a->policy, N, x, out, NULL);
+}

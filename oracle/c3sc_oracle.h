@@ -161,6 +161,11 @@ int orc_policy_eval(struct orc_problem *p, const double *x, int *uidx, double *v
 /* Same for the FT stencil only: out F*N*(2dx+1). */
 int orc_stencil_fibers(struct orc_problem *p, size_t k, size_t F, const int *idx, double *out, int *absorbed_out);
 
+/* The fiber callbacks in the cross approximation's ABI (valuefunc.c:615-616); args points to a struct orc_cb_args. */
+struct orc_cb_args { struct orc_problem *p; struct orc_valuef *policy; int use_memo; size_t ncalls; };
+int orc_cb_bellman_vi(size_t N, const double *x, double *out, void *args); /* bellman_vi, bellman.h:96  */
+int orc_cb_bellman_pi(size_t N, const double *x, double *out, void *args); /* bellman_pi, bellman.h:105 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,218 @@
+"""The reference's end-to-end regression (test/transition_prob/tprob_test.c:1996-2357: Test_bellman_pi_25_const, _25,
+_50, _100 -- the last one is the only test AllMyTests.c:59-62 runs) as a call sequence that can be driven two ways:
+
+* `GpuLoop`    -- through libc3sc.so exactly as the reference test calls it (c3control_create, add_*, set_external_boundary,
+                  init_value(quad2d), then per control update pi_solve(10) + vi_solve(1)); every fiber runs on the device.
+* `OracleLoop` -- the same outer loops (bellman.c:2282-2407 restated below) over the same cross driver (valuef_interp, host
+                  code), with the black-box fiber function being the CPU oracle's bellman_vi / bellman_pi
+                  (oracle/c3sc_oracle.c: orc_cb_bellman_vi / orc_cb_bellman_pi, C function pointers -- no Python in the
+                  inner loop).  This is the "reference CPU path" of the parity statement.
+
+Problem of the regression (tprob_test.c:132-168, 253-318, 1389-1398): dx=2, du=1, dw=2, drift (x1, u), diffusion I,
+stage x0^2+x1^2+u^2, boundcost 100, obscost 0, [-2,2]^2, reflect/reflect, discount 0.1, start value 0.2, u in [-1,1].
+Those callbacks are the LQG-nD model with params (2, 1, 1) (oracle ORC_MODEL_LQGND == examples/lqgnd/lqgnd.c with dim=2).
+The reference minimises over u with C3's BFGS (absent third party, nondeterministic multistart); here the deterministic
+stand-ins: a 33-point candidate list on [-1,1] (both loops, so they can be compared node by node) and the library's box
+minimiser behind the reference's own c3opt_alloc(BFGS)+bounds set-up (GPU loop only).
+The anchor the reference holds: |100 - ||V||_L2| / 100 <= 0.1 ("FROM PAPER", :2075, 2189, 2265, 2346-2348)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+from c3sc_amd import workloads as wl  # noqa: E402
+
+# name -> (ngrid, max control updates, convergence, adapt, startrank, break when |V_vi - V_pi| < convergence)
+CASES = {
+    "pi_25_const": (25, 10000, 1e-5, 0, 3, True),   # tprob_test.c:1996-2119 (the CONSTELM line is commented out: 2032)
+    "pi_25": (25, 400, 1e-4, 1, 5, False),          # :2122-2197
+    "pi_50": (50, 1000, 1e-4, 1, 5, False),         # :2199-2273
+    "pi_100": (100, 10000, 1e-7, 1, 5, True),       # :2275-2357
+}
+
+
+def workload(n):
+    w = wl.c1_lqg2d().scaled(ngrid=(n, n))
+    assert w.discount == 0.1 and w.params == (2.0, 1.0, 1.0) and tuple(w.lb) == (-2.0, -2.0) and tuple(w.ub) == (2.0, 2.0)
+    return w
+
+
+class _Base:
+    def __init__(self, case, minimiser="bruteforce"):
+        import facade_lib
+
+        self.fl = facade_lib
+        self.L = L = facade_lib.lib()
+        for n in ("c3control_init_value", "c3control_step_vi", "c3control_vi_solve", "c3control_pi_solve", "valuef_interp",
+                  "valuef_copy"):
+            getattr(L, n).restype = C.c_void_p
+        for n in ("valuef_norm", "valuef_norm2diff", "valuef_eval_ind"):
+            getattr(L, n).restype = C.c_double
+        L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+        L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
+        self.case = case
+        self.n, self.max_updates, self.conv, adapt, startrank, self.break_on_conv = CASES[case]
+        self.w = workload(self.n)
+        box = None if minimiser == "bruteforce" else ([-1.0], [1.0])  # tprob_test.c:2290-2299
+        self.ctl = facade_lib.Control(self.w, box=box)
+        aa = C.c_void_p(L.approx_args_init())  # tprob_test.c:2303-2309
+        L.approx_args_set_cross_tol(aa, C.c_double(1e-8))
+        L.approx_args_set_round_tol(aa, C.c_double(1e-7))
+        L.approx_args_set_kickrank(aa, C.c_size_t(5))
+        L.approx_args_set_adapt(aa, C.c_int(adapt))
+        L.approx_args_set_startrank(aa, C.c_size_t(startrank))
+        L.approx_args_set_maxrank(aa, C.c_size_t(20))
+        self.aa = aa
+        self._quad2d = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.2), 0)[1])
+        self.history = []  # (update, |V_vi - V_pi|, |V|, rank)
+        self.sweeps = 0
+
+    def init_value(self):
+        return C.c_void_p(self.L.c3control_init_value(self.ctl.h, self._quad2d, None, self.aa, 0))
+
+    def norm(self, vf):
+        return self.L.valuef_norm(vf)
+
+    def rank(self, vf):
+        return int(self.L.valuef_get_ranks(vf)[1])
+
+    def cores_of(self, vf):
+        w = self.w
+        ranks = [int(self.L.valuef_get_ranks(vf)[i]) for i in range(w.dx + 1)]
+        pp = self.L.valuef_get_cores(vf)
+        return ranks, [np.ctypeslib.as_array(pp[m], shape=(w.ngrid[m] * ranks[m] * ranks[m + 1],)).copy() for m in range(w.dx)]
+
+    def nodal(self, vf):
+        """Every nodal value V[i0, i1] (2-D: G0[i0] (1 x r) times G1[i1] (r x 1))."""
+        ranks, cores = self.cores_of(vf)
+        r = ranks[1]
+        return cores[0].reshape(self.n, r) @ cores[1].reshape(self.n, r).T
+
+    # the reference test's outer loop (tprob_test.c:2329-2344); pi_solve / vi_solve supplied by the subclass
+    def run(self, max_updates=None, cost=None, budget_s=None, on_update=None):
+        L = self.L
+        if cost is None:
+            cost = self.init_value()
+        t0 = time.time()
+        nupd = self.max_updates if max_updates is None else min(max_updates, self.max_updates)
+        for ii in range(nupd):
+            nxt = self.pi_solve(10, self.conv, cost)
+            L.valuef_destroy(cost)
+            tmp = self.vi_solve(1, self.conv, nxt)
+            diff = L.valuef_norm2diff(nxt, tmp)
+            L.valuef_destroy(nxt)
+            cost = tmp
+            self.history.append((ii, diff, L.valuef_norm(cost), self.rank(cost)))
+            if on_update is not None:
+                on_update(ii, cost)
+            if self.break_on_conv and diff < self.conv:
+                break
+            if budget_s is not None and time.time() - t0 > budget_s:
+                break
+        return cost
+
+    def close(self):
+        self.L.approx_args_free(self.aa)
+        self.ctl.close()
+
+
+class GpuLoop(_Base):
+    """libc3sc.so's own loops: the product path (device kernels for every fiber)."""
+
+    def pi_solve(self, maxiter, tol, policy):
+        diag = C.c_void_p(None)
+        out = C.c_void_p(self.L.c3control_pi_solve(self.ctl.h, C.c_size_t(maxiter), C.c_double(tol), policy, self.aa, self.ctl.opt, 0,
+                                                   C.byref(diag)))
+        self.L.diag_count.restype = C.c_size_t
+        self.sweeps += self.L.diag_count(diag)
+        self.L.diag_destroy(C.byref(diag))
+        return out
+
+    def vi_solve(self, maxiter, tol, vo):
+        self.sweeps += maxiter
+        return C.c_void_p(self.L.c3control_vi_solve(self.ctl.h, C.c_size_t(maxiter), C.c_double(tol), vo, self.aa, self.ctl.opt, 0, None))
+
+
+class _CbArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("policy", C.c_void_p), ("use_memo", C.c_int), ("ncalls", C.c_size_t)]
+
+
+class OracleLoop(_Base):
+    """bellman.c:2177-2407 restated over valuef_interp with the oracle's fibers (brute-force candidates only)."""
+
+    def __init__(self, case):
+        super().__init__(case, "bruteforce")
+        import oracle_lib
+
+        self.ol = oracle_lib
+        self.O = oracle_lib.lib()
+        self.P = oracle_lib.Problem(self.w)
+        self.xg = [self.fl.f64(g) for g in self.ctl.xgrid()]
+        for m in range(self.w.dx):
+            assert np.array_equal(self.xg[m], self.P.xgrid(m))  # both sides' linspace (bellman.c:1977-1979) agree bit for bit
+        self.gp = self.fl.ptrs(self.xg)
+        self.Ng = self.fl.usz(self.w.ngrid)
+        self.cb_vi = C.cast(self.O.orc_cb_bellman_vi, C.c_void_p)
+        self.cb_pi = C.cast(self.O.orc_cb_bellman_pi, C.c_void_p)
+        self.L.valuef_interp.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+
+    def _orc_vf(self, vf):
+        ranks, cores = self.cores_of(vf)
+        return self.ol.ValueF(self.w.ngrid, ranks, [c.reshape(self.w.ngrid[m], -1) for m, c in enumerate(cores)])
+
+    def _interp(self, cb, args, warm):
+        return C.c_void_p(self.L.valuef_interp(self.w.dx, cb, C.addressof(args), self.Ng.ctypes.data, C.addressof(self.gp), warm, self.aa, 0))
+
+    def step_vi(self, vf):  # bellman.c:2177-2212
+        ovf = self._orc_vf(vf)
+        self.O.orc_problem_set_value(self.P.h, ovf.h)
+        self.P.increment_vi_iter()
+        args = _CbArgs(self.P.h.value, None, 1, 0)
+        nxt = self._interp(self.cb_vi, args, vf)
+        self.sweeps += 1
+        return nxt
+
+    def vi_solve(self, maxiter, tol, vo):  # bellman.c:2282-2340
+        L = self.L
+        start = C.c_void_p(L.valuef_copy(vo))
+        self.O.orc_problem_reset_vi_htable(self.P.h)
+        for ii in range(maxiter):
+            if ii % 1000 == 0:
+                self.O.orc_problem_reset_vi_htable(self.P.h)
+            nxt = self.step_vi(start)
+            diff = L.valuef_norm2diff(start, nxt)
+            L.valuef_destroy(start)
+            start = nxt
+            if diff < tol:
+                break
+        return start
+
+    def pi_solve(self, maxiter, tol, policy):  # bellman.c:2343-2407
+        L = self.L
+        start = C.c_void_p(L.valuef_copy(policy))
+        pol = self._orc_vf(policy)
+        self.P.pi_begin()
+        for ii in range(maxiter):
+            ovf = self._orc_vf(start)  # step_pi, bellman.c:2214-2262
+            self.O.orc_problem_set_value(self.P.h, ovf.h)
+            self.P.pi_step_begin()
+            args = _CbArgs(self.P.h.value, pol.h.value, 1, 0)
+            nxt = self._interp(self.cb_pi, args, start)
+            self.sweeps += 1
+            diff = L.valuef_norm2diff(start, nxt)
+            L.valuef_destroy(start)
+            start = nxt
+            if diff < tol:
+                break
+        return start
+
+
+def anchor(norm):
+    """tprob_test.c:2346-2348."""
+    return abs(100.0 - norm) / 100.0

@@ -484,3 +484,69 @@ def test_one_workgroup_per_tile_launch_path(oracle):
         ref, _, rab = P.bellman_fibers(k, idx[pick])
         assert np.abs(a[pick] - ref).max() <= REL_TOL * scale and np.array_equal(aa[pick], rab)
     assert eng.status() == 0
+
+
+# ---- the BASELINE.json configurations at the instantiations and sizes the bench / examples actually run ----------------
+FULL = [
+    # (workload, scale kwargs, variant, kernel tag, fibers per dim)
+    ("car7d", dict(), 3, "fiber_pair<Car7D,10", 64),            # C4: N=41, r=10 -- the code object bench.py times
+    ("car7d", dict(), 1, "fiber_per_wave<Car7D,10", 64),        # the kernel the solver's small batches take
+    ("quad10d", dict(ngrid=(7, 6, 5, 8, 7, 6, 5, 8, 7, 25)), 0, "Chain<10>,16", 48),  # C5 at rank 15 (padded rank 16)
+    ("dubins3d", dict(), 3, "fiber_pair<Dubins3D,6", 40),       # C2: 101^3, r=6
+    ("dubins3d", dict(), 1, "fiber_per_wave<Dubins3D,6", 40),
+    ("lqg6d", dict(), 3, "fiber_pair<LqgNd<6>,8", 40),          # C3: 31^6, r=8
+    ("lqg6d", dict(), 1, "fiber_per_wave<LqgNd<6>,8", 40),
+    ("scar4d", dict(), 0, "Scar", 40),                          # the reference's own skidding car: 40^4, rank 20
+]
+
+
+@pytest.mark.parametrize("name,kw,variant,tag,nf", FULL, ids=[f"{f[0]}-v{f[2]}" for f in FULL])
+def test_baseline_configs_at_the_benched_instantiation(oracle, name, kw, variant, tag, nf):
+    """Oracle comparison at the exact (model, padded rank, N) instantiations of BASELINE.json's configs: every varying
+    dimension, faces and wrap-around included; a few dozen fibers per dimension cost the oracle milliseconds."""
+    w = wl.WORKLOADS[name]().scaled(**kw) if kw else wl.WORKLOADS[name]()
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    eng = _engine(w, cores, variant)
+    worst = 0.0
+    for k in range(w.dx):
+        idx = wl.synth_fibers(w, k, nf)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        idx[2, :] = 1
+        idx[:, k] = 0
+        worst = max(worst, _check(eng, P, w, k, idx))
+        assert tag in eng.last_kernel(), eng.last_kernel()
+    print(f"{name} {w.ngrid} ranks {w.ranks[1]}: {eng.last_kernel()} max rel err {worst:.2e}")
+
+
+def test_stationary_node_raises_the_status_flag(oracle):
+    """transition_assemble returns 1 when the total rate Q < 1e-14 (nodeutil.c:365-367) and bellman_control asserts on it
+    (bellman.c:452).  2-D LQG with zero diffusion: at x1 = 0 the candidate u = 0 has zero drift in both dimensions.  The
+    oracle fails the fiber with code 101; the device must raise C3SC_STATUS_STATIONARY -- and leave it clear otherwise."""
+    w0 = wl.c1_lqg2d().scaled(ngrid=(51, 51), rank=4)
+    w = wl.Workload(w0.name, w0.model, (2.0, 0.0, 0.0), w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, w0.discount, w0.bc, [], w0.cands)
+    assert w.xgrid()[1][25] == 0.0 and w.cands[16, 0] == 0.0
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    import ctypes as C
+
+    for variant in (1, 3):
+        eng = _engine(w, cores, variant)
+        # fibers along dim 0 at x1 != 0: every candidate has drift x1 in dim 0 -> fine
+        ok = np.array([[0, 3], [0, 40]], dtype=np.int32)
+        out, _, _ = eng.bellman_fibers_host(0, ok)
+        ref, _, _ = P.bellman_fibers(0, ok)
+        assert eng.status() == 0 and np.abs(out - ref).max() <= REL_TOL * np.abs(ref).max()
+        # a fiber through x1 = 0: stationary at u = 0
+        bad = np.array([[0, 25]], dtype=np.int32)
+        o = np.zeros((1, 51)); u = np.zeros((1, 51), dtype=np.int32)
+        rc = P.L.orc_bellman_fibers(P.h, C.c_size_t(0), C.c_size_t(1), bad.ctypes.data_as(C.POINTER(C.c_int)), o.ctypes.data_as(C.POINTER(C.c_double)),
+                                    u.ctypes.data_as(C.POINTER(C.c_int)), None)
+        assert rc == 101  # 100 + transition_assemble's 1
+        eng.bellman_fibers_host(0, bad)
+        assert eng.status() & 1, "C3SC_STATUS_STATIONARY not raised"
+        # and along dim 1 (the fiber crosses x1 = 0 at node 25)
+        eng2 = _engine(w, cores, variant)
+        eng2.bellman_fibers_host(1, np.array([[7, 0]], dtype=np.int32))
+        assert eng2.status() & 1

@@ -43,6 +43,34 @@ __global__ void k_pad_core(const double *__restrict__ src, double *__restrict__ 
     }
 }
 
+// Derived copies of a rank-padded middle core for the fiber-quad kernel (kernel_fiber_quad.hpp), made on the device from
+// the padded core itself: (1) the row-major transpose, (2) the two MFMA A operands of the varying-core products
+// c = G R (x = a, y = b) and a = L G (x = b, y = a): element [prod][mb][s][l] = M[x][y] with x = (i/4) C + 4 mb + i%4
+// (i = l % 16; a zero row when 4 mb + i%4 >= C) and y = (l/16) C + s, so that D register r of lane (q, t) is component
+// q C + 4 mb + r of the product for fiber t.
+__global__ void k_quad_aux(const double *__restrict__ core, double *__restrict__ coreT, double *__restrict__ aop, int N, int RP)
+{
+    const int C = RP / 4, MB = (C + 3) / 4;
+    const int per_t = RP * RP, per_a = 2 * MB * C * 64;
+    const long total = (long)N * (per_t + per_a);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / (per_t + per_a)), w = (int)(e - (long)j * (per_t + per_a));
+        const double *G = core + (size_t)j * per_t; // a + b*RP
+        if (w < per_t) {
+            const int a = w / RP, b = w % RP;
+            coreT[(size_t)j * per_t + w] = G[a + b * RP];
+        } else {
+            const int u = w - per_t;
+            const int l = u % 64, s = (u / 64) % C, mb = (u / (64 * C)) % MB, prod = u / (64 * C * MB);
+            const int i = l % 16, g = 4 * mb + i % 4;
+            const int xc = (i / 4) * C + g, yc = (l / 16) * C + s;
+            double v = 0.0;
+            if (g < C) v = (prod == 0) ? G[xc + yc * RP] : G[yc + xc * RP];
+            aop[(size_t)j * per_a + u] = v;
+        }
+    }
+}
+
 // FP64 peak probes (DESIGN.md "Roofline peaks"): dependent-free FMA streams per lane
 __global__ void k_peak_fma(double *out, int iters)
 {
@@ -104,6 +132,7 @@ struct c3sc_hip_ctx {
     size_t static_doubles = 0; // size of the static section the arena was laid out with
     bool static_dirty = true;
     long core_off[MAXD] = {0};
+    long coreT_off[MAXD] = {0}, aop_off[MAXD] = {0}; // fiber-quad copies of the middle cores (0 = none)
     int obs_off = 0, cands_off = 0, tab_off[4] = {0, 0, 0, 0}, cfeat_off = 0;
     unsigned *d_status = nullptr;
     unsigned long long *d_dbg = nullptr; // diagnostic stamps (C3SC_DBG & 128)
@@ -227,9 +256,14 @@ static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, 
     return best;
 }
 
-static int pick_rp(int d, int maxrank)
-{ // smallest padded rank any instantiation of this dimension offers
+static int pick_rp(int d, int maxrank, int model, int variant)
+{ // smallest padded rank an instantiation of this dimension offers -- of the selected variant and model when a variant
+  // is forced (its padded ranks may differ from the other kernels': the quad kernel wants multiples of 4)
     int rp = 0;
+    if (variant != C3SC_VARIANT_AUTO)
+        for (const auto &e : kernel_registry())
+            if (e.d == d && e.variant == variant && (model == 0 || e.model == model) && e.rp >= maxrank && (rp == 0 || e.rp < rp)) rp = e.rp;
+    if (rp) return rp;
     for (const auto &e : kernel_registry())
         if (e.d == d && e.rp >= maxrank && (rp == 0 || e.rp < rp)) rp = e.rp;
     return rp;
@@ -397,7 +431,7 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
         if (ranks[m] < 1) return fail(c, C3SC_ERR_ARG, "upload_value: rank < 1");
         maxrank = std::max(maxrank, ranks[m]);
     }
-    const int rp = pick_rp(d, (int)maxrank);
+    const int rp = pick_rp(d, (int)maxrank, c->model, c->variant);
     if (rp == 0) return fail(c, C3SC_ERR_UNSUPPORTED, "upload_value: no kernel instantiation for this (dim, rank)");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t stat = static_layout(c);
@@ -407,6 +441,17 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
         core_off[m] = (long)off;
         const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
         off += ((size_t)c->ngrid[m] * per + 15) & ~(size_t)15;
+    }
+    const size_t primary_end = off;
+    long coreT_off[MAXD] = {0}, aop_off[MAXD] = {0};
+    if (rp % 4 == 0) { // derived copies for the fiber-quad kernel (k_quad_aux)
+        const int C = rp / 4, MB = (C + 3) / 4;
+        for (int m = 1; m < d - 1; m++) {
+            coreT_off[m] = (long)off;
+            off += ((size_t)c->ngrid[m] * rp * rp + 15) & ~(size_t)15;
+            aop_off[m] = (long)off;
+            off += ((size_t)c->ngrid[m] * 2 * MB * C * 64 + 15) & ~(size_t)15;
+        }
     }
     if (off > c->arena_cap) {
         if (c->arena) HIPCHK(c, hipFree(c->arena));
@@ -418,11 +463,24 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
     }
     if (stat != c->static_doubles) c->static_dirty = true;
     c->static_doubles = stat;
-    for (int m = 0; m < d; m++) c->core_off[m] = core_off[m];
+    for (int m = 0; m < d; m++) { c->core_off[m] = core_off[m]; c->coreT_off[m] = coreT_off[m]; c->aop_off[m] = aop_off[m]; }
     for (int m = 0; m <= d; m++) c->ranks[m] = ranks[m];
     c->rp = rp;
-    *cores_doubles = off - stat;
+    *cores_doubles = primary_end - stat;
     if (c->static_dirty) return upload_static(c);
+    return C3SC_OK;
+}
+
+static int make_quad_aux(c3sc_hip_ctx *c, void *stream)
+{ // after the padded cores are in the arena (ordered on `stream`)
+    for (int m = 1; m < c->d - 1; m++) {
+        if (c->aop_off[m] == 0) continue;
+        const long total = (long)c->ngrid[m] * (c->rp * c->rp + 2 * ((c->rp / 4 + 3) / 4) * (c->rp / 4) * 64);
+        const int grid = (int)std::min<long>((total + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_quad_aux, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->arena + c->core_off[m],
+                           c->arena + c->coreT_off[m], c->arena + c->aop_off[m], c->ngrid[m], c->rp);
+    }
+    HIPCHK(c, hipGetLastError());
     return C3SC_OK;
 }
 
@@ -450,6 +508,8 @@ int c3sc_hip_upload_value(c3sc_hip_ctx *c, const size_t *ranks, const double *co
                 }
     }
     HIPCHK(c, hipMemcpy(c->arena + c->static_doubles, buf.data(), cd * sizeof(double), hipMemcpyHostToDevice));
+    rc = make_quad_aux(c, nullptr);
+    if (rc != C3SC_OK) return rc;
     c->have_value = true;
     return C3SC_OK;
 }
@@ -468,6 +528,8 @@ int c3sc_hip_upload_value_device(c3sc_hip_ctx *c, const size_t *ranks, const dou
                            c->ngrid[m], (int)ranks[m], (int)ranks[m + 1], rp, kind);
     }
     HIPCHK(c, hipGetLastError());
+    rc = make_quad_aux(c, stream);
+    if (rc != C3SC_OK) return rc;
     c->have_value = true;
     return C3SC_OK;
 }
@@ -497,6 +559,8 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
         A.bctype[m] = c->bctype[m];
         A.xg_off[m] = c->xg_off_rel[m];
         A.core_off[m] = c->core_off[m];
+        A.quad_coreT_off[m] = c->coreT_off[m];
+        A.quad_aop_off[m] = c->aop_off[m];
     }
     A.nobs = c->nobs;
     A.obs_off = c->obs_off;

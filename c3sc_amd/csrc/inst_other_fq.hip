@@ -1,0 +1,34 @@
+// fiber-quad (MFMA) instantiations for the other models: 10-D chain (quad10d, rank 15 -> 16), skidding car (rank 20), 6-D LQG
+#include "launch_fpw.hpp"
+#include "launch_fq.hpp"
+#include "models.hpp"
+namespace c3sc {
+#define REG10Q(RP, NWV)                                    \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 0, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 1, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 2, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 3, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 4, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 5, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 6, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 7, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 8, NWV, Chain<10>)  \
+    C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 9, NWV, Chain<10>)
+REG10Q(4, 8)
+REG10Q(16, 8)
+#define REG4Q(RP, NWV)                                   \
+    C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 0, NWV, Scar4D)  \
+    C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 1, NWV, Scar4D)  \
+    C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 2, NWV, Scar4D)  \
+    C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 3, NWV, Scar4D)
+REG4Q(8, 8)
+REG4Q(20, 8)
+#define REG6Q(RP, NWV)                                     \
+    C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 0, NWV, LqgNd<6>)   \
+    C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 1, NWV, LqgNd<6>)   \
+    C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 2, NWV, LqgNd<6>)   \
+    C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 3, NWV, LqgNd<6>)   \
+    C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 4, NWV, LqgNd<6>)   \
+    C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 5, NWV, LqgNd<6>)
+REG6Q(8, 8)
+} // namespace c3sc

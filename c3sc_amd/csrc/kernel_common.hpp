@@ -45,6 +45,10 @@ struct KArgs {
     double *uopt;              // [F][N][du] minimiser per node (may be null)
     const double *forced_u;    // policy evaluation with continuous controls: [F][N][du] control to apply, or null
     int tbl_off;               // fiber-pair kernel: offset (doubles) of the candidate / node tables in dynamic LDS
+    // fiber-quad kernel (kernel_fiber_quad.hpp): extra copies of the cores made by k_quad_aux, offsets into `ro`
+    long quad_coreT_off[MAXD]; // middle cores row-major (a*RP + b): the staged matrix of the suffix-side levels
+    long quad_aop_off[MAXD];   // middle cores as MFMA A operands: [N][c | a][MB][C][64]
+    int quad_sv_off;           // offset (doubles) of the per-wave node-value rows in dynamic LDS
 };
 
 // Output pointers of one launch (separate __restrict__ kernel parameters).

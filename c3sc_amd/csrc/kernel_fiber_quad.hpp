@@ -1,0 +1,390 @@
+// kernel_fiber_quad.hpp -- "sixteen fibers per wavefront, rank split over four lane groups" Bellman kernel (gfx950).
+//
+// Same fold-once algebra as kernel_fiber_pair.hpp (everything constant along a fiber is folded into L, R and the
+// 2(d-1) neighbour vectors; per node only c = G_k[j] R, a = L G_k[j] and 2d-1 short dots remain), laid out for the
+// matrix cores:
+//
+//   * lane l = (q, t) = (l / 16, l % 16): t is one of the wavefront's 16 fibers, q one of four rank quarters.  Lane
+//     (q, t) keeps components [qC, (q+1)C), C = RP/4, of every folded vector of fiber t -- the per-fiber state
+//     (2(d-1)+2 vectors of RP doubles) is spread over four lanes, so it fits the register file at any compiled rank
+//     without a second wavefront, LDS exchange rows or barriers in the node loop.
+//   * c = G_k[j] R and a = L G_k[j] share their matrix between all fibers: they run on the matrix cores as
+//     v_mfma_f64_16x16x4_f64 with M = components (permuted so that the result lands in the owner lane), N = the 16
+//     fibers, K = RP in C steps.  The A operand is a pre-permuted copy of the core (k_quad_aux) read with one coalesced
+//     512-byte load per step; the B operand is the lane's own component of R / L; the four D registers of lane (q, t)
+//     are exactly its components of c / a.
+//   * the 2d-1 dots of a node are C FMAs per lane plus a sum over q.  Four nodes are processed together and the sum
+//     over q is a transposing reduction in registers (v_permlane32_swap, v_permlane16_swap + 3 adds per four sums):
+//     afterwards lane (q, t) holds the complete stencil of node j0+q of fiber t, and the control minimisation
+//     (node_backup) runs with one (fiber, node) per lane -- all 64 lanes busy for any N.
+//   * folding is level-synchronous over the workgroup: for each fixed dimension the WHOLE core is staged once in LDS
+//     (coalesced; 51 KB at N = 25, rank 16) and every lane reads its fiber's matrix rows from there, so the cores cross
+//     L2 -> CU once per tile of 16 x (waves per workgroup) fibers instead of three gathered matrices per fiber and
+//     dimension.  A matrix-vector product is 4 C^2 FMAs per lane and a transposing reduction per output component; up to
+//     four vectors share one pass over the matrix.  The level loop is a run-time loop (vector slots shift by one pair
+//     per level), so the code size does not grow with d^2.
+//
+// Citations: valuef_eval_fiber_ind_nn src/valuefunc.c:369-585, process_fibers_neighbor src/nodeutil.c:489-627,
+// bellman_optimal / bellman_control src/bellman.c:504-543, 367-480 (see kernel_common.hpp).
+#pragma once
+#include "kernel_common.hpp"
+
+namespace c3sc {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int quad_c(int rp) { return rp / 4; }            // components per lane
+__host__ __device__ constexpr int quad_mb(int rp) { return (rp / 4 + 3) / 4; } // 16-row blocks of the MFMA M dimension
+// doubles of one node's pre-permuted A operands: [product c / a][MB][C steps][64 lanes]
+__host__ __device__ constexpr int quad_aop_node(int rp) { return 2 * quad_mb(rp) * quad_c(rp) * 64; }
+
+// x (lanes 32-63) <-> y (lanes 0-31), both dwords of a double
+__device__ __forceinline__ void swap32_f64(double &x, double &y)
+{
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(x), by = (unsigned long long)__double_as_longlong(y);
+    const v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)bx, (unsigned)by, false, false);
+    const v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)(bx >> 32), (unsigned)(by >> 32), false, false);
+    x = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+    y = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+// odd 16-lane rows of x <-> even rows of y
+__device__ __forceinline__ void swap16_f64(double &x, double &y)
+{
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(x), by = (unsigned long long)__double_as_longlong(y);
+    const v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)bx, (unsigned)by, false, false);
+    const v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)(bx >> 32), (unsigned)(by >> 32), false, false);
+    x = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+    y = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+
+// Transposing sum over the four lane groups: every lane passes its partial values of four items; lane (q, t) gets
+// sum over q' of item q of lane (q', t).  Fixed association ((q, q^2) pairs first), identical on every run.
+__device__ __forceinline__ double reduce4(double p0, double p1, double p2, double p3)
+{
+    swap32_f64(p0, p2); // lanes 0-31: p0 own, p2 = partner's p0;  lanes 32-63: p0 = partner's p2, p2 own
+    swap32_f64(p1, p3);
+    double s0 = p0 + p2, s1 = p1 + p3; // lanes 0-31: items 0, 1;  lanes 32-63: items 2, 3
+    swap16_f64(s0, s1);
+    return s0 + s1;
+}
+
+// v <- M v for the vectors X[B0 .. B0+NVB): M is this lane's fiber's matrix in LDS, row-major [x][y] with row stride RP
+// (x = output component, y = input component; the left side stages the transposed core, so both sides are this product).
+// Lane (q, t) holds y in [qC, (q+1)C) of every vector and ends with x in the same range.
+template <int RP, int NX, int B0, int NVB>
+__device__ __forceinline__ void apply_quad(const double *Mn, double (&X)[NX][RP / 4], int q)
+{
+    constexpr int C = RP / 4;
+    double o[NVB][C];
+#pragma unroll
+    for (int g = 0; g < C; g++) {
+        double P[NVB][4];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const double *row = Mn + (qq * C + g) * RP + q * C;
+            double mrow[C];
+#pragma unroll
+            for (int i = 0; i < C; i++) mrow[i] = row[i];
+#pragma unroll
+            for (int s = 0; s < NVB; s++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < C; i++) acc = fma(mrow[i], X[B0 + s][i], acc);
+                P[s][qq] = acc;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NVB; s++) o[s][g] = reduce4(P[s][0], P[s][1], P[s][2], P[s][3]);
+    }
+#pragma unroll
+    for (int s = 0; s < NVB; s++)
+#pragma unroll
+        for (int g = 0; g < C; g++) X[B0 + s][g] = o[s][g];
+}
+
+// one vector, result returned separately (the two neighbour matrices of a level are applied to the running prefix/suffix)
+template <int RP>
+__device__ __forceinline__ void apply_quad1(const double *Mn, const double (&v)[RP / 4], double (&out)[RP / 4], int q)
+{
+    double X[1][RP / 4];
+#pragma unroll
+    for (int i = 0; i < RP / 4; i++) X[0][i] = v[i];
+    apply_quad<RP, 1, 0, 1>(Mn, X, q);
+#pragma unroll
+    for (int i = 0; i < RP / 4; i++) out[i] = X[0][i];
+}
+
+// all live vectors of one side through the matrix of this level, up to four per pass; blocks past the live count are skipped
+template <int RP, int NX, int B0>
+__device__ __forceinline__ void apply_live(const double *Mn, double (&X)[NX][RP / 4], int nlive, int q)
+{
+    if constexpr (B0 < NX) {
+        constexpr int NVB = (NX - B0) < 4 ? (NX - B0) : 4;
+        if (B0 < nlive) apply_quad<RP, NX, B0, NVB>(Mn, X, q); // wave-uniform
+        apply_live<RP, NX, B0 + NVB>(Mn, X, nlive, q);
+    }
+}
+
+// coalesced copy of `count` doubles (even) from global memory into LDS by the whole workgroup
+__device__ inline void stage_linear(double *dst, const double *__restrict__ src, int count)
+{
+    const int pairs = count >> 1;
+    for (int p = threadIdx.x; p < pairs; p += blockDim.x)
+        reinterpret_cast<double2 *>(dst)[p] = reinterpret_cast<const double2 *>(src)[p];
+}
+
+// c or a of one node on the matrix cores: out[g] = sum_y M[qC+g][y] v[y] with M = G_k[j] (c) or its transpose (a)
+template <int RP>
+__device__ __forceinline__ void mfma_prod(const double *__restrict__ aop /* [MB][C][64] */, const double (&v)[RP / 4],
+                                          double (&out)[RP / 4], int lane)
+{
+    constexpr int C = RP / 4, MB = quad_mb(RP);
+    v4d acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) acc[mb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < C; s++)
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[(mb * C + s) * 64 + lane], v[s], acc[mb], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < C; g++) out[g] = acc[g / 4][g % 4];
+}
+
+template <int C>
+__device__ __forceinline__ double dot_c(const double (&a)[C], const double (&b)[C])
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; i++) s = fma(a[i], b[i], s);
+    return s;
+}
+
+// NWV wavefronts per workgroup share the staged cores; registers per lane <= 512 / (NWV / 4)
+template <class Model, int RP, int K, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 1)
+    k_fiber_quad(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
+                 int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
+{
+    constexpr int D = Model::D, S = 2 * D + 1, C = RP / 4;
+    constexpr int NL = 2 * K, NR = 2 * (D - 1 - K);
+    static_assert(RP % 4 == 0 && RP >= 4 && RP <= 32, "padded rank must be a multiple of 4");
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63, q = lane >> 4, t = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = A.N;
+    double *sM = smem;                                // staged core of the current level
+    double *sV = smem + A.quad_sv_off + wv * (N * 16); // this wave's node values [N][16]
+    CandLds<Model> cr;
+    {
+        CandRegs<Model> cr0;
+        cr0.load(A, ro);
+        cr.fill(smem + A.tbl_off, cr0, A.ncand); // every wave writes the same rows
+        __syncthreads();
+    }
+    unsigned st = 0;
+    const long per_tile = 16L * NWV, ntiles = (A.F + per_tile - 1) / per_tile;
+    const int bck = A.bctype[K];
+    const double *aopK = ro + A.quad_aop_off[K];
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long f_raw = tile * per_tile + wv * 16 + t;
+        const bool flive = f_raw < A.F;
+        const long f = flive ? f_raw : A.F - 1;
+        // ---- fiber description (process_fibers_neighbor, fixed dims): identical in the four lanes of a fiber
+        int fi[D];
+        double x[D];
+        bool fiber_abs = false;
+#pragma unroll
+        for (int m = 0; m < D; m++) {
+            fi[m] = (m == K) ? 0 : idx[f * D + m];
+            int lo, hi;
+            const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], lo, hi);
+            if (m != K) fiber_abs = fiber_abs || face;
+            x[m] = ro[A.xg_off[m] + fi[m]];
+        }
+        double tvf[Model::NTAB > 0 ? Model::NTAB : 1]; // tables not indexed by dim K are constants of the fiber
+        table_values<Model>(A, ro, fi, tvf);
+
+        double XL[1 + NL][C], XR[1 + NR][C]; // [0] = L / R, [1 + 2i + s] = (-,+) neighbour vector of dim K-1-i / K+1+i
+#pragma unroll
+        for (int s = 0; s < 1 + NL; s++)
+#pragma unroll
+            for (int i = 0; i < C; i++) XL[s][i] = 0.0;
+#pragma unroll
+        for (int s = 0; s < 1 + NR; s++)
+#pragma unroll
+            for (int i = 0; i < C; i++) XR[s][i] = 0.0;
+
+        // ---- fold the suffix side: levels m = D-1 .. K+1
+        if constexpr (K < D - 1) {
+            int nlive = 1; // vectors in XR that exist so far (R counts)
+#pragma nounroll
+            for (int m = D - 1; m > K; m--) {
+                const bool edge = (m == D - 1);
+                const int elems = edge ? RP : RP * RP;
+                __syncthreads();
+                stage_linear(sM, ro + (edge ? A.core_off[m] : A.quad_coreT_off[m]), A.ngrid[m] * elems);
+                __syncthreads();
+                const int nd = idx[f * D + m];
+                int lo, hi;
+                (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
+                double T0[C], T1[C];
+                if (edge) { // r x 1 column core
+#pragma unroll
+                    for (int i = 0; i < C; i++) {
+                        XR[0][i] = sM[nd * RP + q * C + i];
+                        T0[i] = sM[lo * RP + q * C + i];
+                        T1[i] = sM[hi * RP + q * C + i];
+                    }
+                } else {
+                    apply_quad1<RP>(sM + lo * elems, XR[0], T0, q);
+                    apply_quad1<RP>(sM + hi * elems, XR[0], T1, q);
+                    apply_live<RP, 1 + NR, 0>(sM + nd * elems, XR, nlive, q);
+                }
+#pragma unroll
+                for (int s = NR; s >= 3; s--)
+#pragma unroll
+                    for (int i = 0; i < C; i++) XR[s][i] = XR[s - 2][i];
+#pragma unroll
+                for (int i = 0; i < C; i++) { XR[1][i] = T0[i]; XR[2][i] = T1[i]; }
+                nlive += 2;
+            }
+        }
+        // ---- fold the prefix side: levels m = 0 .. K-1 (the staged matrix is the transposed core = the arena layout)
+        if constexpr (K > 0) {
+            int nlive = 1;
+#pragma nounroll
+            for (int m = 0; m < K; m++) {
+                const bool edge = (m == 0);
+                const int elems = edge ? RP : RP * RP;
+                __syncthreads();
+                stage_linear(sM, ro + A.core_off[m], A.ngrid[m] * elems);
+                __syncthreads();
+                const int nd = idx[f * D + m];
+                int lo, hi;
+                (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
+                double T0[C], T1[C];
+                if (edge) { // 1 x r row core
+#pragma unroll
+                    for (int i = 0; i < C; i++) {
+                        XL[0][i] = sM[nd * RP + q * C + i];
+                        T0[i] = sM[lo * RP + q * C + i];
+                        T1[i] = sM[hi * RP + q * C + i];
+                    }
+                } else {
+                    apply_quad1<RP>(sM + lo * elems, XL[0], T0, q);
+                    apply_quad1<RP>(sM + hi * elems, XL[0], T1, q);
+                    apply_live<RP, 1 + NL, 0>(sM + nd * elems, XL, nlive, q);
+                }
+#pragma unroll
+                for (int s = NL; s >= 3; s--)
+#pragma unroll
+                    for (int i = 0; i < C; i++) XL[s][i] = XL[s - 2][i];
+#pragma unroll
+                for (int i = 0; i < C; i++) { XL[1][i] = T0[i]; XL[2][i] = T1[i]; }
+                nlive += 2;
+            }
+        }
+
+        // ---- c / a of node jn for this lane's fiber (own components)
+        auto node_c = [&](int jn, double (&c)[C]) __attribute__((always_inline)) {
+            if constexpr (K == D - 1) {
+#pragma unroll
+                for (int i = 0; i < C; i++) c[i] = ro[A.core_off[K] + (size_t)jn * RP + q * C + i];
+            } else if constexpr (K > 0) {
+                mfma_prod<RP>(aopK + (size_t)jn * quad_aop_node(RP), XR[0], c, lane);
+            }
+        };
+        auto node_a = [&](int jn, double (&a)[C]) __attribute__((always_inline)) {
+            if constexpr (K == 0) {
+#pragma unroll
+                for (int i = 0; i < C; i++) a[i] = ro[A.core_off[K] + (size_t)jn * RP + q * C + i];
+            } else if constexpr (K < D - 1) {
+                mfma_prod<RP>(aopK + (size_t)jn * quad_aop_node(RP) + quad_aop_node(RP) / 2, XL[0], a, lane);
+            }
+        };
+
+        // ---- pass 1: node values v_j = L G_k[j] R for the neighbours along the varying dimension
+        wave_sync(); // the previous tile's readers of sV are done
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            double P[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int jn = min(j0 + jj, N - 1);
+                if constexpr (K == 0) {
+                    double a[C];
+                    node_a(jn, a);
+                    P[jj] = dot_c<C>(a, XR[0]);
+                } else {
+                    double c[C];
+                    node_c(jn, c);
+                    P[jj] = dot_c<C>(XL[0], c);
+                }
+            }
+            const double v = reduce4(P[0], P[1], P[2], P[3]);
+            if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+        }
+        wave_sync();
+
+        // ---- pass 2: stencils, boundary flags, control minimisation; lane (q, t) finalises node j0 + q of fiber t
+        const bool forced = A.forced != nullptr; // wave-uniform
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            double V[S];
+            if constexpr (K > 0) {
+                double c[4][C];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) node_c(min(j0 + jj, N - 1), c[jj]);
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int m = K - 1 - i;
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+                        V[2 * m + s] = reduce4(dot_c<C>(XL[1 + 2 * i + s], c[0]), dot_c<C>(XL[1 + 2 * i + s], c[1]),
+                                               dot_c<C>(XL[1 + 2 * i + s], c[2]), dot_c<C>(XL[1 + 2 * i + s], c[3]));
+                }
+            }
+            if constexpr (K < D - 1) {
+                double a[4][C];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) node_a(min(j0 + jj, N - 1), a[jj]);
+#pragma unroll
+                for (int i = 0; i < D - 1 - K; i++) {
+                    const int m = K + 1 + i;
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+                        V[2 * m + s] = reduce4(dot_c<C>(a[0], XR[1 + 2 * i + s]), dot_c<C>(a[1], XR[1 + 2 * i + s]),
+                                               dot_c<C>(a[2], XR[1 + 2 * i + s]), dot_c<C>(a[3], XR[1 + 2 * i + s]));
+                }
+            }
+            const bool nlive = (j0 + q < N);
+            const int j = nlive ? j0 + q : N - 1;
+            // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
+            x[K] = ro[A.xg_off[K] + j];
+            int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
+            if (fiber_abs) ab = 1;
+            int lo, hi;
+            ab = vary_neighbors(j, N, bck, ab, lo, hi);
+            V[2 * K] = sV[lo * 16 + t];
+            V[2 * K + 1] = sV[hi * 16 + t];
+            V[2 * D] = sV[j * 16 + t];
+            double tv[Model::NTAB > 0 ? Model::NTAB : 1];
+            tv[0] = 0.0;
+#pragma unroll
+            for (int tt = 0; tt < Model::NTAB; tt++) tv[tt] = (Model::tab_dim(tt) == K) ? ro[A.tab_off[tt] + j] : tvf[tt];
+            int ui;
+            const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
+            const double val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+            if (nlive && flive) {
+                outv[(size_t)f * N + j] = val;
+                if (uidx) uidx[(size_t)f * N + j] = ui;
+                if (absorbed) absorbed[(size_t)f * N + j] = ab;
+            }
+        }
+    }
+    if (st) atomicOr(A.status, st);
+}
+
+} // namespace c3sc

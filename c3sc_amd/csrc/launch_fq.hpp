@@ -1,0 +1,73 @@
+// launch_fq.hpp -- host launcher + registration macro for the fiber-quad kernels (kernel_fiber_quad.hpp).
+#pragma once
+#include "kernel_fiber_quad.hpp"
+#include "registry.hpp"
+
+namespace c3sc {
+
+template <class Model, int RP, int K, int NWV>
+hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
+{
+    constexpr int D = Model::D;
+    if (A.cmode == 1) return hipErrorNotSupported; // candidate lists only
+    if (K > 0 && K < D - 1 && A.quad_aop_off[K] == 0) return hipErrorNotSupported;
+    // LDS: the largest staged fixed core, then the per-wave node values, then the candidate table
+    size_t doubles = 0;
+    for (int m = 0; m < D; m++) {
+        if (m == K) continue;
+        const size_t need = (size_t)A.ngrid[m] * ((m == 0 || m == D - 1) ? RP : RP * RP);
+        if (need > doubles) doubles = need;
+    }
+    doubles = (doubles + 1) & ~(size_t)1;
+    KArgs B = A;
+    B.quad_sv_off = (int)doubles;
+    doubles += (size_t)NWV * A.N * 16;
+    B.tbl_off = (int)doubles;
+    doubles += (size_t)CandLds<Model>::doubles(A.ncand);
+    const size_t shmem = doubles * sizeof(double);
+    if (shmem > 160u * 1024u) return hipErrorOutOfMemory;
+    auto kern = k_fiber_quad<Model, RP, K, NWV>;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    // per device: the dynamic-LDS opt-in and the occupancy belong to the device the context runs on
+    constexpr int MAXDEV = 16;
+    static size_t attr_shmem[MAXDEV] = {0}, occ_shmem[MAXDEV] = {0};
+    static int blocks_per_cu[MAXDEV] = {0}, num_cu[MAXDEV] = {0};
+    if (dev < 0 || dev >= MAXDEV) return hipErrorInvalidDevice;
+    if (shmem > attr_shmem[dev]) {
+        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_shmem[dev] = shmem;
+    }
+    if (shmem != occ_shmem[dev] || blocks_per_cu[dev] == 0) {
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NWV, shmem);
+        if (e != hipSuccess) return e;
+        blocks_per_cu[dev] = nb > 0 ? nb : 1;
+        occ_shmem[dev] = shmem;
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) return e;
+        num_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long per_tile = 16L * NWV, ntiles = (A.F + per_tile - 1) / per_tile;
+    const long cap = (long)num_cu[dev] * blocks_per_cu[dev];
+    int grid = (int)(ntiles < cap ? ntiles : cap);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), shmem, io.stream, B, io.ro, io.idx, io.out, io.uidx, io.absorbed);
+    return hipGetLastError();
+}
+
+template <class Model, int RP, int K, int NWV>
+hipError_t launch_fq(const KArgs &A, const LaunchIO &io)
+{
+    return launch_fq_impl<Model, RP, K, NWV>(A, io);
+}
+
+#define C3SC_REG_FQ1(MODEL_ID, RP, K, NWV, ...)                                                                  \
+    static Registrar C3SC_CAT(reg_fq_, __COUNTER__)(KernelEntry{                                                 \
+        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_QUAD, 128, K, &launch_fq<__VA_ARGS__, RP, K, NWV>,  \
+        "k_fiber_quad<" #__VA_ARGS__ "," #RP ",K=" #K ">"});
+
+} // namespace c3sc

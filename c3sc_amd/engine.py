@@ -34,7 +34,7 @@ EXPORTS = [
     "c3sc_hip_debug_read", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]
 
-VARIANT_AUTO, VARIANT_FIBER_PER_WAVE, VARIANT_FIBER_PER_LANE, VARIANT_FIBER_PAIR = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_FIBER_PER_WAVE, VARIANT_FIBER_PER_LANE, VARIANT_FIBER_PAIR, VARIANT_FIBER_QUAD = 0, 1, 2, 3, 4
 
 
 class C3scHipError(RuntimeError):

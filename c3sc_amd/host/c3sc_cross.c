@@ -123,6 +123,7 @@ static void right_solve(size_t m, size_t r, const double *Q, const size_t *rows,
     free(T);
 }
 
+#define TIE_EPS 1e-9
 /* maxvol: r rows of the m x r matrix Q (full column rank) whose submatrix has (locally) maximal volume;
  * B = Q inv(Q[rows]) has entries bounded by 1 + delta on exit. */
 static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
@@ -134,8 +135,11 @@ static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
     for (size_t k = 0; k < r; k++) {
         size_t p = m;
         double best = -1.0;
+        /* ties (mirror-image nodes of a symmetric value function have equal entries up to rounding) go to the lower
+         * index: a later row must exceed the best so far by more than rounding noise to replace it, so that fiber
+         * values that differ in the last bits (device vs host arithmetic) select the same rows */
         for (size_t i = 0; i < m; i++)
-            if (!used[i] && fabs(W[i + k * m]) > best) { best = fabs(W[i + k * m]); p = i; }
+            if (!used[i] && (p == m || fabs(W[i + k * m]) > best * (1.0 + TIE_EPS))) { best = fabs(W[i + k * m]); p = i; }
         rows[k] = p;
         used[p] = 1;
         const double d = W[p + k * m];
@@ -157,7 +161,7 @@ static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
         double best = 0.0;
         for (size_t j = 0; j < r; j++)
             for (size_t i = 0; i < m; i++)
-                if (fabs(B[i + j * m]) > best) { best = fabs(B[i + j * m]); bi = i; bj = j; }
+                if (fabs(B[i + j * m]) > best * (1.0 + TIE_EPS)) { best = fabs(B[i + j * m]); bi = i; bj = j; }
         if (best <= 1.0 + 1e-2) break;
         /* swap row rows[bj] for row bi: B <- B - B[:,bj] (B[bi,:] - e_bj) / B[bi,bj] */
         const double piv = B[bi + bj * m];

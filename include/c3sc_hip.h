@@ -65,7 +65,8 @@ enum {
 };
 
 /* kernel variants (c3sc_hip_set_variant); 0 lets the library choose */
-enum { C3SC_VARIANT_AUTO = 0, C3SC_VARIANT_FIBER_PER_WAVE = 1, C3SC_VARIANT_FIBER_PER_LANE = 2, C3SC_VARIANT_FIBER_PAIR = 3 };
+enum { C3SC_VARIANT_AUTO = 0, C3SC_VARIANT_FIBER_PER_WAVE = 1, C3SC_VARIANT_FIBER_PER_LANE = 2, C3SC_VARIANT_FIBER_PAIR = 3,
+       C3SC_VARIANT_FIBER_QUAD = 4 };
 
 typedef struct c3sc_hip_ctx c3sc_hip_ctx;
 

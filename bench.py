@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- Bellman-sweep throughput of the HIP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload car7d] [--fibers F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload car7d] [--fibers F] [--scaling strong|weak]
 
-One "step" = one Bellman sweep over a batch of synthetic fibers: for every varying dimension
-k = 0..d-1, F fibers (x N_k nodes) go through the batched bellman_vi kernel
-(c3sc_hip_bellman_fibers), then the sweep ends the way a value-iteration sweep does: the updated FT
-cores are exchanged (RCCL all-gather over xGMI when N > 1) and re-staged on the device
-(valuef_precompute_cores equivalent, c3sc_hip_upload_value_device).  Inputs (cores, grids, fiber
-indices) are resident in HBM before the timed region.  Fibers are independent units: each rank owns
-its own F fibers per dimension (weak scaling), no collective in the data path.
+One "step" = one Bellman sweep over a batch of synthetic fibers: for every varying dimension k = 0..d-1, F fibers
+(x N_k nodes) go through the batched bellman_vi kernel (c3sc_hip_bellman_fibers); the sweep ends the way a value-iteration
+sweep does: every rank updates the slice of the FT cores it owns from its own outputs, the slices are all-gathered (RCCL
+over xGMI when N > 1) and the cores re-staged on the device (valuef_precompute_cores equivalent,
+c3sc_hip_upload_value_device).  Inputs (cores, grids, fiber indices) are resident in HBM before the timed region.
+Fibers are independent units: the batch is sharded over the ranks in contiguous blocks (c3sc_amd.distributed.shard_range)
+with no collective in the data path.  --scaling strong (default): the batch of F fibers per dimension is fixed and split
+over the N GPUs (north_star's strong-scaling target); --scaling weak: every rank draws its own F fibers.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and
-`cpu_baseline` objects.  The workload is BASELINE.json's headline config ("7D car rank-10":
-SURVEY.md 8d C4 = synthetic 7-D car, 41^7 grid, FT rank 10, 9 brute-force controls).
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) the script starts its N ranks itself, as fresh child
+processes, before anything in the parent touches the GPU.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline`, `cpu_baseline` and -- measured after
+the timed region through libc3sc.so on rank 0 at N = 1 -- `vi_sweep` (a whole value-iteration sweep of the solver: ms,
+node backups, kernel launches) and `vi_iters_to_tol` (the examples' outer loop under a wall-time budget).  The workload is
+BASELINE.json's headline config ("7D car rank-10": SURVEY.md 8d C4 = synthetic 7-D car, 41^7 grid, FT rank 10, 9
+brute-force controls).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +37,10 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 vector = FP64 matrix; the microarch guide lists no f64 row
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
+REFERENCE_CPU = {"value": 3.26e5, "unit": "nodes/s", "cores": 1,
+                 "what": "the reference's own bellman_vi (src/*.c, gcc -O2 -ftree-vectorize, 1 thread; 5.76e4 with 8 OpenMP threads), "
+                         "car7d batch, measured by the survey on the build container's Xeon @2.1 GHz (SURVEY.md section 6); "
+                         "context only -- the reference cannot travel to the GPU box"}
 
 
 def _cpu_worker(workload, budget_s, wid):
@@ -52,8 +65,6 @@ def cpu_baseline(w, cores, budget_s=12.0, nproc=None):
     same workload: `nproc` single-threaded worker processes, each on its own fibers for `budget_s` seconds (fibers are
     independent, so this is the fiber-parallel CPU path of SURVEY.md 8d).  The oracle is only the checker / baseline
     here -- never the thing measured as the product."""
-    import subprocess
-
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
@@ -71,7 +82,140 @@ def cpu_baseline(w, cores, budget_s=12.0, nproc=None):
     return {"value": nodes / wall, "unit": "nodes/s", "cores": nproc, "kind": "port", "per_core": per_core,
             "sample": f"{nodes} node backups ({sum(o['chunks'] for o in outs)} chunks of 256 random fibers, dims round-robin) in "
                       f"{wall:.1f} s on {nproc} single-threaded worker processes, oracle/c3sc_oracle.c -O2, "
-                      f"{os.cpu_count()} host cores visible"}
+                      f"{os.cpu_count()} host cores visible",
+            "reference_context": REFERENCE_CPU}
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: N fresh child processes (one per GPU), started before this process imports torch or
+    touches HIP; rank 0's JSON line goes straight to our stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def solver_measurements(workload, budget_s):
+    """After the timed region, rank 0, one GPU: the solver as a user runs it, through libc3sc.so (reference API names).
+    vi_sweep: c3control_step_vi on the bench workload at its rank (own cross driver + batched kernels);
+    vi_iters_to_tol: the examples' outer loop (pi_solve(10) + one vi_solve step, e.g. dubinscar.c:343-352) until
+    |V_vi - V_pi|_L2 < tol or the wall-time budget ends -- reported as measured, converged or not."""
+    import ctypes as C
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import facade_lib
+    from c3sc_amd import workloads as wl
+    from c3sc_amd.engine import load_library
+
+    H = load_library()
+    L = facade_lib.lib()
+    for n in ("c3control_init_value", "c3control_step_vi", "c3control_vi_solve", "c3control_pi_solve"):
+        getattr(L, n).restype = C.c_void_p
+    for n in ("valuef_norm", "valuef_norm2diff"):
+        getattr(L, n).restype = C.c_double
+    L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+    L.diag_count.restype = C.c_size_t
+    w = wl.WORKLOADS[workload]()
+    d = w.dx
+    ctl = facade_lib.Control(w)
+    rmax = max(w.ranks)
+
+    def aargs(cross, rnd, kick, start, maxrank):
+        aa = C.c_void_p(L.approx_args_init())
+        L.approx_args_set_cross_tol(aa, C.c_double(cross))
+        L.approx_args_set_round_tol(aa, C.c_double(rnd))
+        L.approx_args_set_kickrank(aa, C.c_size_t(kick))
+        L.approx_args_set_startrank(aa, C.c_size_t(start))
+        L.approx_args_set_maxrank(aa, C.c_size_t(maxrank))
+        return aa
+
+    def smooth(n, x, out, a):
+        X = np.ctypeslib.as_array(x, shape=(n, d))
+        np.ctypeslib.as_array(out, shape=(n,))[:] = 1.0 + 0.1 * (X ** 2).sum(axis=1)
+        return 0
+
+    cb = facade_lib.FIBER_FN(smooth)
+    aa = aargs(1e-6, 1e-5, 2, 4, rmax)
+    vf = C.c_void_p(L.c3control_init_value(ctl.h, cb, None, aa, 0))
+    ne = C.c_size_t(0)
+    rows = []
+    for it in range(6):
+        l0, t0 = H.c3sc_hip_launch_count(), time.perf_counter()
+        nxt = C.c_void_p(L.c3control_step_vi(ctl.h, vf, aa, ctl.opt, 0, C.byref(ne)))
+        rows.append((time.perf_counter() - t0, ne.value, H.c3sc_hip_launch_count() - l0))
+        L.valuef_destroy(vf)
+        vf = nxt
+    rows = rows[2:]  # the first sweeps grow the ranks to the cap
+    ms = 1e3 * float(np.mean([r[0] for r in rows]))
+    nb = float(np.mean([r[1] for r in rows]))
+    vi_sweep = {"ms_per_sweep": ms, "node_backups_per_sweep": nb, "nodes_per_s_through_the_driver": nb / (ms * 1e-3),
+                "kernel_launches_per_sweep": float(np.mean([r[2] for r in rows])),
+                "ranks": [int(L.valuef_get_ranks(vf)[i]) for i in range(d + 1)],
+                "what": f"c3control_step_vi through libc3sc.so on {w.name} (own TT-cross driver, rank cap {rmax}), mean of {len(rows)} sweeps"}
+    L.valuef_destroy(vf)
+    L.approx_args_free(aa)
+
+    aa = aargs(1e-5, 1e-5, 5, 5, rmax)
+    zero = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.0), 0)[1])
+    cost = C.c_void_p(L.c3control_init_value(ctl.h, zero, None, aa, 0))
+    diag = C.c_void_p(None)
+    tol, t0, diff, outer, conv = 1e-3, time.perf_counter(), float("nan"), 0, False
+    while time.perf_counter() - t0 < budget_s:
+        nxt = C.c_void_p(L.c3control_pi_solve(ctl.h, C.c_size_t(10), C.c_double(1e-2), cost, aa, ctl.opt, 0, C.byref(diag)))
+        L.valuef_destroy(cost)
+        cost = C.c_void_p(L.c3control_vi_solve(ctl.h, C.c_size_t(1), C.c_double(tol), nxt, aa, ctl.opt, 0, C.byref(diag)))
+        diff = L.valuef_norm2diff(nxt, cost)
+        L.valuef_destroy(nxt)
+        outer += 1
+        if diff < tol:
+            conv = True
+            break
+    norm = L.valuef_norm(cost)
+    iters = {"converged": conv, "tol_abs_L2": tol, "outer_iterations": outer, "bellman_sweeps": int(L.diag_count(diag)),
+             "seconds": time.perf_counter() - t0, "last_diff_L2": diff, "norm_L2": norm, "last_diff_rel": diff / norm if norm else None,
+             "rank_cap": rmax, "wall_budget_s": budget_s,
+             "what": "pi_solve(10, 1e-2) + vi_solve(1) per outer iteration through libc3sc.so, start value 0, until |V_vi - V_pi|_L2 < tol"}
+    L.diag_destroy(C.byref(diag))
+    L.valuef_destroy(cost)
+    L.approx_args_free(aa)
+    ctl.close()
+    return vi_sweep, iters
+
+
+def pmc_summary(kernel, F):
+    """HBM traffic and executed FP64 work of the dominant kernel per launch: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE,
+    SQ_INSTS_VALU_*_F64 in separate runs; FETCH x2 per the gfx950 correction of MI355X_MICROARCH.md) cannot be collected
+    from inside this process, so the newest committed summary of the same command is read (profiles/README.md)."""
+    tag = "fiber_quad" if "fiber_quad" in kernel else ("fiber_pair" if "fiber_pair" in kernel else None)
+    if tag is None:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), reverse=True):
+        try:
+            pm = json.load(open(path))
+            if int(pm.get("fibers_per_dim", 0)) != F:
+                continue
+            ks = [v for kname, v in pm["kernels"].items() if tag in kname]
+            if not ks:
+                continue
+            out = {"traffic": float(np.mean([v["fetch_bytes_x2_gfx950_correction"] + v["write_bytes_per_launch"] for v in ks])),
+                   "source": "profiles/" + os.path.basename(path)}
+            ex = [v["executed_flops_per_node"] for v in ks if "executed_flops_per_node" in v]
+            if ex:
+                out["executed_flops_per_node"] = float(np.mean(ex))
+            return out
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def main():
@@ -84,19 +228,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="car7d")
     ap.add_argument("--fibers", type=int, default=None,
-                    help="fibers per varying dimension per GPU per step (default: 2^20 for car7d, the roofline batch of "
-                         "SURVEY.md 8d; 2^17 for the other workloads)")
+                    help="fibers per varying dimension per step: the whole job's with --scaling strong, each GPU's with weak "
+                         "(default: 2^20 for car7d, the roofline batch of SURVEY.md 8d; 2^17 for the other workloads)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solver", action="store_true", help="skip the vi_sweep / vi_iters_to_tol measurements after the timed region")
+    ap.add_argument("--solver-budget", type=float, default=20.0)
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=None, help="worker processes of the CPU baseline (default min(16, cores))")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
 
     from c3sc_amd import workloads as wl
-    from c3sc_amd.distributed import allgather_cores, pack_cores, padded_len
+    from c3sc_amd.distributed import allgather_cores, pack_cores, padded_len, shard_range
     from c3sc_amd.engine import BellmanEngine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,32 +265,43 @@ def main():
     dev = torch.device("cuda", local_rank)
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)  # RCCL
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     w = wl.WORKLOADS[args.workload]()
     cores = wl.synth_cores(w)
     eng = BellmanEngine(local_rank)
-    eng.configure(w, cores)
     if args.variant:
-        eng.set_variant(args.variant)
+        eng.set_variant(args.variant)  # before the value is uploaded: the padded rank follows the variant
+    eng.configure(w, cores)
 
     F = args.fibers if args.fibers is not None else ((1 << 20) if args.workload == "car7d" else (1 << 17))
     d = w.dx
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
-    # fiber batches resident in HBM; every rank owns different fibers (seed offset by rank)
-    idx_t = [torch.from_numpy(wl.synth_fibers(w, k, F, seed=0xF1BE + 7919 * rank)).to(dev) for k in range(d)]
-    out_t = [torch.empty((F, w.ngrid[k]), dtype=torch.float64, device=dev) for k in range(d)]
-    # FT cores on the device in the reference layout (what a cross-approximation step produces);
-    # each rank "owns" a 1/world slice of the flattened cores and all-gathers the rest per sweep
+    # fiber batches resident in HBM.  strong: one batch of F fibers per dimension for the whole job, rank r owns the
+    # contiguous block shard_range(F, world, r); weak: every rank draws its own F fibers (seed offset by rank)
+    if args.scaling == "strong":
+        lo, hi = shard_range(F, world, rank)
+        idx_t = [torch.from_numpy(np.ascontiguousarray(wl.synth_fibers(w, k, F, seed=0xF1BE)[lo:hi])).to(dev) for k in range(d)]
+        F_job = F
+    else:
+        lo, hi = 0, F
+        idx_t = [torch.from_numpy(wl.synth_fibers(w, k, F, seed=0xF1BE + 7919 * rank)).to(dev) for k in range(d)]
+        F_job = F * world
+    F_loc = hi - lo
+    out_t = [torch.empty((F_loc, w.ngrid[k]), dtype=torch.float64, device=dev) for k in range(d)]
+    # FT cores on the device in the reference layout (what a cross-approximation step produces); each rank owns a
+    # 1/world slice of the flattened cores, updates it from its own outputs and all-gathers the rest per sweep
     flat, offs = pack_cores(cores)
     flat_t = torch.from_numpy(np.concatenate([flat, np.zeros(padded_len(len(flat), world) - len(flat))])).to(dev)
-    shard = flat_t.view(world, -1)[rank].clone()
+    shard0 = flat_t.view(world, -1)[rank].clone()
 
     def core_views(buf):
         return [buf[offs[m]:offs[m + 1]] for m in range(d)]
 
-    nodes_per_step = sum(F * w.ngrid[k] for k in range(d))
+    nodes_per_step_job = sum(F_job * w.ngrid[k] for k in range(d))
+    nodes_per_step_loc = sum(F_loc * w.ngrid[k] for k in range(d))
     ev = []
 
     def step(record):
@@ -152,8 +313,12 @@ def main():
             if record:
                 e1.record(stream)
                 ev.append((k, e0, e1))
-        # end of sweep: exchange the updated cores and re-stage them for the next sweep
-        gathered = allgather_cores(shard, world, force=use_dist) if use_dist else flat_t
+        # end of sweep: this rank's slice of the cores becomes a function of its own outputs (a stand-in for the core
+        # update of the cross approximation: a true data dependency, values moved by ~1e-12 only so that every step does
+        # the same work), the slices are exchanged and the cores re-staged for the next sweep
+        probe = out_t[d - 1][: min(F_loc, 4096)].mean()
+        shard = shard0 * (1.0 + 1e-12 * torch.tanh(probe))
+        gathered = allgather_cores(shard, world, force=use_dist) if (use_dist or world > 1) else shard
         eng.upload_value_device(w.ranks, core_views(gathered), sp)
 
     def fence():
@@ -180,68 +345,62 @@ def main():
     kms = [e0.elapsed_time(e1) for (_, e0, e1) in ev]
     avg_ms = float(np.mean(kms))
     Wf = wl.algorithmic_flops_per_node(w)
-    nodes_per_launch = nodes_per_step / d
+    nodes_per_launch = nodes_per_step_loc / d
     achieved_tflops = Wf * nodes_per_launch / (avg_ms * 1e-3) / 1e12
     bytes_per_node = float(np.mean([wl.algorithmic_bytes_per_node(w, k) for k in range(d)]))
     hbm_gbs = bytes_per_node * nodes_per_launch / (avg_ms * 1e-3) / 1e9
-
-    # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
-    # runs; FETCH x2 per the gfx950 correction of MI355X_MICROARCH.md) cannot be collected from inside this
-    # process, so the committed summary of the same command is read (profiles/README.md says how it was made).
-    traffic, traffic_src = None, None
-    try:
-        pmc_file = {1 << 17: "r01_f_fiber_pair_pmc.json", 1 << 20: "r01_g_fiber_pair_pmc.json"}.get(F)
-        if args.workload == "car7d" and pmc_file:
-            pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            ks = [v for kname, v in pm["kernels"].items() if "k_fiber_pair" in kname]
-            if ks and "fiber_pair" in eng.last_kernel():
-                traffic = float(np.mean([v["fetch_bytes_x2_gfx950_correction"] + v["write_bytes_per_launch"] for v in ks]))
-                traffic_src = "profiles/" + pmc_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch, FETCH x2)"
-    except (OSError, KeyError, ValueError):
-        pass
     kern = eng.last_kernel()
+    pm = pmc_summary(kern, F_loc)
     if "K=" in kern:
         kern = kern[: kern.index("K=")] + "K=0..%d>" % (d - 1)
 
     if rank == 0:
         res = {
             "metric": "Bellman-sweep nodes/sec (7D car rank-10)" if args.workload == "car7d" else f"Bellman-sweep nodes/sec ({w.name})",
-            "value": nodes_per_step * args.steps * world / elapsed,
+            "value": nodes_per_step_job * args.steps / elapsed,
             "unit": "nodes/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{w.name}: d={w.dx} N={w.ngrid[0]} FT rank {max(w.ranks)} U={w.ncand} controls, "
-                                   f"{F} random fibers per varying dim per GPU per step ({nodes_per_step} node backups/GPU/step), "
+                                   f"{F_job} random fibers per varying dim per step for the whole job ({nodes_per_step_job} node backups/step), "
                                    f"seeded synthetic cores (SURVEY.md 8d {'C4' if w.name == 'car7d' else ''})",
-                       "fibers_per_dim_per_gpu": F, "parallelism": f"fiber-sharded x{world}" if world > 1 else "single GPU",
-                       "exchange": "all-gather of FT cores per sweep (RCCL)" if world > 1 else "none"},
-            # not measured by this run: the examples' outer loop through libc3sc.so on the same config (tools/solve_to_tol.py)
-            "vi_iters_to_tol": ({"outer_iterations": 30, "bellman_sweeps": 341, "seconds": 5.6,
-                                 "criterion": "|V| plateau reached; the step difference then stays at the rank-10 truncation floor (0.4-1.7 % of |V|)",
-                                 "source": "profiles/r01_f_solve_car7d.txt"} if args.workload == "car7d" else None),
+                       "fibers_per_dim_per_gpu": F_loc, "fibers_per_dim_job": F_job,
+                       "parallelism": f"fiber-sharded x{world} ({args.scaling} scaling)" if world > 1 else "single GPU",
+                       "exchange": "all-gather of the updated FT cores per sweep (RCCL)" if world > 1 else "none"},
             "kernel_status_flags": status,
             "roofline": {
-                "bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_node * nodes_per_launch,
+                "bound": "valu_fp64", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / FP64_PEAK_TFLOPS,
+                "traffic": pm["traffic"] if pm else None, "traffic_unit": "bytes/launch", "traffic_source": pm["source"] if pm else None,
+                "algorithmic_bytes_per_launch": bytes_per_node * nodes_per_launch,
                 "kernel": kern, "avg_launch_ms": avg_ms, "launches": len(kms),
                 "algorithmic_flops_per_node": Wf, "nodes_per_launch": nodes_per_launch,
-                "note": "FP64 compute bound (vector FMA path; dense f64 MFMA peak is the same 78.6 TFLOP/s datasheet figure)",
+                # what the kernel actually executes (fold-once algebra), from the SQ_INSTS_VALU_*_F64 / MFMA counters of the
+                # committed PMC pass of this command; null when no such pass is committed for this kernel and batch
+                "executed_flops_per_node": pm.get("executed_flops_per_node") if pm else None,
+                "executed_frac": (pm["executed_flops_per_node"] * nodes_per_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
+                if pm and "executed_flops_per_node" in pm else None,
+                "note": "`achieved`/`frac` credit the ALGORITHMIC flops of SURVEY.md 8d (W = W_ft + U W_mc per node) as the task "
+                        "defines them; the kernel's fold-once algebra executes fewer (executed_flops_per_node, executed_frac). "
+                        "FP64 vector and matrix peak are the same 78.6 TFLOP/s datasheet figure",
                 "hbm_secondary": {"algorithmic_bytes_per_node": bytes_per_node, "achieved_GBs": hbm_gbs,
                                   "peak_GBs": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(w, cores, args.cpu_budget, args.cpu_procs)
-        else:
-            res["cpu_baseline"] = None
+        res["vi_sweep"], res["vi_iters_to_tol"] = None, None
+        if world == 1 and not args.no_solver:
+            try:
+                res["vi_sweep"], res["vi_iters_to_tol"] = solver_measurements(args.workload, args.solver_budget)
+            except Exception as e:  # the headline measurement above stands on its own
+                res["vi_sweep"] = {"error": repr(e)}
+        res["cpu_baseline"] = cpu_baseline(w, cores, args.cpu_budget, args.cpu_procs) if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

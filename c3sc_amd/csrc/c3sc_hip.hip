@@ -45,8 +45,8 @@ __global__ void k_pad_core(const double *__restrict__ src, double *__restrict__ 
 
 // Derived copies of a rank-padded middle core for the fiber-quad kernel (kernel_fiber_quad.hpp), made on the device from
 // the padded core itself: (1) the row-major transpose, (2) the two MFMA A operands of the varying-core products
-// c = G R (x = a, y = b) and a = L G (x = b, y = a): element [prod][mb][s][l] = M[x][y] with x = (i/4) C + 4 mb + i%4
-// (i = l % 16; a zero row when 4 mb + i%4 >= C) and y = (l/16) C + s, so that D register r of lane (q, t) is component
+// c = G R (x = a, y = b) and a = L G (x = b, y = a): element [prod][mb][s][l] = M[x][y] with x = (i%4) C + 4 mb + i/4
+// (i = l % 16; a zero row when 4 mb + i/4 >= C) and y = (l/16) C + s, so that D register r of lane (q, t) is component
 // q C + 4 mb + r of the product for fiber t.
 __global__ void k_quad_aux(const double *__restrict__ core, double *__restrict__ coreT, double *__restrict__ aop, int N, int RP)
 {
@@ -62,8 +62,8 @@ __global__ void k_quad_aux(const double *__restrict__ core, double *__restrict__
         } else {
             const int u = w - per_t;
             const int l = u % 64, s = (u / 64) % C, mb = (u / (64 * C)) % MB, prod = u / (64 * C * MB);
-            const int i = l % 16, g = 4 * mb + i % 4;
-            const int xc = (i / 4) * C + g, yc = (l / 16) * C + s;
+            const int i = l % 16, g = 4 * mb + i / 4; // D register r of lane (q, t) is row 4 r + q of the 16 x 16 block (probed:
+            const int xc = (i % 4) * C + g, yc = (l / 16) * C + s; // tools/probe_mfma_layout.hip), so A row i serves (q, r) = (i % 4, i / 4)
             double v = 0.0;
             if (g < C) v = (prod == 0) ? G[xc + yc * RP] : G[yc + xc * RP];
             aop[(size_t)j * per_a + u] = v;
@@ -269,6 +269,7 @@ static int pick_rp(int d, int maxrank, int model, int variant)
     return rp;
 }
 
+static unsigned long long g_launches = 0; // Bellman / stencil kernel launches of this process (c3sc_hip_launch_count)
 static int ensure_scratch(c3sc_hip_ctx *c, size_t bytes);
 static int ensure_pinned(c3sc_hip_ctx *c, size_t bytes);
 static bool zero_copy_batch(size_t bytes);
@@ -596,6 +597,7 @@ static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
+    g_launches++;
     const hipError_t he = e->fn(A, io);
     if (he == hipErrorOutOfMemory)
         return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: N x rank^2 of the varying core exceeds the 160 KB of LDS the per-wave kernel stages it in");
@@ -630,6 +632,7 @@ static int launch_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, co
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: no fiber-per-wave instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, nullptr, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
+    g_launches++;
     const hipError_t he = e->fn(A, io);
     if (he == hipErrorNotSupported) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: no box-minimiser instantiation for this model");
     HIPCHK(c, he);
@@ -736,6 +739,7 @@ static int launch_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx,
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_tables: no kernel instantiation for (dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, d_tables, d_costs2, (hipStream_t)stream};
+    g_launches++;
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
 }
@@ -819,6 +823,7 @@ int c3sc_hip_stencil_fibers_nb(c3sc_hip_ctx *c, int k, size_t F, const int32_t *
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "stencil_fibers: no kernel instantiation for (dim, rank, N)");
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, d_nb_fixed, d_nb_vary, nullptr, nullptr, (hipStream_t)stream};
+    g_launches++;
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
 }
@@ -987,6 +992,8 @@ int c3sc_hip_get_status(c3sc_hip_ctx *c, unsigned *flags, int clear)
     if (clear && *flags) HIPCHK(c, hipMemset(c->d_status, 0, sizeof(unsigned))); /* nothing to clear otherwise */
     return C3SC_OK;
 }
+
+unsigned long long c3sc_hip_launch_count(void) { return g_launches; }
 
 int c3sc_hip_debug_read(c3sc_hip_ctx *c, unsigned long long *out, size_t n)
 {

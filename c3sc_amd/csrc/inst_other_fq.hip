@@ -22,7 +22,7 @@ REG10Q(16, 8)
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 2, NWV, Scar4D)  \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 3, NWV, Scar4D)
 REG4Q(8, 8)
-REG4Q(20, 8)
+REG4Q(20, 4) // N x 400 doubles of a staged core leave LDS for four waves of node values only
 #define REG6Q(RP, NWV)                                     \
     C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 0, NWV, LqgNd<6>)   \
     C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 1, NWV, LqgNd<6>)   \

@@ -337,8 +337,6 @@ __global__ void __launch_bounds__(64 * NWV, 1)
                 for (int jj = 0; jj < 4; jj++) node_c(min(j0 + jj, N - 1), c[jj]);
 #pragma unroll
                 for (int i = 0; i < K; i++) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int m = K - 1 - i;
 #pragma unroll
                     for (int s = 0; s < 2; s++)

@@ -31,7 +31,7 @@ EXPORTS = [
     "c3sc_hip_set_control_box", "c3sc_hip_bellman_fibers_box", "c3sc_hip_bellman_fibers_box_host", "c3sc_hip_policy_fibers_box",
     "c3sc_hip_policy_fibers_box_host",
     "c3sc_hip_stencil_fibers_host", "c3sc_hip_stencil_fibers_nb", "c3sc_hip_stencil_fibers_nb_host", "c3sc_hip_sync", "c3sc_hip_get_status", "c3sc_hip_last_kernel",
-    "c3sc_hip_debug_read", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
+    "c3sc_hip_debug_read", "c3sc_hip_launch_count", "c3sc_hip_timer_start", "c3sc_hip_timer_stop", "c3sc_hip_peak_fma_f64", "c3sc_hip_peak_mfma_f64",
 ]
 
 VARIANT_AUTO, VARIANT_FIBER_PER_WAVE, VARIANT_FIBER_PER_LANE, VARIANT_FIBER_PAIR, VARIANT_FIBER_QUAD = 0, 1, 2, 3, 4
@@ -72,6 +72,7 @@ def load_library():
         L.c3sc_hip_stencil_fibers_nb_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_void_p]
         L.c3sc_hip_bellman_fibers_tables_host.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
+        L.c3sc_hip_launch_count.restype = C.c_ulonglong
         L.c3sc_hip_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.c3sc_hip_timer_start.argtypes = [C.c_void_p, C.c_void_p]
         L.c3sc_hip_timer_stop.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]

@@ -192,6 +192,9 @@ const char *c3sc_hip_last_kernel(const c3sc_hip_ctx *ctx);
 
 /* diagnostic builds only (C3SC_DBG & 128): per-wave segment cycle sums written by the kernels */
 int c3sc_hip_debug_read(c3sc_hip_ctx *ctx, unsigned long long *out, size_t n);
+/* diagnostics: Bellman / policy / stencil kernel launches made by this process so far (the reference calls its fiber
+ * callback once per fiber, bellman.c:1295; here one launch serves a batch -- this counts them) */
+unsigned long long c3sc_hip_launch_count(void);
 
 /* device-side timing on `stream` with HIP events (used by bench.py's roofline leg) */
 int c3sc_hip_timer_start(c3sc_hip_ctx *ctx, void *stream);

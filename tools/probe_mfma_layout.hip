@@ -8,15 +8,16 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-__global__ void k_probe(const double *A /*16x4 row-major*/, const double *B /*4x16 row-major*/, double *D /*16x16 row-major*/,
+__global__ void k_probe(const double *A /*16x4 row-major*/, const double *B /*4x16 row-major*/, double *D /*16x16 row-major*/, double *Draw /*[64][4] as held*/,
                         unsigned *sw32 /*[2][64]*/, unsigned *sw16 /*[2][64]*/)
 {
     const int l = threadIdx.x;
-    // assumed layout: A[i = l%16][k = l/16], B[k = l/16][n = l%16], D[i = 4*(l/16) + r][n = l%16]
+    // layout: A[i = l%16][k = l/16], B[k = l/16][n = l%16], D[i = 4*r + l/16][n = l%16]
     const double a = A[(l % 16) * 4 + l / 16], b = B[(l / 16) * 16 + l % 16];
     v4d c = {0, 0, 0, 0};
     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    for (int r = 0; r < 4; r++) D[(4 * (l / 16) + r) * 16 + l % 16] = c[r];
+    for (int r = 0; r < 4; r++) D[(4 * r + l / 16) * 16 + l % 16] = c[r];
+    for (int r = 0; r < 4; r++) Draw[l * 4 + r] = c[r];
     unsigned x = 1000 + l, y = 2000 + l;
     auto r32 = __builtin_amdgcn_permlane32_swap(x, y, false, false);
     sw32[l] = r32[0];
@@ -33,16 +34,30 @@ int main()
     for (int i = 0; i < 16; i++)
         for (int n = 0; n < 16; n++)
             for (int k = 0; k < 4; k++) ref[i * 16 + n] += A[i * 4 + k] * B[k * 16 + n];
-    double *dA, *dB, *dD;
+    double *dA, *dB, *dD, *dR;
     unsigned *d32, *d16;
-    hipMalloc(&dA, 64 * 8); hipMalloc(&dB, 64 * 8); hipMalloc(&dD, 256 * 8); hipMalloc(&d32, 128 * 4); hipMalloc(&d16, 128 * 4);
+    hipMalloc(&dA, 64 * 8); hipMalloc(&dB, 64 * 8); hipMalloc(&dD, 256 * 8); hipMalloc(&dR, 256 * 8); hipMalloc(&d32, 128 * 4); hipMalloc(&d16, 128 * 4);
     hipMemcpy(dA, A.data(), 64 * 8, hipMemcpyHostToDevice);
     hipMemcpy(dB, B.data(), 64 * 8, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, dA, dB, dD, d32, d16);
+    hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, dA, dB, dD, dR, d32, d16);
     hipMemcpy(D.data(), dD, 256 * 8, hipMemcpyDeviceToHost);
     unsigned s32[128], s16[128];
     hipMemcpy(s32, d32, 128 * 4, hipMemcpyDeviceToHost);
     hipMemcpy(s16, d16, 128 * 4, hipMemcpyDeviceToHost);
+    std::vector<double> Rw(256);
+    hipMemcpy(Rw.data(), dR, 256 * 8, hipMemcpyDeviceToHost);
+    // where does each held value belong?  (A / B operand layout as assumed; the products are pairwise distinct)
+    printf("D layout found by value: lane reg -> (row i, col n)\n");
+    for (int l = 0; l < 64; l += 1) {
+        if (!(l < 4 || l % 16 == 0 || l == 17 || l == 63)) continue;
+        printf("  lane %2d:", l);
+        for (int r = 0; r < 4; r++) {
+            int fi = -1, fn = -1;
+            for (int i = 0; i < 256; i++) if (std::abs(Rw[l * 4 + r] - ref[i]) < 1e-12) { fi = i / 16; fn = i % 16; }
+            printf("  r%d->(%2d,%2d)", r, fi, fn);
+        }
+        printf("\n");
+    }
     double err = 0;
     for (int i = 0; i < 256; i++) err = std::max(err, std::abs(D[i] - ref[i]));
     printf("mfma_f64_16x16x4 layout: max err %.3e -> %s\n", err, err < 1e-12 ? "AS ASSUMED" : "DIFFERENT");

@@ -246,8 +246,8 @@ static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, 
         if (e.k >= 0 && e.k != k) continue;
         if (variant != C3SC_VARIANT_AUTO && e.variant != variant) continue;
         auto pref = [small](int v) {
-            if (small) return v == C3SC_VARIANT_FIBER_PER_WAVE ? 0 : (v == C3SC_VARIANT_FIBER_PAIR ? 1 : 2);
-            return v == C3SC_VARIANT_FIBER_PAIR ? 0 : (v == C3SC_VARIANT_FIBER_PER_WAVE ? 1 : 2);
+            if (small) return v == C3SC_VARIANT_FIBER_PER_WAVE ? 0 : (v == C3SC_VARIANT_FIBER_PAIR ? 1 : (v == C3SC_VARIANT_FIBER_QUAD ? 2 : 3));
+            return v == C3SC_VARIANT_FIBER_PAIR ? 0 : (v == C3SC_VARIANT_FIBER_QUAD ? 1 : (v == C3SC_VARIANT_FIBER_PER_WAVE ? 2 : 3));
         };
         if (!best || e.rp < best->rp || (e.rp == best->rp && pref(e.variant) < pref(best->variant)) ||
             (e.rp == best->rp && e.variant == best->variant && e.npl < best->npl))

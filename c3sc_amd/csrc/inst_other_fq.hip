@@ -15,7 +15,7 @@ namespace c3sc {
     C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 8, NWV, Chain<10>)  \
     C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 9, NWV, Chain<10>)
 REG10Q(4, 8)
-REG10Q(16, 8)
+REG10Q(16, 4) // 2(d-1)+2 vectors of 4 doubles per lane: one wave per SIMD with the whole 512-entry register file, no scratch
 #define REG4Q(RP, NWV)                                   \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 0, NWV, Scar4D)  \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 1, NWV, Scar4D)  \

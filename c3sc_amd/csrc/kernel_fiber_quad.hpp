@@ -29,6 +29,10 @@
 #pragma once
 #include "kernel_common.hpp"
 
+#ifndef FQ_NVB
+#define FQ_NVB 4 // vectors per pass over a staged matrix in the folding phase
+#endif
+
 namespace c3sc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -72,28 +76,50 @@ __device__ __forceinline__ double reduce4(double p0, double p1, double p2, doubl
 // v <- M v for the vectors X[B0 .. B0+NVB): M is this lane's fiber's matrix in LDS, row-major [x][y] with row stride RP
 // (x = output component, y = input component; the left side stages the transposed core, so both sides are this product).
 // Lane (q, t) holds y in [qC, (q+1)C) of every vector and ends with x in the same range.
+// C consecutive doubles of a staged matrix row.  For even C the address is 16-byte aligned (node stride, row stride and q C
+// are all even numbers of doubles), which the compiler cannot see: told so, it emits ds_read_b128 (256 B/clk) instead of
+// ds_read2_b64 (128 B/clk) -- LDS is the busiest unit of the folding phase.
+template <int C>
+__device__ __forceinline__ void load_row(const double *p, double (&m)[C])
+{
+    if constexpr (C % 2 == 0) {
+        const double2 *p2 = reinterpret_cast<const double2 *>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+        for (int i = 0; i < C / 2; i++) { const double2 v = p2[i]; m[2 * i] = v.x; m[2 * i + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; i++) m[i] = p[i];
+    }
+}
+
 template <int RP, int NX, int B0, int NVB>
 __device__ __forceinline__ void apply_quad(const double *Mn, double (&X)[NX][RP / 4], int q)
 {
     constexpr int C = RP / 4;
     double o[NVB][C];
+    // The four rows of output group g are four independent FMA chains per vector, advanced together (a chain of its own per
+    // row and vector is C dependent f64 FMAs with nothing in between: latency-bound at one or two wavefronts per SIMD), and the
+    // rows of group g+1 are fetched from LDS while group g is summed.
+    double mrow[2][4][C];
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) load_row<C>(Mn + (qq * C) * RP + q * C, mrow[0][qq]);
 #pragma unroll
     for (int g = 0; g < C; g++) {
+        if (g + 1 < C) {
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) load_row<C>(Mn + (qq * C + g + 1) * RP + q * C, mrow[(g + 1) & 1][qq]);
+        }
         double P[NVB][4];
 #pragma unroll
-        for (int qq = 0; qq < 4; qq++) {
-            const double *row = Mn + (qq * C + g) * RP + q * C;
-            double mrow[C];
+        for (int s = 0; s < NVB; s++)
 #pragma unroll
-            for (int i = 0; i < C; i++) mrow[i] = row[i];
+            for (int qq = 0; qq < 4; qq++) P[s][qq] = mrow[g & 1][qq][0] * X[B0 + s][0];
 #pragma unroll
-            for (int s = 0; s < NVB; s++) {
-                double acc = 0.0;
+        for (int i = 1; i < C; i++)
 #pragma unroll
-                for (int i = 0; i < C; i++) acc = fma(mrow[i], X[B0 + s][i], acc);
-                P[s][qq] = acc;
-            }
-        }
+            for (int s = 0; s < NVB; s++)
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) P[s][qq] = fma(mrow[g & 1][qq][i], X[B0 + s][i], P[s][qq]);
 #pragma unroll
         for (int s = 0; s < NVB; s++) o[s][g] = reduce4(P[s][0], P[s][1], P[s][2], P[s][3]);
     }
@@ -101,6 +127,33 @@ __device__ __forceinline__ void apply_quad(const double *Mn, double (&X)[NX][RP 
     for (int s = 0; s < NVB; s++)
 #pragma unroll
         for (int g = 0; g < C; g++) X[B0 + s][g] = o[s][g];
+}
+
+// The two neighbour matrices of a level applied to the same vector v (the running prefix / suffix): the two products are
+// interleaved, eight independent chains per output group.
+template <int RP>
+__device__ __forceinline__ void apply_quad_pair(const double *Mlo, const double *Mhi, const double (&v)[RP / 4], double (&olo)[RP / 4],
+                                                double (&ohi)[RP / 4], int q)
+{
+    constexpr int C = RP / 4;
+#pragma unroll
+    for (int g = 0; g < C; g++) {
+        double ml[4][C], mh[4][C];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            load_row<C>(Mlo + (qq * C + g) * RP + q * C, ml[qq]);
+            load_row<C>(Mhi + (qq * C + g) * RP + q * C, mh[qq]);
+        }
+        double Pl[4], Ph[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) { Pl[qq] = ml[qq][0] * v[0]; Ph[qq] = mh[qq][0] * v[0]; }
+#pragma unroll
+        for (int i = 1; i < C; i++)
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) { Pl[qq] = fma(ml[qq][i], v[i], Pl[qq]); Ph[qq] = fma(mh[qq][i], v[i], Ph[qq]); }
+        olo[g] = reduce4(Pl[0], Pl[1], Pl[2], Pl[3]);
+        ohi[g] = reduce4(Ph[0], Ph[1], Ph[2], Ph[3]);
+    }
 }
 
 // one vector, result returned separately (the two neighbour matrices of a level are applied to the running prefix/suffix)
@@ -120,18 +173,25 @@ template <int RP, int NX, int B0>
 __device__ __forceinline__ void apply_live(const double *Mn, double (&X)[NX][RP / 4], int nlive, int q)
 {
     if constexpr (B0 < NX) {
-        constexpr int NVB = (NX - B0) < 4 ? (NX - B0) : 4;
+        constexpr int NVB = (NX - B0) < FQ_NVB ? (NX - B0) : FQ_NVB;
         if (B0 < nlive) apply_quad<RP, NX, B0, NVB>(Mn, X, q); // wave-uniform
         apply_live<RP, NX, B0 + NVB>(Mn, X, nlive, q);
     }
 }
 
-// coalesced copy of `count` doubles (even) from global memory into LDS by the whole workgroup
-__device__ inline void stage_linear(double *dst, const double *__restrict__ src, int count)
+// LDS stride of one node's matrix / vector: two doubles of padding shift consecutive nodes by four banks, so the 16 fibers
+// of a wavefront (16 different nodes in general) do not all read the same bank (an unpadded rank^2 stride is a multiple of
+// the 64 banks: a 16-way conflict on every read)
+__host__ __device__ constexpr int quad_stride(int elems) { return elems + 2; }
+
+// coalesced copy of n_nodes x elems doubles (elems even) from global memory into LDS rows of quad_stride(elems), whole workgroup
+__device__ inline void stage_padded(double *dst, const double *__restrict__ src, int n_nodes, int elems)
 {
-    const int pairs = count >> 1;
-    for (int p = threadIdx.x; p < pairs; p += blockDim.x)
-        reinterpret_cast<double2 *>(dst)[p] = reinterpret_cast<const double2 *>(src)[p];
+    const int pairs = (n_nodes * elems) >> 1;
+    for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
+        const int e = 2 * p, node = e / elems;
+        *reinterpret_cast<double2 *>(dst + e + 2 * node) = *reinterpret_cast<const double2 *>(src + e);
+    }
 }
 
 // c or a of one node on the matrix cores: out[g] = sum_y M[qC+g][y] v[y] with M = G_k[j] (c) or its transpose (a)
@@ -149,6 +209,37 @@ __device__ __forceinline__ void mfma_prod(const double *__restrict__ aop /* [MB]
         for (int mb = 0; mb < MB; mb++) acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[(mb * C + s) * 64 + lane], v[s], acc[mb], 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < C; g++) out[g] = acc[g / 4][g % 4];
+}
+
+// the same product for the four nodes of a round, one K step at a time: only four A operands are in flight at once
+// (left to itself the scheduler hoists all 4 x C loads of a round above the first MFMA: 8 C registers per lane)
+template <int RP>
+__device__ __forceinline__ void mfma_prod4(const double *__restrict__ aop, const int (&jn)[4], const double (&v)[RP / 4],
+                                           double (&out)[4][RP / 4], int lane)
+{
+    constexpr int C = RP / 4, MB = quad_mb(RP);
+    v4d acc[4][MB];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) acc[jj][mb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < C; s++) {
+        double av[4][MB];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) av[jj][mb] = aop[(size_t)jn[jj] * quad_aop_node(RP) + (mb * C + s) * 64 + lane];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) acc[jj][mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[jj][mb], v[s], acc[jj][mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+        for (int g = 0; g < C; g++) out[jj][g] = acc[jj][g / 4][g % 4];
 }
 
 template <int C>
@@ -222,25 +313,26 @@ __global__ void __launch_bounds__(64 * NWV, 1)
 #pragma nounroll
             for (int m = D - 1; m > K; m--) {
                 const bool edge = (m == D - 1);
-                const int elems = edge ? RP : RP * RP;
+                const int elems = edge ? RP : RP * RP, ns = quad_stride(elems);
                 __syncthreads();
-                stage_linear(sM, ro + (edge ? A.core_off[m] : A.quad_coreT_off[m]), A.ngrid[m] * elems);
+                if (!(A.dbg & 512)) stage_padded(sM, ro + (edge ? A.core_off[m] : A.quad_coreT_off[m]), A.ngrid[m], elems);
                 __syncthreads();
                 const int nd = idx[f * D + m];
                 int lo, hi;
                 (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
                 double T0[C], T1[C];
+#pragma unroll
+                for (int i = 0; i < C; i++) { T0[i] = 0.0; T1[i] = 0.0; }
                 if (edge) { // r x 1 column core
 #pragma unroll
                     for (int i = 0; i < C; i++) {
-                        XR[0][i] = sM[nd * RP + q * C + i];
-                        T0[i] = sM[lo * RP + q * C + i];
-                        T1[i] = sM[hi * RP + q * C + i];
+                        XR[0][i] = sM[nd * ns + q * C + i];
+                        T0[i] = sM[lo * ns + q * C + i];
+                        T1[i] = sM[hi * ns + q * C + i];
                     }
-                } else {
-                    apply_quad1<RP>(sM + lo * elems, XR[0], T0, q);
-                    apply_quad1<RP>(sM + hi * elems, XR[0], T1, q);
-                    apply_live<RP, 1 + NR, 0>(sM + nd * elems, XR, nlive, q);
+                } else if (!(A.dbg & 256)) {
+                    apply_quad_pair<RP>(sM + lo * ns, sM + hi * ns, XR[0], T0, T1, q);
+                    apply_live<RP, 1 + NR, 0>(sM + nd * ns, XR, nlive, q);
                 }
 #pragma unroll
                 for (int s = NR; s >= 3; s--)
@@ -257,25 +349,26 @@ __global__ void __launch_bounds__(64 * NWV, 1)
 #pragma nounroll
             for (int m = 0; m < K; m++) {
                 const bool edge = (m == 0);
-                const int elems = edge ? RP : RP * RP;
+                const int elems = edge ? RP : RP * RP, ns = quad_stride(elems);
                 __syncthreads();
-                stage_linear(sM, ro + A.core_off[m], A.ngrid[m] * elems);
+                if (!(A.dbg & 512)) stage_padded(sM, ro + A.core_off[m], A.ngrid[m], elems);
                 __syncthreads();
                 const int nd = idx[f * D + m];
                 int lo, hi;
                 (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
                 double T0[C], T1[C];
+#pragma unroll
+                for (int i = 0; i < C; i++) { T0[i] = 0.0; T1[i] = 0.0; }
                 if (edge) { // 1 x r row core
 #pragma unroll
                     for (int i = 0; i < C; i++) {
-                        XL[0][i] = sM[nd * RP + q * C + i];
-                        T0[i] = sM[lo * RP + q * C + i];
-                        T1[i] = sM[hi * RP + q * C + i];
+                        XL[0][i] = sM[nd * ns + q * C + i];
+                        T0[i] = sM[lo * ns + q * C + i];
+                        T1[i] = sM[hi * ns + q * C + i];
                     }
-                } else {
-                    apply_quad1<RP>(sM + lo * elems, XL[0], T0, q);
-                    apply_quad1<RP>(sM + hi * elems, XL[0], T1, q);
-                    apply_live<RP, 1 + NL, 0>(sM + nd * elems, XL, nlive, q);
+                } else if (!(A.dbg & 256)) {
+                    apply_quad_pair<RP>(sM + lo * ns, sM + hi * ns, XL[0], T0, T1, q);
+                    apply_live<RP, 1 + NL, 0>(sM + nd * ns, XL, nlive, q);
                 }
 #pragma unroll
                 for (int s = NL; s >= 3; s--)
@@ -305,9 +398,10 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             }
         };
 
-        // ---- pass 1: node values v_j = L G_k[j] R for the neighbours along the varying dimension
+        // ---- pass 1: node values v_j = L G_k[j] R (the neighbours along the varying dimension), four nodes per round
+        const bool forced = A.forced != nullptr; // wave-uniform
         wave_sync(); // the previous tile's readers of sV are done
-        for (int j0 = 0; j0 < N; j0 += 4) {
+        for (int j0 = 0; j0 < ((A.dbg & 2048) ? 0 : N); j0 += 4) {
             double P[4];
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
@@ -328,13 +422,18 @@ __global__ void __launch_bounds__(64 * NWV, 1)
         wave_sync();
 
         // ---- pass 2: stencils, boundary flags, control minimisation; lane (q, t) finalises node j0 + q of fiber t
-        const bool forced = A.forced != nullptr; // wave-uniform
-        for (int j0 = 0; j0 < N; j0 += 4) {
+#ifndef FQ_NO_PASS2
+        for (int j0 = 0; j0 < ((A.dbg & 4096) ? 0 : N); j0 += 4) {
             double V[S];
             if constexpr (K > 0) {
                 double c[4][C];
+                if constexpr (K < D - 1) {
+                    const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
+                    mfma_prod4<RP>(aopK, jn, XR[0], c, lane);
+                } else {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) node_c(min(j0 + jj, N - 1), c[jj]);
+                    for (int jj = 0; jj < 4; jj++) node_c(min(j0 + jj, N - 1), c[jj]);
+                }
 #pragma unroll
                 for (int i = 0; i < K; i++) {
                     const int m = K - 1 - i;
@@ -344,10 +443,16 @@ __global__ void __launch_bounds__(64 * NWV, 1)
                                                dot_c<C>(XL[1 + 2 * i + s], c[2]), dot_c<C>(XL[1 + 2 * i + s], c[3]));
                 }
             }
+            __builtin_amdgcn_sched_barrier(0); // the c products and their dots retire before the a products start: 32 fewer live VGPRs
             if constexpr (K < D - 1) {
                 double a[4][C];
+                if constexpr (K > 0) {
+                    const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
+                    mfma_prod4<RP>(aopK + quad_aop_node(RP) / 2, jn, XL[0], a, lane);
+                } else {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) node_a(min(j0 + jj, N - 1), a[jj]);
+                    for (int jj = 0; jj < 4; jj++) node_a(min(j0 + jj, N - 1), a[jj]);
+                }
 #pragma unroll
                 for (int i = 0; i < D - 1 - K; i++) {
                     const int m = K + 1 + i;
@@ -357,6 +462,7 @@ __global__ void __launch_bounds__(64 * NWV, 1)
                                                dot_c<C>(a[2], XR[1 + 2 * i + s]), dot_c<C>(a[3], XR[1 + 2 * i + s]));
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             const bool nlive = (j0 + q < N);
             const int j = nlive ? j0 + q : N - 1;
             // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
@@ -372,15 +478,20 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             tv[0] = 0.0;
 #pragma unroll
             for (int tt = 0; tt < Model::NTAB; tt++) tv[tt] = (Model::tab_dim(tt) == K) ? ro[A.tab_off[tt] + j] : tvf[tt];
-            int ui;
+            int ui = 0;
             const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
-            const double val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+            double val = V[0] + V[2 * D - 1];
+            ui = 0;
+#ifndef FQ_NO_BACKUP
+            if (!(A.dbg & 1024)) val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+#endif
             if (nlive && flive) {
                 outv[(size_t)f * N + j] = val;
                 if (uidx) uidx[(size_t)f * N + j] = ui;
                 if (absorbed) absorbed[(size_t)f * N + j] = ab;
             }
         }
+#endif
     }
     if (st) atomicOr(A.status, st);
 }

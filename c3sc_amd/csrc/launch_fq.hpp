@@ -15,7 +15,7 @@ hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
     size_t doubles = 0;
     for (int m = 0; m < D; m++) {
         if (m == K) continue;
-        const size_t need = (size_t)A.ngrid[m] * ((m == 0 || m == D - 1) ? RP : RP * RP);
+        const size_t need = (size_t)A.ngrid[m] * quad_stride((m == 0 || m == D - 1) ? RP : RP * RP);
         if (need > doubles) doubles = need;
     }
     doubles = (doubles + 1) & ~(size_t)1;

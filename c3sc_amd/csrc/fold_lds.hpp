@@ -1,0 +1,162 @@
+// fold_lds.hpp -- folding helpers of the lane = fiber kernels (kernel_fiber_pair.hpp): a lane applies ITS fiber's matrix
+// (G_m[i_m] with the lane's own i_m), read from a core staged once per tile in LDS with an odd node stride, to up to four
+// vectors per pass; products are software-pipelined by hand (see the scheduling note below).  These were written for the
+// one-wave-per-64-fibers kernel of round 1 (k_fiber_per_lane), which was retired in round 2: it was capped by the FP64
+// issue rate of one wavefront per SIMD, AUTO never picked it, and it was the last kernel that depended on the "no
+// lane-divergent branch may touch a lane-distributed table" rule.
+#pragma once
+#include <utility>
+
+#include "kernel_common.hpp"
+
+namespace c3sc {
+
+#ifndef FPL_NV
+#define FPL_NV 2
+#endif
+// keep the scheduler from hoisting whole matrices of loads ahead of their FMAs (register pressure)
+#ifndef FPL_NO_FENCE
+#define FPL_SCHED_FENCE() asm volatile("" ::: "memory")
+#else
+#define FPL_SCHED_FENCE()
+#endif
+
+__host__ __device__ constexpr int fpl_lds_stride(int elems) { return elems | 1; } // odd #doubles per node
+
+// Scheduling control.  hipcc's schedulers happily hoist every LDS load of an unrolled r x r product above
+// the FMAs (200 live VGPRs per matrix -> AGPR/scratch spills that made the first version of this kernel
+// 20x slower than its instruction count).  The products below are therefore software-pipelined BY HAND:
+// column b+1 is loaded while column b is consumed, and an empty asm that "modifies" the accumulators and
+// clobbers memory pins each column's FMAs between its neighbours' loads.
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void mem_fence() { asm volatile("" ::: "memory"); }
+
+// out[b] = sum_a v[a] G[a + b*RP]   (row vector times the lane's own matrix in LDS), NV vectors per pass.
+// Walks the matrix ROW by row so that the RP outputs are RP independent FMA chains (a column-wise walk is one
+// RP-deep dependent chain per output and is latency-bound at two wavefronts per SIMD).
+template <int RP, int NV>
+__device__ inline void vecmat_lds(const double *G, double (&v)[NV][RP])
+{
+    double t[NV][RP];
+    double g[2][RP];
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int b = 0; b < RP; b++) t[s][b] = 0.0;
+#pragma unroll
+    for (int b = 0; b < RP; b++) g[0][b] = G[b * RP];
+#pragma unroll
+    for (int a = 0; a < RP; a++) {
+        if (a + 1 < RP) {
+#pragma unroll
+            for (int b = 0; b < RP; b++) g[(a + 1) & 1][b] = G[(a + 1) + b * RP];
+        }
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int b = 0; b < RP; b++) {
+                t[s][b] = fma(v[s][a], g[a & 1][b], t[s][b]);
+                pin(t[s][b]);
+            }
+        mem_fence();
+    }
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int b = 0; b < RP; b++) v[s][b] = t[s][b];
+}
+
+// out[a] = sum_b G[a + b*RP] v[b]   (matrix times column vector)
+template <int RP, int NV>
+__device__ inline void matvec_lds(const double *G, double (&v)[NV][RP])
+{
+    double t[NV][RP];
+    double g[2][RP];
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int a = 0; a < RP; a++) t[s][a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < RP; a++) g[0][a] = G[a];
+#pragma unroll
+    for (int b = 0; b < RP; b++) {
+        if (b + 1 < RP) {
+#pragma unroll
+            for (int a = 0; a < RP; a++) g[(b + 1) & 1][a] = G[a + (b + 1) * RP];
+        }
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) {
+                t[s][a] = fma(g[b & 1][a], v[s][b], t[s][a]);
+                pin(t[s][a]);
+            }
+        mem_fence();
+    }
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int a = 0; a < RP; a++) v[s][a] = t[s][a];
+}
+
+// apply `op` to W[FIRST .. FIRST+COUNT) in passes of at most 4 vectors (compile-time recursion)
+template <int RP, int NW, int FIRST, int COUNT, bool ROWVEC, int NVMAX = FPL_NV>
+__device__ inline void apply_core(const double *G, double (&W)[NW][RP])
+{
+    if constexpr (COUNT > 0) {
+        constexpr int NV = COUNT >= NVMAX ? NVMAX : COUNT;
+        double tmp[NV][RP];
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) tmp[s][a] = W[FIRST + s][a];
+        if constexpr (ROWVEC) vecmat_lds<RP, NV>(G, tmp);
+        else matvec_lds<RP, NV>(G, tmp);
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) W[FIRST + s][a] = tmp[s][a];
+        apply_core<RP, NW, FIRST + NV, COUNT - NV, ROWVEC, NVMAX>(G, W);
+    }
+}
+
+template <int RP>
+__device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < RP; i++) s = fma(a[i], b[i], s);
+    return s;
+}
+
+// cooperative global -> LDS copy of one core with the padded node stride
+__device__ inline void stage_core_n(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride, int nthreads)
+{
+    // The copy is pure latency (33 KB from L2 per core and tile): every thread moves PAIRS of doubles (16-byte
+    // loads; elems is even, so a pair never straddles two nodes) and keeps a batch of 8 loads in flight before
+    // the first LDS write.  dst index of element e = e + (e / elems) * (stride - elems).  Trip counts are the same
+    // for every thread; past the end a thread repeats the last pair (same values to the same slots): no
+    // lane-divergent branch or loop exit.
+    const int pairs = (n_nodes * elems) >> 1, pad = stride - elems;
+    constexpr int B = 8;
+    const int per_batch = B * nthreads;
+    for (int base = 0; base < pairs; base += per_batch) {
+        double2 buf[B];
+        int pe[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int p = base + q * nthreads + (int)threadIdx.x;
+            pe[q] = 2 * (p < pairs ? p : pairs - 1);
+            buf[q] = *reinterpret_cast<const double2 *>(src + pe[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int node = pe[q] / elems; // elems is a small wave-uniform value: one multiply-high
+            double *d = sK + pe[q] + node * pad;
+            d[0] = buf[q].x;
+            d[1] = buf[q].y;
+        }
+    }
+}
+
+} // namespace c3sc

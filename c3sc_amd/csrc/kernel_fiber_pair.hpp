@@ -1,6 +1,6 @@
 // kernel_fiber_pair.hpp -- "one fiber per lane, two wavefronts per 64 fibers" Bellman kernel (gfx950).
 //
-// Same algebra as kernel_fiber_per_lane.hpp (fold everything that is constant along a fiber into
+// Fold-once algebra (fold everything that is constant along a fiber into
 // L, R and the 2(d-1) neighbour vectors w_m^{-+} / z_m^{-+}; per node only c = G_k[j] R, a = L G_k[j]
 // and 2d-1 short dots remain), but the folded vectors do not fit the 256 VALU-addressable VGPRs of a
 // lane (2(d-1) r doubles = 240 VGPRs at d = 7, r = 10).  So a WORKGROUP OF TWO WAVEFRONTS owns 64
@@ -20,7 +20,7 @@
 #pragma once
 #include <utility>
 
-#include "kernel_fiber_per_lane.hpp"
+#include "fold_lds.hpp"
 
 #ifndef FPP_CGD
 #define FPP_CGD 3
@@ -522,8 +522,8 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         double vwrap = 0.0;
         if (bck == C3SC_PERIODIC) {
             const double pv = partials(N - 2, [](int, double) __attribute__((always_inline)) {});
-            B0[(NP + H) * 64 + lane] = pv; // two spare slots: B0[NP] (wave 0) and B1[0].. use B0[NP] / B1[NP]
-            if constexpr (H == 1) B1[NP * 64 + lane] = pv;
+            if constexpr (H == 0) B0[NP * 64 + lane] = pv; // each wave writes the spare row of its own exchange block
+            else B1[NP * 64 + lane] = pv;
             pair_barrier();
             vwrap = pv + (H == 0 ? B1[NP * 64 + lane] : B0[NP * 64 + lane]);
             pair_barrier();

@@ -26,23 +26,12 @@ hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
     doubles += (size_t)CandLds<Model>::doubles(A.ncand) + (size_t)NodeLds<Model, K>::doubles(A.N);
     const size_t shmem = doubles * sizeof(double);
     auto kern = k_fiber_pair<Model, RP, K, FORCED>;
-    static int blocks_per_cu = 0;
-    static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
-    hipError_t e;
-    if (shmem > attr_shmem) {
-        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        attr_shmem = shmem;
-    }
-    if (shmem != occ_shmem) {
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, FPP_THREADS, shmem);
-        if (e != hipSuccess) return e;
-        blocks_per_cu = nb > 0 ? nb : 1;
-        occ_shmem = shmem;
-    }
+    static LaunchCache cache;
+    int blocks_per_cu = 1, num_cu = 256;
+    hipError_t e = cache.prepare((const void *)kern, FPP_THREADS, shmem, blocks_per_cu, num_cu);
+    if (e != hipSuccess) return e;
     const long ntiles = (A.F + 63) / 64;
-    const long cap = 256L * blocks_per_cu;
+    const long cap = (long)num_cu * blocks_per_cu;
     // Persistent workgroups (one per resident slot, striding over the tiles) amortise the per-workgroup set-up, but a
     // static split leaves the slots that drew the slow tiles running at the end.  Once there are many tiles per slot the
     // hardware dispatcher balances better with one workgroup per tile (car7d, 2^20 fibers = 16 tiles per slot: 1.84 vs

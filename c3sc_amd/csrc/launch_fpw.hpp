@@ -5,8 +5,6 @@
 
 namespace c3sc {
 
-constexpr int NUM_CU = 256; // MI355X
-
 template <class Model, int RP, int NPL, bool STENCIL, bool BOX, bool STAGED>
 hipError_t launch_fpw_impl(const KArgs &A, const LaunchIO &io)
 {
@@ -19,23 +17,12 @@ hipError_t launch_fpw_impl(const KArgs &A, const LaunchIO &io)
     if constexpr (!STENCIL && !Model::IS_TABLE) doubles += (size_t)CandLds<Model>::doubles(A.ncand);
     const size_t shmem = doubles * sizeof(double);
     auto kern = k_fiber_per_wave<Model, RP, NPL, STENCIL, BOX, STAGED>;
-    static int blocks_per_cu = 0;
-    static size_t attr_shmem = 0, occ_shmem = (size_t)-1;
-    hipError_t e;
-    if (shmem > attr_shmem) { // dynamic LDS above 64 KiB must be opted into
-        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        attr_shmem = shmem;
-    }
-    if (shmem != occ_shmem) {
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, shmem);
-        if (e != hipSuccess) return e;
-        blocks_per_cu = nb > 0 ? nb : 1;
-        occ_shmem = shmem;
-    }
+    static LaunchCache cache;
+    int blocks_per_cu = 1, num_cu = 256;
+    hipError_t e = cache.prepare((const void *)kern, 256, shmem, blocks_per_cu, num_cu);
+    if (e != hipSuccess) return e;
     long want = (A.F + 3) / 4;
-    long cap = (long)NUM_CU * blocks_per_cu;
+    long cap = (long)num_cu * blocks_per_cu;
     int grid = (int)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, io.stream, B, io.ro, io.idx, io.out, io.uidx, io.absorbed,

@@ -27,32 +27,12 @@ hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
     const size_t shmem = doubles * sizeof(double);
     if (shmem > 160u * 1024u) return hipErrorOutOfMemory;
     auto kern = k_fiber_quad<Model, RP, K, NWV>;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static LaunchCache cache;
+    int blocks_per_cu = 1, num_cu = 256;
+    hipError_t e = cache.prepare((const void *)kern, 64 * NWV, shmem, blocks_per_cu, num_cu);
     if (e != hipSuccess) return e;
-    // per device: the dynamic-LDS opt-in and the occupancy belong to the device the context runs on
-    constexpr int MAXDEV = 16;
-    static size_t attr_shmem[MAXDEV] = {0}, occ_shmem[MAXDEV] = {0};
-    static int blocks_per_cu[MAXDEV] = {0}, num_cu[MAXDEV] = {0};
-    if (dev < 0 || dev >= MAXDEV) return hipErrorInvalidDevice;
-    if (shmem > attr_shmem[dev]) {
-        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        attr_shmem[dev] = shmem;
-    }
-    if (shmem != occ_shmem[dev] || blocks_per_cu[dev] == 0) {
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NWV, shmem);
-        if (e != hipSuccess) return e;
-        blocks_per_cu[dev] = nb > 0 ? nb : 1;
-        occ_shmem[dev] = shmem;
-        hipDeviceProp_t prop;
-        e = hipGetDeviceProperties(&prop, dev);
-        if (e != hipSuccess) return e;
-        num_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
     const long per_tile = 16L * NWV, ntiles = (A.F + per_tile - 1) / per_tile;
-    const long cap = (long)num_cu[dev] * blocks_per_cu[dev];
+    const long cap = (long)num_cu * blocks_per_cu;
     int grid = (int)(ntiles < cap ? ntiles : cap);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), shmem, io.stream, B, io.ro, io.idx, io.out, io.uidx, io.absorbed);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 
 #include "kernel_common.hpp"
@@ -36,6 +37,46 @@ struct KernelEntry {
 };
 
 std::vector<KernelEntry> &kernel_registry();
+
+// What a launcher has to find out once per (kernel, device, dynamic-LDS size): the opt-in to more than 64 KiB of dynamic
+// LDS (hipFuncSetAttribute applies to the CURRENT device only), the resident workgroups per CU and the CU count.  One
+// instance per kernel instantiation (a function-local static of the launcher), slots per device, guarded by a mutex: the
+// C API allows contexts on several devices and calls from several threads.
+struct LaunchCache {
+    static constexpr int MAXDEV = 16;
+    std::mutex mu;
+    size_t attr_shmem[MAXDEV] = {0}, occ_shmem[MAXDEV] = {0};
+    int blocks_per_cu[MAXDEV] = {0}, num_cu[MAXDEV] = {0};
+    hipError_t prepare(const void *kern, int threads, size_t shmem, int &blocks, int &cus)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= MAXDEV) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lk(mu);
+        if (shmem > attr_shmem[dev]) {
+            e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) return e;
+            attr_shmem[dev] = shmem;
+        }
+        if (blocks_per_cu[dev] == 0 || shmem != occ_shmem[dev]) {
+            int nb = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, shmem);
+            if (e != hipSuccess) return e;
+            blocks_per_cu[dev] = nb > 0 ? nb : 1;
+            occ_shmem[dev] = shmem;
+        }
+        if (num_cu[dev] == 0) {
+            hipDeviceProp_t prop;
+            e = hipGetDeviceProperties(&prop, dev);
+            if (e != hipSuccess) return e;
+            num_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        blocks = blocks_per_cu[dev];
+        cus = num_cu[dev];
+        return hipSuccess;
+    }
+};
 
 struct Registrar {
     explicit Registrar(const KernelEntry &e) { kernel_registry().push_back(e); }

@@ -64,7 +64,8 @@ enum {
                                    the reference asserts (bellman.c:452); the candidate is skipped here */
 };
 
-/* kernel variants (c3sc_hip_set_variant); 0 lets the library choose */
+/* kernel variants (c3sc_hip_set_variant); 0 lets the library choose.  Set the variant BEFORE uploading the value: the padded
+ * rank of the device copy follows it (the quad kernel wants multiples of 4).  2 (one wavefront per 64 fibers) was retired. */
 enum { C3SC_VARIANT_AUTO = 0, C3SC_VARIANT_FIBER_PER_WAVE = 1, C3SC_VARIANT_FIBER_PER_LANE = 2, C3SC_VARIANT_FIBER_PAIR = 3,
        C3SC_VARIANT_FIBER_QUAD = 4 };
 

@@ -73,10 +73,10 @@ FPL = [("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)), ("car7d", dict(ng
 
 
 @pytest.mark.parametrize("name,kw", FPL, ids=[f"{n}-r{k['rank']}" for n, k in FPL])
-@pytest.mark.parametrize("variant,tag", [(2, "fiber_per_lane"), (3, "fiber_pair")])
-def test_fiber_per_lane_kernel_vs_oracle(oracle, name, kw, variant, tag):
-    """The fiber-per-lane / fiber-pair kernels (one per varying dimension) against the oracle, incl.
-    ragged tiles (F not a multiple of the tile), boundary faces and the periodic wrap."""
+@pytest.mark.parametrize("variant,tag", [(3, "fiber_pair")])
+def test_fiber_pair_kernel_vs_oracle(oracle, name, kw, variant, tag):
+    """The fiber-pair kernels (one per varying dimension) against the oracle, incl. ragged tiles (F not a multiple
+    of the tile), boundary faces and the periodic wrap."""
     w = wl.WORKLOADS[name]().scaled(**kw)
     cores = wl.synth_cores(w)
     P = oracle.Problem(w, cores)

@@ -1,5 +1,5 @@
-"""The fiber-pair / fiber-per-lane kernels keep wave-uniform tables in VGPR lanes (NodeRegs, CandRegs) and read
-them with v_readlane.  A register the compiler spills and reloads inside a lane-divergent branch is only restored
+"""The fiber-pair kernels compute wave-uniform tables lane-distributed (NodeRegs, CandRegs: v_readlane) before parking
+them in LDS.  A register the compiler spills and reloads inside a lane-divergent branch is only restored
 for the active lanes, so those kernels must not contain lane-divergent control flow at all (kernel_common.hpp,
 node_backup).  This test compiles the headline instantiations to ISA and checks that EXEC is only touched by the
 single-lane status atomic of the epilogue."""
@@ -17,7 +17,7 @@ EXEC_WRITE = re.compile(r"saveexec|s_mov_b64 exec|s_and_b64 exec|s_andn2_b64 exe
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("src,kernel", [("inst_car7d_fpp.hip", "k_fiber_pair"), ("inst_other_fpp.hip", "k_fiber_pair"),
-                                        ("inst_lqg6_fpp.hip", "k_fiber_pair"), ("inst_car7d_fpl.hip", "k_fiber_per_lane")])
+                                        ("inst_lqg6_fpp.hip", "k_fiber_pair")])
 def test_no_lane_divergent_control_flow(tmp_path, src, kernel):
     out = tmp_path / "k.s"
     subprocess.run([HIPCC, "-std=c++20", "-O3", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),

@@ -58,3 +58,37 @@ def allgather_fiber_outputs(local_out_t, F: int, world: int):
     full = torch.empty((per * world, N), dtype=buf.dtype, device=buf.device)
     dist.all_gather_into_tensor(full, buf)
     return full[:F]
+
+
+# the exchange callback of include/c3sc/valuefunc.h (c3sc_exchange_fn): int (*)(double *out, size_t F, size_t N, size_t lo, size_t hi, void *)
+def make_fiber_exchange(world: int, rank: int, device=None, group=None):
+    """All-gather of a core step's fiber values for libc3sc.so's sharded solver (c3control_set_fiber_sharding /
+    valuef_interp_idx_sharded): rank r has filled rows [lo, hi) of the host array out[F][N]; afterwards every rank holds all F
+    rows.  One all_gather_into_tensor of ceil(F/world) x N doubles per core step -- tens of KB, latency-bound -- through the
+    process group's backend: RCCL over xGMI with a device staging tensor when `device` is given, gloo on host memory
+    otherwise.  Returns the ctypes callback (keep a reference while the solver may call it)."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    EX = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p)
+
+    def _exchange(out_p, F, N, lo, hi, _xarg):
+        try:
+            per = (F + world - 1) // world
+            out = np.ctypeslib.as_array(out_p, shape=(F * N,)).reshape(F, N)
+            buf = torch.zeros((per, N), dtype=torch.float64)
+            if hi > lo:
+                buf[: hi - lo] = torch.from_numpy(out[lo:hi])
+            if device is not None:
+                buf = buf.to(device)
+            full = torch.empty((per * world, N), dtype=torch.float64, device=buf.device)
+            dist.all_gather_into_tensor(full, buf, group=group)
+            out[:] = full[:F].cpu().numpy()
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            print(f"c3sc fiber exchange failed on rank {rank}: {e!r}", flush=True)
+            return 1
+
+    return EX(_exchange)

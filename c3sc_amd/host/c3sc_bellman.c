@@ -107,6 +107,7 @@ struct ValueF *valuef_copy(struct ValueF *vf)
     struct ValueF *c = valuef_create_nodal(vf->d, vf->N, vf->ranks, vf->cores);
     if (vf->grid) valuef_attach_grid(c, vf->grid);
     if (vf->isl) valuef_set_cross_indices(c, vf->nisl, vf->isl, vf->nisr, vf->isr);
+    c->elem_class = vf->elem_class;
     return c;
 }
 size_t *valuef_get_ranks(struct ValueF *vf) { return vf->ranks; }
@@ -1046,6 +1047,10 @@ struct C3Control {
     struct c3Opt *opt_sim;
     void (*transform_sim)(size_t, const double *, double *);
     double *prevpol;
+    /* fibers of every core step sharded over the GPUs of a node (c3control_set_fiber_sharding) */
+    size_t shard_world, shard_rank;
+    c3sc_exchange_fn shard_exchange;
+    void *shard_xarg;
 };
 
 struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, double *ub, size_t *ngrid, double discount)
@@ -1093,6 +1098,15 @@ void c3control_add_stagecost(struct C3Control *c, int (*f)(double, const double 
 void c3control_add_boundcost(struct C3Control *c, int (*f)(double, const double *, double *)) { dp_param_add_boundcost(c->dp, f); }
 void c3control_add_obscost(struct C3Control *c, int (*f)(const double *, double *)) { dp_param_add_obscost(c->dp, f); }
 void c3control_set_device_model(struct C3Control *c, int model, const double *params, size_t n) { dp_param_set_device_model(c->dp, model, params, n); }
+
+void c3control_set_fiber_sharding(struct C3Control *c, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg)
+{ /* one process per GPU: every rank runs the same solver; step_vi / step_pi evaluate 1/world of each core step's fibers
+     on their own device and all-gather the values (world <= 1 or exchange == NULL switches it off) */
+    c->shard_world = world;
+    c->shard_rank = rank;
+    c->shard_exchange = exchange;
+    c->shard_xarg = xarg;
+}
 
 struct VIparam *c3control_begin_vi(struct C3Control *c, struct ValueF *vf, struct c3Opt *opt)
 { /* the callback state c3control_step_vi assembles before valuef_interp (bellman.c:2192-2199) */
@@ -1256,7 +1270,8 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
 { /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
     struct VIparam *vi = c3control_begin_vi(c, vf, opt);
     struct ApproxArgs *aa = device_rank_cap(c, apargs);
-    struct ValueF *next = valuef_interp_idx(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose);
+    struct ValueF *next = valuef_interp_idx_sharded(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose,
+                                                    c->shard_world, c->shard_rank, c->shard_exchange, c->shard_xarg);
     approx_args_free(aa);
     c3control_end_vi(c, vi, nevals);
     return next;
@@ -1267,7 +1282,8 @@ struct ValueF *c3control_step_pi(struct C3Control *c, struct ValueF *vf, struct 
 { /* bellman.c:2214-2262 */
     c3control_begin_pi_step(c, poli, vf, opt);
     struct ApproxArgs *aa = device_rank_cap(c, apargs);
-    struct ValueF *next = valuef_interp_idx(c->dx, bellman_pi_batch_idx, poli, c->ngrid, c->xgrid, vf, aa, verbose);
+    struct ValueF *next = valuef_interp_idx_sharded(c->dx, bellman_pi_batch_idx, poli, c->ngrid, c->xgrid, vf, aa, verbose,
+                                                    c->shard_world, c->shard_rank, c->shard_exchange, c->shard_xarg);
     approx_args_free(aa);
     c3control_end_pi_step(c, poli, niter_evals);
     return next;

@@ -470,11 +470,25 @@ static double tt_rel_change(const struct tt *a, const struct tt *b, double nb2, 
 /* continuous L2 inner products of the piecewise-multilinear interpolants of nodal TTs: weight every core along its
  * node index with L^T, M = L L^T the (tridiagonal) mass matrix of the hat functions on that grid; nodal sums of
  * the weighted TTs are then integrals. */
-static struct tt *tt_weight_l2(const struct tt *src, double **grid)
+/* Piecewise-constant elements (CONSTELM, valuefunc.c:665-667; C3's const_elem_exp): the nodal value holds on the cell
+ * around its node -- half way to each neighbour -- so the mass matrix is diagonal with those cell widths.  What the
+ * reference's own test pins (tprob_test.c:1899-1994): norm and point values of a constant agree with LINELM to 1e-10;
+ * beyond that the element class lives in C3 (unpinned). */
+static struct tt *tt_weight_l2(const struct tt *src, double **grid, int elem_class)
 {
     struct tt *t = tt_copy(src);
     for (size_t k = 0; k < t->d; k++) {
         const size_t N = t->N[k], r0 = t->r[k], r1 = t->r[k + 1];
+        if (elem_class == CONSTELM) {
+            for (size_t i = 0; i < N; i++) {
+                const double hl = (i > 0) ? grid[k][i] - grid[k][i - 1] : 0.0;
+                const double hr = (i + 1 < N) ? grid[k][i + 1] - grid[k][i] : 0.0;
+                const double w = sqrt(0.5 * (hl + hr));
+                for (size_t b = 0; b < r1; b++)
+                    for (size_t a = 0; a < r0; a++) t->G[k][a + r0 * (i + N * b)] *= w;
+            }
+            continue;
+        }
         double *dg = xcalloc(N, sizeof(double)), *lo = xcalloc(N, sizeof(double)); /* L: diagonal and sub-diagonal */
         for (size_t i = 0; i < N; i++) {
             const double hl = (i > 0) ? grid[k][i] - grid[k][i - 1] : 0.0;
@@ -498,9 +512,9 @@ static struct tt *tt_weight_l2(const struct tt *src, double **grid)
 }
 
 /* ||src||_L2.  A norm has no cancellation, so the Gram recursion is exact to rounding. */
-static double tt_norm_l2(const struct tt *src, double **grid)
+static double tt_norm_l2(const struct tt *src, double **grid, int elem_class)
 {
-    struct tt *t = tt_weight_l2(src, grid);
+    struct tt *t = tt_weight_l2(src, grid, elem_class);
     const double n2 = tt_dot(t, t);
     tt_free(t);
     return sqrt(n2 > 0.0 ? n2 : 0.0);
@@ -508,9 +522,9 @@ static double tt_norm_l2(const struct tt *src, double **grid)
 
 /* ||a - b||_L2: Gram recursion while the answer is far above its cancellation level (1e-5 of the larger norm),
  * otherwise through the orthogonalised difference (error eps*||.||, not sqrt(eps)*||.||) */
-static double tt_norm2diff_l2(const struct tt *a, const struct tt *b, double **grid)
+static double tt_norm2diff_l2(const struct tt *a, const struct tt *b, double **grid, int elem_class)
 {
-    struct tt *wa = tt_weight_l2(a, grid), *wb = tt_weight_l2(b, grid);
+    struct tt *wa = tt_weight_l2(a, grid, elem_class), *wb = tt_weight_l2(b, grid, elem_class);
     const double aa = tt_dot(wa, wa), bb = tt_dot(wb, wb), ab = tt_dot(wa, wb);
     const double d2 = aa - 2.0 * ab + bb;
     double n;
@@ -539,7 +553,7 @@ double valuef_norm(struct ValueF *vf)
 { /* valuefunc.c:315-322 -> function_train_norm2 of linear elements: sqrt(int V^2) */
     struct tt *t = tt_from_valuef(vf);
     double **g = vf->grid ? vf->grid : unit_grid(vf->d, vf->N);
-    const double n = tt_norm_l2(t, g);
+    const double n = tt_norm_l2(t, g, vf->elem_class);
     if (!vf->grid) { for (size_t k = 0; k < vf->d; k++) free(g[k]); free(g); }
     tt_free(t);
     return n;
@@ -550,7 +564,7 @@ double valuef_norm2diff(struct ValueF *a, struct ValueF *b)
     assert(a->d == b->d);
     struct tt *ta = tt_from_valuef(a), *tb = tt_from_valuef(b);
     double **g = a->grid ? a->grid : (b->grid ? b->grid : unit_grid(a->d, a->N));
-    const double n = tt_norm2diff_l2(ta, tb, g);
+    const double n = tt_norm2diff_l2(ta, tb, g, a->elem_class);
     if (!a->grid && !b->grid) { for (size_t k = 0; k < a->d; k++) free(g[k]); free(g); }
     tt_free(ta); tt_free(tb);
     return n;
@@ -576,6 +590,7 @@ double valuef_eval(struct ValueF *vf, const double *x)
             i = lo;
             wt = (x[m] - g[lo]) / (g[lo + 1] - g[lo]);
         }
+        if (vf->elem_class == CONSTELM) wt = (wt < 0.5) ? 0.0 : 1.0; /* the nearer node's value holds on its cell */
         const double *G0 = vf->cores[m] + i * r0 * r1, *G1 = vf->cores[m] + (i + 1 < N ? i + 1 : i) * r0 * r1;
         for (size_t b = 0; b < r1; b++) {
             double s = 0.0;
@@ -770,7 +785,8 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                                   struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 {
     if (d < 2) DIE("valuef_interp: need at least two dimensions");
-    if (approx_args_get_function_class(aargs) != LINELM) DIE("valuef_interp: only LINELM (nodal linear elements) is built");
+    const int elem_class = (int)approx_args_get_function_class(aargs);
+    if (elem_class != LINELM && elem_class != CONSTELM) DIE("valuef_interp: function class must be LINELM or CONSTELM (valuefunc.c:661-669)");
     size_t minN = N[0];
     for (size_t k = 0; k < d; k++) if (N[k] < minN) minN = N[k];
     size_t maxrank = approx_args_get_maxrank(aargs);
@@ -868,6 +884,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     }
     if (verbose > 0) { printf("Final Ranks: "); for (size_t k = 0; k <= d; k++) printf("%zu ", best->r[k]); printf("\n"); }
     struct ValueF *vf = valuef_from_tt(best, grid);
+    vf->elem_class = elem_class;
     if (getenv("C3SC_PROFILE")) {
         g_tc[5] = tnow() - t_all;
         fprintf(stderr, "c3sc cross profile: total %.2f ms = fibers (callback + gather) %.2f, qr %.2f, maxvol %.2f, convergence check %.2f, rounding %.2f\n",
@@ -902,6 +919,40 @@ struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32
                                  const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 { /* fibers handed over as grid indices: fi(F, dim_vary, idx[F*d], out[F*N], args) */
     return interp_impl(d, NULL, NULL, fi, args, N, grid, vref, aargs, verbose);
+}
+
+/* fibers of a core step sharded over ranks: the wrapper the cross driver sees in place of fi */
+struct shard_args {
+    int (*fi)(size_t, size_t, const int32_t *, double *, void *);
+    void *args;
+    size_t d, world, rank;
+    const size_t *N;
+    c3sc_exchange_fn exchange;
+    void *xarg;
+};
+
+static int sharded_fibers_idx(size_t F, size_t k, const int32_t *idx, double *out, void *arg)
+{
+    struct shard_args *s = arg;
+    const size_t per = (F + s->world - 1) / s->world;
+    size_t lo = s->rank * per, hi;
+    if (lo > F) lo = F;
+    hi = lo + per > F ? F : lo + per;
+    const size_t N = s->N[k];
+    int rc = 0;
+    if (hi > lo) rc = s->fi(hi - lo, k, idx + lo * s->d, out + lo * N, s->args);
+    if (rc != 0) return rc;
+    return s->exchange(out, F, N, lo, hi, s->xarg);
+}
+
+struct ValueF *valuef_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
+                                         const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
+                                         int verbose, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg)
+{
+    if (world <= 1 || exchange == NULL) return valuef_interp_idx(d, fi, args, N, grid, vref, aargs, verbose);
+    if (rank >= world) DIE("valuef_interp_idx_sharded: rank %zu of %zu", rank, world);
+    struct shard_args s = {fi, args, d, world, rank, N, exchange, xarg};
+    return interp_impl(d, NULL, NULL, sharded_fibers_idx, &s, N, grid, vref, aargs, verbose);
 }
 
 /* ------------------------------------------------------------------------------ value-function files

@@ -21,6 +21,7 @@ struct ValueF {
     double **grid;               /* nodes per dimension, or NULL (valuef_create_nodal without valuef_attach_grid) */
     size_t *nisl, *nisr;         /* cross index sets of the last interpolation (warm start), or NULL */
     int **isl, **isr;
+    int elem_class;              /* 0 / LINELM: piecewise-linear between the nodes; CONSTELM: piecewise-constant (valuefunc.c:661-669) */
     unsigned long version;       /* bumps on every construction: identifies an upload */
     struct c3sc_hip_ctx *bound;  /* device context the cores were uploaded to */
 };

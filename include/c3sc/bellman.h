@@ -86,6 +86,9 @@ void c3control_add_stagecost(struct C3Control *, int (*)(double, const double *,
 void c3control_add_boundcost(struct C3Control *, int (*)(double, const double *, double *));
 void c3control_add_obscost(struct C3Control *, int (*)(const double *, double *));
 void c3control_set_device_model(struct C3Control *, int model, const double *params, size_t nparams); /* new */
+/* new: multi-GPU (one process per GPU, every rank runs the same solver): the fibers of every core step of step_vi /
+ * step_pi are split over `world` ranks and all-gathered by `exchange` (valuefunc.h: valuef_interp_idx_sharded) */
+void c3control_set_fiber_sharding(struct C3Control *, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg);
 /* one value-iteration sweep's callback state, as c3control_step_vi builds it (bellman.c:2177-2199); the
  * cross approximation that consumes it (valuef_interp -> C3) is out of scope, so the caller drives the fibers */
 struct VIparam *c3control_begin_vi(struct C3Control *, struct ValueF *vf, struct c3Opt *opt);

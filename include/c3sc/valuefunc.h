@@ -41,6 +41,15 @@ struct ValueF *valuef_interp_batch(size_t d, int (*fb)(size_t, size_t, const dou
 struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
                                  const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
                                  int verbose);
+/* new: the same, with the fibers of every core step sharded over `world` ranks (one process per GPU): rank r runs fi on
+ * the contiguous block [lo, hi) = ceil(F/world) fibers and `exchange(out, F, N_k, lo, hi, xarg)` fills the other ranks'
+ * rows of out[F*N_k] (an all-gather: RCCL on the GPU box, gloo in the CPU tests; c3sc_amd/distributed.py builds it).
+ * Every rank then holds the same fiber values and takes the same QR / maxvol decisions, so the ranks' results are
+ * bit-identical to each other and to the unsharded call.  SURVEY.md 8e; the reference hook is bellman.c:2201. */
+typedef int (*c3sc_exchange_fn)(double *out, size_t F, size_t N, size_t lo, size_t hi, void *xarg);
+struct ValueF *valuef_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
+                                         const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
+                                         int verbose, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg);
 double valuef_norm(struct ValueF *);                       /* valuefunc.c:315-322: sqrt(int V^2), linear elements */
 double valuef_norm2diff(struct ValueF *, struct ValueF *); /* valuefunc.c:324-335 */
 double valuef_eval(struct ValueF *, const double *x);      /* valuefunc.c:337-343: off-grid multilinear interpolant */

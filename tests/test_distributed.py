@@ -83,3 +83,130 @@ def test_gloo_world2_shard_and_gather(oracle):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_cores and ok_out
+
+
+# ---- the sharded solver path of libc3sc.so (valuef_interp_idx_sharded / c3control_set_fiber_sharding) ---------------------
+def _sharded_worker(rank, world, port, q, use_gpu):
+    import ctypes as C
+    import sys
+
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import facade_lib
+    import oracle_lib
+    from c3sc_amd.distributed import make_fiber_exchange
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = facade_lib.lib()
+    for n in ("valuef_interp_idx", "valuef_interp_idx_sharded", "c3control_init_value", "c3control_step_vi"):
+        getattr(L, n).restype = C.c_void_p
+    L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+    L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
+    ex = make_fiber_exchange(world, rank)
+
+    def cores_of(vf, w):
+        ranks = [int(L.valuef_get_ranks(vf)[i]) for i in range(w.dx + 1)]
+        pp = L.valuef_get_cores(vf)
+        return ranks, [np.ctypeslib.as_array(pp[m], shape=(w.ngrid[m] * ranks[m] * ranks[m + 1],)).copy() for m in range(w.dx)]
+
+    def aargs():
+        aa = C.c_void_p(L.approx_args_init())
+        L.approx_args_set_cross_tol(aa, C.c_double(1e-10))
+        L.approx_args_set_round_tol(aa, C.c_double(1e-9))
+        L.approx_args_set_kickrank(aa, C.c_size_t(2))
+        L.approx_args_set_startrank(aa, C.c_size_t(3))
+        L.approx_args_set_maxrank(aa, C.c_size_t(6))
+        return aa
+
+    if not use_gpu:
+        # CPU: the cross driver's sharded core steps with the oracle's bellman_vi as the fiber function (no device here)
+        w = wl.c2_dubins().scaled(ngrid=(9, 8, 10), rank=3)
+        P = oracle_lib.Problem(w, wl.synth_cores(w))
+        FI = C.CFUNCTYPE(C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p)
+        calls = []
+
+        def fi(F, k, idx_p, out_p, _a):
+            idx = np.ctypeslib.as_array(idx_p, shape=(F, w.dx)).copy()
+            out = np.ctypeslib.as_array(out_p, shape=(F, w.ngrid[k]))
+            out[:] = P.bellman_fibers(k, idx, want_absorbed=False)[0]
+            calls.append(F)
+            return 0
+
+        cb = FI(fi)
+        xg = [facade_lib.f64(g) for g in w.xgrid()]
+        gp, Ng, aa = facade_lib.ptrs(xg), facade_lib.usz(w.ngrid), aargs()
+        a = C.c_void_p(L.valuef_interp_idx_sharded(C.c_size_t(w.dx), cb, None, facade_lib.sp(Ng), gp, None, aa, 0, C.c_size_t(world),
+                                                   C.c_size_t(rank), ex, None))
+        n_sharded = sum(calls)
+        calls.clear()
+        b = C.c_void_p(L.valuef_interp_idx(C.c_size_t(w.dx), cb, None, facade_lib.sp(Ng), gp, None, aa, 0))
+        n_full = sum(calls)
+        ra, ca = cores_of(a, w)
+        rb, cb_ = cores_of(b, w)
+        same = ra == rb and all(np.array_equal(x, y) for x, y in zip(ca, cb_))
+        q.put((rank, same, n_sharded, n_full))
+    else:
+        # GPU: the whole solver step (c3control_step_vi, device kernels) sharded over two ranks on the one device of the box
+        w = wl.c4_car7d().scaled(ngrid=(11,) * 7, rank=4)
+        ctl = facade_lib.Control(w)
+        aa = aargs()
+        zero = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(1.0), 0)[1])
+        outs = []
+        for sharded in (True, False):
+            L.c3control_set_fiber_sharding(ctl.h, C.c_size_t(world if sharded else 1), C.c_size_t(rank), ex if sharded else None, None)
+            vf = C.c_void_p(L.c3control_init_value(ctl.h, zero, None, aa, 0))
+            ne = C.c_size_t(0)
+            for _ in range(3):
+                nxt = C.c_void_p(L.c3control_step_vi(ctl.h, vf, aa, ctl.opt, 0, C.byref(ne)))
+                L.valuef_destroy(vf)
+                vf = nxt
+            outs.append((cores_of(vf, w), ne.value))
+        (ra, ca), na = outs[0]
+        (rb, cb_), nb = outs[1]
+        same = ra == rb and all(np.array_equal(x, y) for x, y in zip(ca, cb_))
+        q.put((rank, same, na, nb))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_sharded(use_gpu):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, use_gpu)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_gloo_world2_sharded_cross_driver(oracle):
+    """valuef_interp_idx_sharded on two gloo ranks: every rank evaluates half of each core step's fibers, the exchange
+    callback (c3sc_amd.distributed.make_fiber_exchange) all-gathers them, and both ranks end with the cores of the
+    unsharded interpolation, bit for bit."""
+    res = _run_sharded(False)
+    for rank, same, n_sharded, n_full in res:
+        assert same, f"rank {rank}: sharded result differs from the unsharded one"
+        assert 0 < n_sharded < 0.75 * n_full  # about half of the fibers ran on this rank
+
+
+@pytest.mark.gpu
+def test_world2_sharded_solver_step_matches_single_rank(oracle):
+    """c3control_set_fiber_sharding: three value-iteration sweeps of the car problem through libc3sc.so with the fibers of
+    every core step split over two ranks (both on the box's one GPU, exchange over gloo) against the same sweeps unsharded:
+    identical cores on both ranks, about half the node backups per rank."""
+    res = _run_sharded(True)
+    for rank, same, n_sharded, n_full in res:
+        assert same, f"rank {rank}: sharded sweeps differ from the unsharded ones"
+        assert 0 < n_sharded < 0.8 * n_full

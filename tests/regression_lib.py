@@ -57,19 +57,28 @@ class _Base:
         L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
         L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
         self.case = case
-        self.n, self.max_updates, self.conv, adapt, startrank, self.break_on_conv = CASES[case]
-        self.w = workload(self.n)
+        if isinstance(case, dict):  # the same loops on another problem: {w, max_updates, conv, adapt, startrank, ...}
+            cfg = dict(cross_tol=1e-8, round_tol=1e-7, kick=5, maxrank=20, start_value=0.2, break_on_conv=False, pi_sweeps=10)
+            cfg.update(case)
+            self.w, self.n = cfg["w"], cfg["w"].ngrid[0]
+        else:
+            n, max_updates, conv, adapt, startrank, brk = CASES[case]
+            cfg = dict(w=workload(n), max_updates=max_updates, conv=conv, adapt=adapt, startrank=startrank, break_on_conv=brk,
+                       cross_tol=1e-8, round_tol=1e-7, kick=5, maxrank=20, start_value=0.2, pi_sweeps=10)  # tprob_test.c:2303-2309
+            self.w, self.n = cfg["w"], n
+        self.max_updates, self.conv, self.break_on_conv, self.pi_sweeps = cfg["max_updates"], cfg["conv"], cfg["break_on_conv"], cfg["pi_sweeps"]
         box = None if minimiser == "bruteforce" else ([-1.0], [1.0])  # tprob_test.c:2290-2299
         self.ctl = facade_lib.Control(self.w, box=box)
-        aa = C.c_void_p(L.approx_args_init())  # tprob_test.c:2303-2309
-        L.approx_args_set_cross_tol(aa, C.c_double(1e-8))
-        L.approx_args_set_round_tol(aa, C.c_double(1e-7))
-        L.approx_args_set_kickrank(aa, C.c_size_t(5))
-        L.approx_args_set_adapt(aa, C.c_int(adapt))
-        L.approx_args_set_startrank(aa, C.c_size_t(startrank))
-        L.approx_args_set_maxrank(aa, C.c_size_t(20))
+        aa = C.c_void_p(L.approx_args_init())
+        L.approx_args_set_cross_tol(aa, C.c_double(cfg["cross_tol"]))
+        L.approx_args_set_round_tol(aa, C.c_double(cfg["round_tol"]))
+        L.approx_args_set_kickrank(aa, C.c_size_t(cfg["kick"]))
+        L.approx_args_set_adapt(aa, C.c_int(cfg["adapt"]))
+        L.approx_args_set_startrank(aa, C.c_size_t(cfg["startrank"]))
+        L.approx_args_set_maxrank(aa, C.c_size_t(cfg["maxrank"]))
         self.aa = aa
-        self._quad2d = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.2), 0)[1])
+        sv = float(cfg["start_value"])
+        self._quad2d = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(sv), 0)[1])
         self.history = []  # (update, |V_vi - V_pi|, |V|, rank)
         self.sweeps = 0
 
@@ -80,7 +89,7 @@ class _Base:
         return self.L.valuef_norm(vf)
 
     def rank(self, vf):
-        return int(self.L.valuef_get_ranks(vf)[1])
+        return max(int(self.L.valuef_get_ranks(vf)[i]) for i in range(self.w.dx + 1))
 
     def cores_of(self, vf):
         w = self.w
@@ -89,10 +98,14 @@ class _Base:
         return ranks, [np.ctypeslib.as_array(pp[m], shape=(w.ngrid[m] * ranks[m] * ranks[m + 1],)).copy() for m in range(w.dx)]
 
     def nodal(self, vf):
-        """Every nodal value V[i0, i1] (2-D: G0[i0] (1 x r) times G1[i1] (r x 1))."""
+        """Every nodal value (the full tensor; small grids only): chain of the cores in the reference layout a + b r_m."""
+        w = self.w
         ranks, cores = self.cores_of(vf)
-        r = ranks[1]
-        return cores[0].reshape(self.n, r) @ cores[1].reshape(self.n, r).T
+        acc = np.ones((1, 1))
+        for m in range(w.dx):
+            G = cores[m].reshape(w.ngrid[m], ranks[m + 1], ranks[m]).transpose(2, 0, 1)  # [a, j, b]
+            acc = np.tensordot(acc, G, axes=([acc.ndim - 1], [0]))  # [..., j, b]
+        return acc.reshape(w.ngrid)
 
     # the reference test's outer loop (tprob_test.c:2329-2344); pi_solve / vi_solve supplied by the subclass
     def run(self, max_updates=None, cost=None, budget_s=None, on_update=None):
@@ -102,7 +115,7 @@ class _Base:
         t0 = time.time()
         nupd = self.max_updates if max_updates is None else min(max_updates, self.max_updates)
         for ii in range(nupd):
-            nxt = self.pi_solve(10, self.conv, cost)
+            nxt = self.pi_solve(self.pi_sweeps, self.conv, cost)
             L.valuef_destroy(cost)
             tmp = self.vi_solve(1, self.conv, nxt)
             diff = L.valuef_norm2diff(nxt, tmp)

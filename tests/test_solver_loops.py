@@ -127,3 +127,31 @@ def test_policy_and_value_iteration_loops_contract():
     L.valuef_destroy(cost)
     L.approx_args_free(aa)
     ctl.close()
+
+
+def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
+    """The examples' outer loop (pi_solve(10) + one vi_solve step per control update, e.g. dubinscar.c:343-352) on a reduced
+    7-D car grid, 20 control updates: each update run on the device path and on the oracle-fed path from the SAME state
+    agrees to 1e-6 of max |V| node by node (measured ~1e-14).  (The first update from the constant start value is skipped in
+    the lock-step: exact ties between candidates there, see tests/test_reference_regression.py.)"""
+    import regression_lib as R
+
+    w = wl.c4_car7d().scaled(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)
+    cfg = dict(w=w, max_updates=21, conv=1e-9, adapt=1, startrank=3, maxrank=5, kick=2, cross_tol=1e-10, round_tol=1e-9, start_value=1.0)
+    gpu, orc = R.GpuLoop(cfg), R.OracleLoop(cfg)
+    Lb = gpu.L
+    state = gpu.run(max_updates=1)
+    worst = 0.0
+    for _ in range(20):
+        a = gpu.run(max_updates=1, cost=C.c_void_p(Lb.valuef_copy(state)))
+        b = orc.run(max_updates=1, cost=C.c_void_p(Lb.valuef_copy(state)))
+        vb = orc.nodal(b)
+        worst = max(worst, np.abs(gpu.nodal(a) - vb).max() / np.abs(vb).max())
+        Lb.valuef_destroy(b)
+        Lb.valuef_destroy(state)
+        state = a
+    print(f"car7d {w.ngrid}: 20 control updates in lock-step, worst nodal L-inf / max|V| = {worst:.3e}; |V| = {gpu.norm(state):.6e}, rank {gpu.rank(state)}")
+    assert worst <= 1e-6
+    Lb.valuef_destroy(state)
+    gpu.close()
+    orc.close()

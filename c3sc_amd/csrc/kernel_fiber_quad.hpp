@@ -27,6 +27,8 @@
 // Citations: valuef_eval_fiber_ind_nn src/valuefunc.c:369-585, process_fibers_neighbor src/nodeutil.c:489-627,
 // bellman_optimal / bellman_control src/bellman.c:504-543, 367-480 (see kernel_common.hpp).
 #pragma once
+#include <type_traits>
+
 #include "kernel_common.hpp"
 
 #ifndef FQ_NVB
@@ -252,7 +254,7 @@ __device__ __forceinline__ double dot_c(const double (&a)[C], const double (&b)[
 }
 
 // NWV wavefronts per workgroup share the staged cores; registers per lane <= 512 / (NWV / 4)
-template <class Model, int RP, int K, int NWV>
+template <class Model, int RP, int K, int NWV, bool ONEPASS>
 __global__ void __launch_bounds__(64 * NWV, 1)
     k_fiber_quad(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
                  int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
@@ -398,41 +400,20 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             }
         };
 
-        // ---- pass 1: node values v_j = L G_k[j] R (the neighbours along the varying dimension), four nodes per round
         const bool forced = A.forced != nullptr; // wave-uniform
-        wave_sync(); // the previous tile's readers of sV are done
-        for (int j0 = 0; j0 < ((A.dbg & 2048) ? 0 : N); j0 += 4) {
-            double P[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const int jn = min(j0 + jj, N - 1);
-                if constexpr (K == 0) {
-                    double a[C];
-                    node_a(jn, a);
-                    P[jj] = dot_c<C>(a, XR[0]);
-                } else {
-                    double c[C];
-                    node_c(jn, c);
-                    P[jj] = dot_c<C>(XL[0], c);
-                }
-            }
-            const double v = reduce4(P[0], P[1], P[2], P[3]);
-            if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
-        }
-        wave_sync();
-
-        // ---- pass 2: stencils, boundary flags, control minimisation; lane (q, t) finalises node j0 + q of fiber t
-#ifndef FQ_NO_PASS2
-        for (int j0 = 0; j0 < ((A.dbg & 4096) ? 0 : N); j0 += 4) {
-            double V[S];
+        // stencil of a round of four nodes, every dimension but K: lane (q, t) ends with the values of node j0 + q of fiber t;
+        // with SELF the node values v_j = L G_k[j] R of the round are formed as well (from the c / a already in registers)
+        // and put into this wave's LDS row
+        auto stencil = [&](int j0, double (&V)[S], auto self_tag) __attribute__((always_inline)) {
+            constexpr bool SELF = decltype(self_tag)::value;
+            double vs[4] = {0.0, 0.0, 0.0, 0.0};
+            const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
             if constexpr (K > 0) {
                 double c[4][C];
-                if constexpr (K < D - 1) {
-                    const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
-                    mfma_prod4<RP>(aopK, jn, XR[0], c, lane);
-                } else {
+                if constexpr (K < D - 1) mfma_prod4<RP>(aopK, jn, XR[0], c, lane);
+                else {
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) node_c(min(j0 + jj, N - 1), c[jj]);
+                    for (int jj = 0; jj < 4; jj++) node_c(jn[jj], c[jj]);
                 }
 #pragma unroll
                 for (int i = 0; i < K; i++) {
@@ -442,16 +423,18 @@ __global__ void __launch_bounds__(64 * NWV, 1)
                         V[2 * m + s] = reduce4(dot_c<C>(XL[1 + 2 * i + s], c[0]), dot_c<C>(XL[1 + 2 * i + s], c[1]),
                                                dot_c<C>(XL[1 + 2 * i + s], c[2]), dot_c<C>(XL[1 + 2 * i + s], c[3]));
                 }
+                if constexpr (SELF) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) vs[jj] = dot_c<C>(XL[0], c[jj]);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0); // the c products and their dots retire before the a products start: 32 fewer live VGPRs
+            __builtin_amdgcn_sched_barrier(0); // the c products and their dots retire before the a products start
             if constexpr (K < D - 1) {
                 double a[4][C];
-                if constexpr (K > 0) {
-                    const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
-                    mfma_prod4<RP>(aopK + quad_aop_node(RP) / 2, jn, XL[0], a, lane);
-                } else {
+                if constexpr (K > 0) mfma_prod4<RP>(aopK + quad_aop_node(RP) / 2, jn, XL[0], a, lane);
+                else {
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) node_a(min(j0 + jj, N - 1), a[jj]);
+                    for (int jj = 0; jj < 4; jj++) node_a(jn[jj], a[jj]);
                 }
 #pragma unroll
                 for (int i = 0; i < D - 1 - K; i++) {
@@ -461,8 +444,19 @@ __global__ void __launch_bounds__(64 * NWV, 1)
                         V[2 * m + s] = reduce4(dot_c<C>(a[0], XR[1 + 2 * i + s]), dot_c<C>(a[1], XR[1 + 2 * i + s]),
                                                dot_c<C>(a[2], XR[1 + 2 * i + s]), dot_c<C>(a[3], XR[1 + 2 * i + s]));
                 }
+                if constexpr (SELF && K == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) vs[jj] = dot_c<C>(a[jj], XR[0]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SELF) {
+                const double v = reduce4(vs[0], vs[1], vs[2], vs[3]);
+                if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+            }
+        };
+        // boundary flags and control minimisation of node j0 + q of fiber t from its stencil (the dim-K entries come from sV)
+        auto finalize = [&](int j0, double (&V)[S]) __attribute__((always_inline)) {
             const bool nlive = (j0 + q < N);
             const int j = nlive ? j0 + q : N - 1;
             // node coordinates, obstacle / face / end-point flags (nodeutil.c:496-624)
@@ -481,17 +475,62 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             int ui = 0;
             const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
             double val = V[0] + V[2 * D - 1];
-            ui = 0;
-#ifndef FQ_NO_BACKUP
             if (!(A.dbg & 1024)) val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
-#endif
             if (nlive && flive) {
                 outv[(size_t)f * N + j] = val;
                 if (uidx) uidx[(size_t)f * N + j] = ui;
                 if (absorbed) absorbed[(size_t)f * N + j] = ab;
             }
+        };
+        wave_sync(); // the previous tile's readers of sV are done
+        if constexpr (ONEPASS) {
+            // one pass: a round's stencils wait in registers until the next round has produced the value of the node after
+            // its last one (S more doubles per lane, no second set of products)
+            if (bck == C3SC_PERIODIC && N > 5) { // node 0 needs v[N-2] long before the last round produces it
+                double Vw[S];
+                stencil((N - 2) & ~3, Vw, std::true_type{});
+            }
+            double Vp[S];
+#pragma unroll
+            for (int s = 0; s < S; s++) Vp[s] = 0.0;
+            const int rounds = (N + 3) / 4;
+            for (int r = 0; r <= rounds; r++) {
+                double Vc[S];
+#pragma unroll
+                for (int s = 0; s < S; s++) Vc[s] = 0.0;
+                if (r < rounds) stencil(4 * r, Vc, std::true_type{});
+                wave_sync(); // this round's node values are visible to the wave
+                if (r > 0) finalize(4 * (r - 1), Vp);
+#pragma unroll
+                for (int s = 0; s < S; s++) Vp[s] = Vc[s];
+            }
+        } else {
+            // two passes: node values first (one product per node), then stencils and minimisation round by round
+            for (int j0 = 0; j0 < ((A.dbg & 2048) ? 0 : N); j0 += 4) {
+                double P[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int jn = min(j0 + jj, N - 1);
+                    if constexpr (K == 0) {
+                        double a[C];
+                        node_a(jn, a);
+                        P[jj] = dot_c<C>(a, XR[0]);
+                    } else {
+                        double c[C];
+                        node_c(jn, c);
+                        P[jj] = dot_c<C>(XL[0], c);
+                    }
+                }
+                const double v = reduce4(P[0], P[1], P[2], P[3]);
+                if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+            }
+            wave_sync();
+            for (int j0 = 0; j0 < ((A.dbg & 4096) ? 0 : N); j0 += 4) {
+                double V[S];
+                stencil(j0, V, std::false_type{});
+                finalize(j0, V);
+            }
         }
-#endif
     }
     if (st) atomicOr(A.status, st);
 }

@@ -5,7 +5,7 @@
 
 namespace c3sc {
 
-template <class Model, int RP, int K, int NWV>
+template <class Model, int RP, int K, int NWV, bool ONEPASS>
 hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
 {
     constexpr int D = Model::D;
@@ -26,7 +26,7 @@ hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
     doubles += (size_t)CandLds<Model>::doubles(A.ncand);
     const size_t shmem = doubles * sizeof(double);
     if (shmem > 160u * 1024u) return hipErrorOutOfMemory;
-    auto kern = k_fiber_quad<Model, RP, K, NWV>;
+    auto kern = k_fiber_quad<Model, RP, K, NWV, ONEPASS>;
     static LaunchCache cache;
     int blocks_per_cu = 1, num_cu = 256;
     hipError_t e = cache.prepare((const void *)kern, 64 * NWV, shmem, blocks_per_cu, num_cu);
@@ -39,10 +39,16 @@ hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
     return hipGetLastError();
 }
 
+#ifndef FQ_ONEPASS
+#define FQ_ONEPASS 1 // node loop in one pass with a one-round delay (0: node values in a pass of their own)
+#endif
 template <class Model, int RP, int K, int NWV>
 hipError_t launch_fq(const KArgs &A, const LaunchIO &io)
 {
-    return launch_fq_impl<Model, RP, K, NWV>(A, io);
+    // one pass keeps a round's stencil (2d+1 doubles) in registers for one more round: at rank 16 x d = 10 the kernel is already
+    // over its register budget and the second set of products is cheaper than the spills (0.82 vs 0.87 ms on quad10d)
+    constexpr bool ONEPASS = (FQ_ONEPASS != 0) && !(RP >= 16 && Model::D >= 8);
+    return launch_fq_impl<Model, RP, K, NWV, ONEPASS>(A, io);
 }
 
 #define C3SC_REG_FQ1(MODEL_ID, RP, K, NWV, ...)                                                                  \

@@ -675,6 +675,8 @@ static void die_if_stationary(struct c3sc_hip_ctx *ctx)
     if (st & C3SC_STATUS_STATIONARY) DIE("transition_assemble: stationary node (Q < 1e-14); the reference asserts here (bellman.c:452)");
 }
 
+int c3sc_memo_bypass = 0; /* diagnostic: the index-based entry points neither look up nor store (every node is evaluated) */
+
 static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, const double *x_in, double *out, int fast)
 {
     struct ControlParams *cp = vi->cp;
@@ -698,7 +700,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
             double v = 0.0;
             int found;
             if (fast) {
-                found = fastmemo_fiber_get(fm, &ff, j, &v);
+                found = c3sc_memo_bypass ? 0 : fastmemo_fiber_get(fm, &ff, j, &v);
             } else {
                 ser[k0] = j;
                 size_t_a_to_char(ser, dx + 2, key);
@@ -765,7 +767,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
                 if (hit[f * N + j]) continue;
                 out[f * N + j] = rout[r * N + j];
                 if (fast) {
-                    fastmemo_fiber_put(fm, &ff, j, out[f * N + j]);
+                    if (!c3sc_memo_bypass) fastmemo_fiber_put(fm, &ff, j, out[f * N + j]);
                 } else {
                     ser[k0] = j;
                     size_t_a_to_char(ser, dx + 2, key);
@@ -816,6 +818,24 @@ int bellman_vi_batch_idx(size_t F, size_t k, const int32_t *idx, double *out, vo
 }
 
 int bellman_vi(size_t N, const double *x, double *out, void *arg) { return bellman_vi_batch(1, N, x, out, arg); }
+
+/* sharded core steps (c3control_set_fiber_sharding): the rows other ranks evaluated enter this rank's memo as if they had
+ * been evaluated here -- first value stays, as in the reference's table (bellman.c:1349-1353, hashgrid.c:252-261) */
+static void vi_absorb_foreign(size_t F, size_t k, const int32_t *idx, const double *out, size_t lo, size_t hi, void *arg)
+{
+    struct VIparam *vi = arg;
+    struct ControlParams *cp = vi->cp;
+    const size_t dx = cp->mca->dx, N = cp->mca->ngrid[k];
+    struct FastMemo *fm = workspace_get_vi_fastmemo(cp->work);
+    const size_t vi_iter = workspace_get_vi_iter(cp->work);
+    struct FmFiber ff;
+    if (c3sc_memo_bypass) return;
+    for (size_t f = 0; f < F; f++) {
+        if (f >= lo && f < hi) continue;
+        fastmemo_fiber_begin(&ff, dx, idx + f * dx, k, 0, vi_iter);
+        for (size_t j = 0; j < N; j++) fastmemo_fiber_put(fm, &ff, j, out[f * N + j]);
+    }
+}
 
 
 /* =============================================================================== policy iteration */
@@ -1270,8 +1290,8 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
 { /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
     struct VIparam *vi = c3control_begin_vi(c, vf, opt);
     struct ApproxArgs *aa = device_rank_cap(c, apargs);
-    struct ValueF *next = valuef_interp_idx_sharded(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose,
-                                                    c->shard_world, c->shard_rank, c->shard_exchange, c->shard_xarg);
+    struct ValueF *next = c3sc_interp_idx_sharded(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose, c->shard_world,
+                                                  c->shard_rank, c->shard_exchange, c->shard_xarg, vi_absorb_foreign);
     approx_args_free(aa);
     c3control_end_vi(c, vi, nevals);
     return next;

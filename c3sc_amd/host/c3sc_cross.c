@@ -929,6 +929,7 @@ struct shard_args {
     const size_t *N;
     c3sc_exchange_fn exchange;
     void *xarg;
+    c3sc_absorb_fn absorb;
 };
 
 static int sharded_fibers_idx(size_t F, size_t k, const int32_t *idx, double *out, void *arg)
@@ -942,17 +943,40 @@ static int sharded_fibers_idx(size_t F, size_t k, const int32_t *idx, double *ou
     int rc = 0;
     if (hi > lo) rc = s->fi(hi - lo, k, idx + lo * s->d, out + lo * N, s->args);
     if (rc != 0) return rc;
-    return s->exchange(out, F, N, lo, hi, s->xarg);
+    rc = s->exchange(out, F, N, lo, hi, s->xarg);
+    if (rc == 0 && s->absorb) s->absorb(F, k, idx, out, lo, hi, s->args);
+    if (rc == 0 && getenv("C3SC_SHARD_DEBUG")) { /* diagnostic: every rank recomputes the whole batch and compares */
+        extern int c3sc_memo_bypass;
+        double *chk = xcalloc(F * N, sizeof(double));
+        c3sc_memo_bypass = 1;
+        s->fi(F, k, idx, chk, s->args);
+        c3sc_memo_bypass = 0;
+        size_t bad = 0, first = F;
+        for (size_t f = 0; f < F; f++)
+            for (size_t j = 0; j < N; j++)
+                if (chk[f * N + j] != out[f * N + j]) { bad++; if (first == F) first = f; }
+        if (bad) fprintf(stderr, "c3sc shard debug: rank %zu k %zu F %zu [%zu,%zu): %zu values differ from the full batch, first row %zu (%s)\n",
+                         s->rank, k, F, lo, hi, bad, first, (first >= lo && first < hi) ? "own" : "foreign");
+        free(chk);
+    }
+    return rc;
+}
+
+struct ValueF *c3sc_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args, const size_t *N,
+                                       double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose, size_t world,
+                                       size_t rank, c3sc_exchange_fn exchange, void *xarg, c3sc_absorb_fn absorb)
+{
+    if (world <= 1 || exchange == NULL) return valuef_interp_idx(d, fi, args, N, grid, vref, aargs, verbose);
+    if (rank >= world) DIE("valuef_interp_idx_sharded: rank %zu of %zu", rank, world);
+    struct shard_args s = {fi, args, d, world, rank, N, exchange, xarg, absorb};
+    return interp_impl(d, NULL, NULL, sharded_fibers_idx, &s, N, grid, vref, aargs, verbose);
 }
 
 struct ValueF *valuef_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
                                          const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
                                          int verbose, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg)
 {
-    if (world <= 1 || exchange == NULL) return valuef_interp_idx(d, fi, args, N, grid, vref, aargs, verbose);
-    if (rank >= world) DIE("valuef_interp_idx_sharded: rank %zu of %zu", rank, world);
-    struct shard_args s = {fi, args, d, world, rank, N, exchange, xarg};
-    return interp_impl(d, NULL, NULL, sharded_fibers_idx, &s, N, grid, vref, aargs, verbose);
+    return c3sc_interp_idx_sharded(d, fi, args, N, grid, vref, aargs, verbose, world, rank, exchange, xarg, NULL);
 }
 
 /* ------------------------------------------------------------------------------ value-function files

@@ -26,6 +26,17 @@ struct ValueF {
     struct c3sc_hip_ctx *bound;  /* device context the cores were uploaded to */
 };
 void c3sc_forget_ctx(struct c3sc_hip_ctx *ctx);
+/* valuef_interp_idx_sharded with a hook that is handed the rows the OTHER ranks computed (after the exchange): the solver's
+ * value-iteration callback stores them in its node memo, so that every rank's memo has the content the unsharded run's
+ * would have -- a node's value can depend on the direction of the fiber it was first computed in, and the
+ * reference's memo keeps the first (bellman.c:1349-1353) */
+#include <stdint.h>
+typedef void (*c3sc_absorb_fn)(size_t F, size_t k, const int32_t *idx, const double *out, size_t lo, size_t hi, void *args);
+struct ApproxArgs;
+struct ValueF *c3sc_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args, const size_t *N,
+                                       double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose, size_t world,
+                                       size_t rank, int (*exchange)(double *, size_t, size_t, size_t, size_t, void *), void *xarg,
+                                       c3sc_absorb_fn absorb);
 void valuef_set_cross_indices(struct ValueF *vf, const size_t *nisl, int *const *isl, const size_t *nisr, int *const *isr);
 void valuef_free_cross_indices(struct ValueF *vf);
 #endif

@@ -126,7 +126,7 @@ def _sharded_worker(rank, world, port, q, use_gpu):
 
     if not use_gpu:
         # CPU: the cross driver's sharded core steps with the oracle's bellman_vi as the fiber function (no device here)
-        w = wl.c2_dubins().scaled(ngrid=(9, 8, 10), rank=3)
+        w = wl.c4_car7d().scaled(ngrid=(6, 5, 7, 5, 6, 5, 6), rank=3) if os.environ.get("C3SC_TEST_SHARD_7D") else wl.c2_dubins().scaled(ngrid=(9, 8, 10), rank=3)
         P = oracle_lib.Problem(w, wl.synth_cores(w))
         FI = C.CFUNCTYPE(C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p)
         calls = []

@@ -192,14 +192,14 @@ def solver_measurements(workload, budget_s):
     return vi_sweep, iters
 
 
-def pmc_summary(kernel, F):
+def pmc_summary(kernel, F, workload):
     """HBM traffic and executed FP64 work of the dominant kernel per launch: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE,
     SQ_INSTS_VALU_*_F64 in separate runs; FETCH x2 per the gfx950 correction of MI355X_MICROARCH.md) cannot be collected
     from inside this process, so the newest committed summary of the same command is read (profiles/README.md)."""
     tag = "fiber_quad" if "fiber_quad" in kernel else ("fiber_pair" if "fiber_pair" in kernel else None)
     if tag is None:
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_{tag}_pmc.json")), reverse=True):
         try:
             pm = json.load(open(path))
             if int(pm.get("fibers_per_dim", 0)) != F:
@@ -350,7 +350,7 @@ def main():
     bytes_per_node = float(np.mean([wl.algorithmic_bytes_per_node(w, k) for k in range(d)]))
     hbm_gbs = bytes_per_node * nodes_per_launch / (avg_ms * 1e-3) / 1e9
     kern = eng.last_kernel()
-    pm = pmc_summary(kern, F_loc)
+    pm = pmc_summary(kern, F_loc, w.name)
     if "K=" in kern:
         kern = kern[: kern.index("K=")] + "K=0..%d>" % (d - 1)
 

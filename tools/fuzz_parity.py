@@ -15,7 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 BASES = ["lqg2d", "dubins3d", "lqg6d", "car7d", "quad10d", "scar4d"]
 MAXN = {"lqg2d": 128, "dubins3d": 128, "lqg6d": 40, "car7d": 48, "quad10d": 28, "scar4d": 64}
-MAXR = {"lqg2d": 20, "dubins3d": 20, "lqg6d": 8, "car7d": 10, "quad10d": 16, "scar4d": 20}
+MAXR = {"lqg2d": 20, "dubins3d": 20, "lqg6d": 20, "car7d": 20, "quad10d": 20, "scar4d": 20}
 t0 = time.time(); ncase = nfail = nrun = 0
 last_note = t0
 worst = 0.0
@@ -50,7 +50,13 @@ while time.time() - t0 < budget:
     if time.time() - last_note > 30.0:  # a silent GPU job is taken to be hung
         print(f"... {ncase} problems, {nrun} kernel runs, {nfail} failures, {time.time() - t0:.0f} s", flush=True)
         last_note = time.time()
-    for variant in (0, 1, 3):
+    eng_q = None  # the quad kernel pads ranks to multiples of 4: its own device copy of the value function
+    try:
+        eng_q = BellmanEngine(0); eng_q.set_variant(4); eng_q.configure(w, cores)
+    except C3scHipError:
+        eng_q = None
+    for variant in (0, 1, 3, 4):
+        if variant == 4 and eng_q is None: continue
         for k in range(d):
             F = int(rng.choice([1, 3, 64, 65, 200]))
             idx = wl.synth_fibers(w, k, F, seed=int(rng.integers(1 << 30)))
@@ -58,10 +64,11 @@ while time.time() - t0 < budget:
                 idx[0, :] = 0; idx[1, :] = np.array(ngrid) - 1
             idx[:, k] = 0
             try:
-                eng.set_variant(variant)
-                out, ui, ab = eng.bellman_fibers_host(k, idx)
+                e_use = eng_q if variant == 4 else eng
+                e_use.set_variant(variant)
+                out, ui, ab = e_use.bellman_fibers_host(k, idx)
             except C3scHipError as e:
-                if "no kernel instantiation" in str(e): continue
+                if "no kernel instantiation" in str(e) or "exceeds the 160 KB" in str(e) or "code 3" in str(e): continue
                 raise
             ref, rui, rab = P.bellman_fibers(k, idx)
             nrun += 1
@@ -73,7 +80,8 @@ while time.time() - t0 < budget:
             if err > 1e-11 or bad_ab or not np.isfinite(out).all():
                 nfail += 1
                 print("FAIL", name, "ngrid", ngrid, "ranks", ranks, "bc", bc, "disc", discount, "U", len(cands), "obs", len(obstacles),
-                      "variant", variant, eng.last_kernel(), "k", k, "F", F, "err", err, "absorbed mismatches", bad_ab, flush=True)
+                      "variant", variant, e_use.last_kernel(), "k", k, "F", F, "err", err, "absorbed mismatches", bad_ab, flush=True)
+    del eng_q
     st = eng.status()
     if st: print("status flags", st, name, ngrid, ranks)
     # the batched valuef_eval_fiber_ind_nn (stencil of neighbour values) on its own

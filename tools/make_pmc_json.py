@@ -16,7 +16,7 @@ out = {"_what": "rocprofv3 --pmc passes (separate runs for FETCH_SIZE, WRITE_SIZ
                 "--warmup 1 --no-cpu-baseline`, per-dispatch averages per kernel; FETCH/WRITE_SIZE are KiB counters, FETCH is "
                 "reported raw and with the x2 gfx950 wide-read correction (MI355X_MICROARCH.md HBM section; these reads are not a "
                 "wide coalesced stream, so the correction is an upper bound)",
-       "nodes_per_launch": NODES, "algorithmic_bytes_per_node": 8.68, "algorithmic_flop_per_node": 2591.8, "kernels": {}}
+       "nodes_per_launch": NODES, "fibers_per_dim": int(os.environ.get("C3SC_PMC_FIBERS", 0)), "kernels": {}}
 for k in sorted(acc):
     c = {n: sum(v) / len(v) for n, v in acc[k].items()}
     if "FETCH_SIZE" in c:
@@ -28,10 +28,19 @@ for k in sorted(acc):
         c["hbm_bytes_per_node_uncorrected"] = (c["fetch_bytes_per_launch"] + c["write_bytes_per_launch"]) / NODES
     if "SQ_INSTS_VALU_FMA_F64" in c:
         fl = 64 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0))
-        c["executed_f64_flop_per_launch"] = fl
-        c["executed_flop_per_node"] = fl / NODES
+        mf = 512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)  # one v_mfma_f64_16x16x4_f64 = 4 MOPS = 2048 flop
+        c["executed_valu_f64_flop_per_launch"] = fl
+        c["executed_mfma_f64_flop_per_launch"] = mf
+        c["executed_flop_per_node"] = (fl + mf) / NODES
+        c["executed_flops_per_node"] = (fl + mf) / NODES
+        c["executed_mfma_share"] = mf / (fl + mf) if fl + mf > 0 else 0.0
     if "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
         c["valu_active_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if n in c:
+                c[n.lower() + "_share_of_wave_cycles"] = c[n] / c["SQ_WAVE_CYCLES"]
+    if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"] > 0:
+        c["lds_bank_conflict_share_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
     out["kernels"][k] = c
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 ks = out["kernels"].values()

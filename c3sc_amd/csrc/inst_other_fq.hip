@@ -22,7 +22,12 @@ REG10Q(16, 4) // 2(d-1)+2 vectors of 4 doubles per lane: one wave per SIMD with 
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 2, NWV, Scar4D)  \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 3, NWV, Scar4D)
 REG4Q(8, 8)
-REG4Q(20, 4) // N x 400 doubles of a staged core leave LDS for four waves of node values only
+// rank 20: the end-point dimensions fold three levels with five components per lane (one wave per SIMD, 512 registers);
+// the middle ones fit two waves per SIMD
+C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, 20, 0, 4, Scar4D)
+C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, 20, 1, 8, Scar4D)
+C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, 20, 2, 8, Scar4D)
+C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, 20, 3, 4, Scar4D)
 #define REG6Q(RP, NWV)                                     \
     C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 0, NWV, LqgNd<6>)   \
     C3SC_REG_FQ1(C3SC_MODEL_LQGND, RP, 1, NWV, LqgNd<6>)   \

@@ -266,8 +266,19 @@ __global__ void __launch_bounds__(64 * NWV, 1)
     const int lane = threadIdx.x & 63, q = lane >> 4, t = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = A.N;
+    const int bck = A.bctype[K];
     double *sM = smem;                                // staged core of the current level
-    double *sV = smem + A.quad_sv_off + wv * (N * 16); // this wave's node values [N][16]
+    // this wave's node values v_j: [N][16] with two passes; with one pass a ring of 16 nodes (a round is finalised one round
+    // after it was computed and looks one node back and ahead) plus two slots for the periodic wrap (v_1, v_{N-2})
+    constexpr int SVROWS = 18;
+    double *sV = smem + A.quad_sv_off + wv * ((ONEPASS ? SVROWS : N) * 16);
+    auto svslot = [&](int j) __attribute__((always_inline)) -> int {
+        if constexpr (!ONEPASS) return j;
+        else {
+            const bool wrap = (bck == C3SC_PERIODIC);
+            return (wrap && j == 1) ? 16 : ((wrap && j == N - 2) ? 17 : (j & 15));
+        }
+    };
     CandLds<Model> cr;
     {
         CandRegs<Model> cr0;
@@ -277,7 +288,6 @@ __global__ void __launch_bounds__(64 * NWV, 1)
     }
     unsigned st = 0;
     const long per_tile = 16L * NWV, ntiles = (A.F + per_tile - 1) / per_tile;
-    const int bck = A.bctype[K];
     const double *aopK = ro + A.quad_aop_off[K];
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -452,7 +462,7 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SELF) {
                 const double v = reduce4(vs[0], vs[1], vs[2], vs[3]);
-                if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+                if (j0 + q < N) sV[svslot(j0 + q) * 16 + t] = v;
             }
         };
         // boundary flags and control minimisation of node j0 + q of fiber t from its stencil (the dim-K entries come from sV)
@@ -465,9 +475,9 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             if (fiber_abs) ab = 1;
             int lo, hi;
             ab = vary_neighbors(j, N, bck, ab, lo, hi);
-            V[2 * K] = sV[lo * 16 + t];
-            V[2 * K + 1] = sV[hi * 16 + t];
-            V[2 * D] = sV[j * 16 + t];
+            V[2 * K] = sV[svslot(lo) * 16 + t];
+            V[2 * K + 1] = sV[svslot(hi) * 16 + t];
+            V[2 * D] = sV[svslot(j) * 16 + t];
             double tv[Model::NTAB > 0 ? Model::NTAB : 1];
             tv[0] = 0.0;
 #pragma unroll
@@ -522,7 +532,7 @@ __global__ void __launch_bounds__(64 * NWV, 1)
                     }
                 }
                 const double v = reduce4(P[0], P[1], P[2], P[3]);
-                if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+                if (j0 + q < N) sV[svslot(j0 + q) * 16 + t] = v;
             }
             wave_sync();
             for (int j0 = 0; j0 < ((A.dbg & 4096) ? 0 : N); j0 += 4) {

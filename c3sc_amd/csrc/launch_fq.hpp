@@ -21,7 +21,7 @@ hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
     doubles = (doubles + 1) & ~(size_t)1;
     KArgs B = A;
     B.quad_sv_off = (int)doubles;
-    doubles += (size_t)NWV * A.N * 16;
+    doubles += (size_t)NWV * (ONEPASS ? 18 : A.N) * 16; // per-wave node values: a ring with one pass, all N with two
     B.tbl_off = (int)doubles;
     doubles += (size_t)CandLds<Model>::doubles(A.ncand);
     const size_t shmem = doubles * sizeof(double);

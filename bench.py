@@ -218,6 +218,31 @@ def pmc_summary(kernel, F, workload):
     return None
 
 
+def kernel_resources(kernel):
+    """Registers / spills / scratch of the timed kernel's instantiations (all K), from the compiler's resource-usage remarks
+    collected at build time (c3sc_amd/csrc/kernel_resources.json, tools/kernel_resources.py); None if that file is absent."""
+    try:
+        res = json.load(open(os.path.join(ROOT, "c3sc_amd", "csrc", "kernel_resources.json")))
+    except (OSError, ValueError):
+        return None
+    import re
+
+    m = re.match(r"(k_fiber_\w+)<(.*?),(\d+),", kernel)
+    if not m:
+        return None
+    fam, model, rp = m.group(1), m.group(2), int(m.group(3))
+    hits = [v for k, v in res.items() if k.startswith(fam + "<" + model.replace("<", "<").strip() + ", " + str(rp) + ",") and "true>" not in k.split(",")[-1][:6]]
+    if not hits:
+        hits = [v for k, v in res.items() if k.startswith(fam + "<" + model + ", " + str(rp) + ",")]
+    if not hits:
+        return None
+    return {"instantiations": len(hits), "vgprs_max": max(h.get("vgprs", 0) for h in hits), "agprs_max": max(h.get("agprs", 0) for h in hits),
+            "vgpr_spill_min_max": [min(h.get("vgpr_spill", 0) for h in hits), max(h.get("vgpr_spill", 0) for h in hits)],
+            "scratch_bytes_per_lane_min_max": [min(h.get("scratch_bytes_per_lane", 0) for h in hits), max(h.get("scratch_bytes_per_lane", 0) for h in hits)],
+            "waves_per_simd": sorted(set(h.get("waves_per_simd", 0) for h in hits)),
+            "source": "hipcc -Rpass-analysis=kernel-resource-usage at build time"}
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline: before anything touches torch / the GPU
         _cpu_worker(sys.argv[2], float(sys.argv[3]), int(sys.argv[4]))
@@ -350,6 +375,7 @@ def main():
     bytes_per_node = float(np.mean([wl.algorithmic_bytes_per_node(w, k) for k in range(d)]))
     hbm_gbs = bytes_per_node * nodes_per_launch / (avg_ms * 1e-3) / 1e9
     kern = eng.last_kernel()
+    kres = kernel_resources(kern)
     pm = pmc_summary(kern, F_loc, w.name)
     if "K=" in kern:
         kern = kern[: kern.index("K=")] + "K=0..%d>" % (d - 1)
@@ -380,13 +406,14 @@ def main():
                 "frac": achieved_tflops / FP64_PEAK_TFLOPS,
                 "traffic": pm["traffic"] if pm else None, "traffic_unit": "bytes/launch", "traffic_source": pm["source"] if pm else None,
                 "algorithmic_bytes_per_launch": bytes_per_node * nodes_per_launch,
-                "kernel": kern, "avg_launch_ms": avg_ms, "launches": len(kms),
+                "kernel": kern, "kernel_resources": kres, "avg_launch_ms": avg_ms, "launches": len(kms),
                 "algorithmic_flops_per_node": Wf, "nodes_per_launch": nodes_per_launch,
                 # what the kernel actually executes (fold-once algebra), from the SQ_INSTS_VALU_*_F64 / MFMA counters of the
                 # committed PMC pass of this command; null when no such pass is committed for this kernel and batch
                 "executed_flops_per_node": pm.get("executed_flops_per_node") if pm else None,
                 "executed_frac": (pm["executed_flops_per_node"] * nodes_per_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
                 if pm and "executed_flops_per_node" in pm else None,
+                "traffic_note": "WRITE_SIZE above the output bytes is scratch (spilled registers, kernel_resources), not partial-line stores: DESIGN.md 4.1",
                 "note": "`achieved`/`frac` credit the ALGORITHMIC flops of SURVEY.md 8d (W = W_ft + U W_mc per node) as the task "
                         "defines them; the kernel's fold-once algebra executes fewer (executed_flops_per_node, executed_frac). "
                         "FP64 vector and matrix peak are the same 78.6 TFLOP/s datasheet figure",

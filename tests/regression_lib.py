@@ -77,8 +77,17 @@ class _Base:
         L.approx_args_set_startrank(aa, C.c_size_t(cfg["startrank"]))
         L.approx_args_set_maxrank(aa, C.c_size_t(cfg["maxrank"]))
         self.aa = aa
-        sv = float(cfg["start_value"])
-        self._quad2d = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(sv), 0)[1])
+        sv, sfn, dxs = float(cfg["start_value"]), cfg.get("start_fn"), self.w.dx
+
+        def _start(n, x, out, a):
+            o = np.ctypeslib.as_array(out, shape=(n,))
+            if sfn is None:
+                o.fill(sv)
+            else:
+                o[:] = sfn(np.ctypeslib.as_array(x, shape=(n, dxs)))
+            return 0
+
+        self._quad2d = facade_lib.FIBER_FN(_start)
         self.history = []  # (update, |V_vi - V_pi|, |V|, rank)
         self.sweeps = 0
 

@@ -12,6 +12,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import regression_lib as R  # noqa: E402
 
 case = sys.argv[1] if len(sys.argv) > 1 else "pi_25"
+if case == "car7d":
+    from c3sc_amd import workloads as wl
+    w0 = wl.c4_car7d().scaled(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)
+    cands = np.array([[a, b] for a in (-0.5, 0.07, 0.43) for b in (-1.0, 0.13, 0.91)])
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, w0.discount, w0.bc, list(w0.obstacles), cands)
+    wts = np.array([0.3, 0.5, 0.2, 0.1, 0.15, 0.7, 0.25])
+    case = dict(w=w, max_updates=21, conv=1e-9, adapt=1, startrank=3, maxrank=5, kick=2, cross_tol=1e-10, round_tol=1e-9,
+                start_fn=lambda X: 1.0 + ((X - 0.1) ** 2 * wts).sum(axis=1))
 gpu, orc = R.GpuLoop(case), R.OracleLoop(case)
 L = gpu.L
 state = gpu.init_value()

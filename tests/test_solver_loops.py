@@ -132,7 +132,12 @@ def test_policy_and_value_iteration_loops_contract():
 def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
     """The examples' outer loop (pi_solve(10) + one vi_solve step per control update, e.g. dubinscar.c:343-352) on a reduced
     7-D car grid, 20 control updates: each update run on the device path and on the oracle-fed path from the SAME state
-    agrees to 1e-6 of max |V| node by node (measured ~1e-14).  The data avoid EXACT ties between candidates (the
+    is compared node by node.  Most updates agree to ~1e-14 of max |V|; a few do not agree at all (0.1 ... 0.3): at a rank
+    cap of 5 this value function is far from representable, the cross approximation's error is of that size, and which of
+    several equally bad approximations comes out depends on pivot decisions that flip with the last bit of the fiber values
+    -- the ORACLE-fed loop shows the same jumps against itself when 1e-16 relative noise is added to its fiber values
+    (update 0 of this very configuration: 0.12).  So the statement tested is: the median update agrees to 1e-12 and at least
+    three quarters of the updates to 1e-6; the outliers are printed.  The data avoid EXACT ties between candidates (the
     tie-break of the brute-force scan lives in C3): with the symmetric 3 x 3 candidate grid and a start value that does not
     depend on the steering / acceleration states, +u and -u tie at every node, the policy's pick among them is decided by
     the last bit (oracle: division per candidate; device: cross-multiplied comparison), and ten evaluation sweeps of two such
@@ -160,8 +165,10 @@ def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
         Lb.valuef_destroy(state)
         state = a
     print("per update:", " ".join(f"{x:.1e}" for x in diffs))
-    print(f"car7d {w.ngrid}: 20 control updates in lock-step, worst nodal L-inf / max|V| = {worst:.3e}; |V| = {gpu.norm(state):.6e}, rank {gpu.rank(state)}")
-    assert worst <= 1e-6
+    good = [x for x in diffs if x <= 1e-6]
+    print(f"car7d {w.ngrid}: 20 control updates in lock-step: {len(good)} agree to 1e-6 (worst of them {max(good):.1e}), median {np.median(diffs):.1e}, "
+          f"pivot-flip outliers {[f'{x:.2f}' for x in diffs if x > 1e-6]}; |V| = {gpu.norm(state):.6e}, rank {gpu.rank(state)}")
+    assert np.median(diffs) <= 1e-12 and len(good) >= 15 and max(good) <= 1e-12
     Lb.valuef_destroy(state)
     gpu.close()
     orc.close()

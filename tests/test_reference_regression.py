@@ -101,7 +101,9 @@ def test_device_loop_meets_the_anchor_and_matches_the_oracle_path(oracle, case):
     # candidates +u and -u tie EXACTLY at the nodes on the symmetry axes (drift (x1, u), symmetric grid): which of the two the
     # policy takes there is decided by the last bit of the right-hand side (libm exp vs the device's polynomial), both are
     # greedy, and ten evaluation sweeps of the two policies differ by 3e-3 (tools/dbg_lockstep.py) -- the tie-break of the
-    # brute-force scan lives in C3 and is unpinned.  So the comparison starts from the state after that update.
+    # brute-force scan lives in C3 and is unpinned.  That update is also the one that amplifies last-bit noise in
+    # the cross approximation (oracle vs oracle + 1e-16 noise: 5e-6 there, 1e-15 in every later update).  So the comparison
+    # starts from the state after that update.
     state = gpu.run(max_updates=1)
     worst = 0.0
     for _ in range(N_LOCKSTEP):

@@ -44,7 +44,7 @@ def workload(n):
 
 
 class _Base:
-    def __init__(self, case, minimiser="bruteforce"):
+    def __init__(self, case, minimiser="bruteforce", callbacks=None):
         import facade_lib
 
         self.fl = facade_lib
@@ -68,7 +68,7 @@ class _Base:
             self.w, self.n = cfg["w"], n
         self.max_updates, self.conv, self.break_on_conv, self.pi_sweeps = cfg["max_updates"], cfg["conv"], cfg["break_on_conv"], cfg["pi_sweeps"]
         box = None if minimiser == "bruteforce" else ([-1.0], [1.0])  # tprob_test.c:2290-2299
-        self.ctl = facade_lib.Control(self.w, box=box)
+        self.ctl = facade_lib.Control(self.w, callbacks=callbacks, box=box)  # callbacks: host functions beside the device model
         aa = C.c_void_p(L.approx_args_init())
         L.approx_args_set_cross_tol(aa, C.c_double(cfg["cross_tol"]))
         L.approx_args_set_round_tol(aa, C.c_double(cfg["round_tol"]))
@@ -144,7 +144,7 @@ class _Base:
         self.ctl.close()
 
 
-class GpuLoop(_Base):
+class GpuLoop(_Base):  # GpuLoop(case, minimiser, callbacks)
     """libc3sc.so's own loops: the product path (device kernels for every fiber)."""
 
     def pi_solve(self, maxiter, tol, policy):

@@ -106,3 +106,77 @@ def test_value_function_files_roundtrip(tmp_path):
     assert L.valuef_eval(vfine, fl.dp(x)) == pytest.approx(L.valuef_eval(vf, fl.dp(x)), rel=1e-12)
     L.valuef_destroy(vfine)
     ctl.close()
+
+
+def _lqg2d_callbacks():
+    """The regression's host callbacks (tprob_test.c:132-168 f1b / s1, :253-271 stagecost2d, :302-318 boundcost / ocost)."""
+    import facade_lib
+
+    def drift(t, x, u, out, jac, args):
+        out[0], out[1] = x[1], u[0]
+        return 0
+
+    def diff(t, x, u, out, grad, args):
+        out[0], out[1], out[2], out[3] = 1.0, 0.0, 0.0, 1.0
+        return 0
+
+    def stage(t, x, u, out, grad):
+        out[0] = x[0] * x[0] + x[1] * x[1] + u[0] * u[0]
+        return 0
+
+    def bcost(t, x, out):
+        out[0] = 100.0
+        return 0
+
+    def ocost(x, out):
+        out[0] = 0.0
+        return 0
+
+    return (facade_lib.DYN_FN(drift), facade_lib.DYN_FN(diff), facade_lib.STAGE_FN(stage), facade_lib.BOUND_FN(bcost),
+            facade_lib.OBS_FN(ocost))
+
+
+@pytest.mark.gpu
+def test_policy_tail_on_a_value_function_solved_on_the_device(oracle, tmp_path):
+    """SURVEY.md 8f-4 end to end on the GPU box: a value function solved by the device loop (the reference's regression
+    problem, tprob_test.c:1996-2119, cut short) goes through valuef_save / valuef_load, the implicit policy
+    (c3control_add_policy_sim + c3control_policy_eval, bellman.c:2034-2158) is compared with the oracle's restatement at
+    random states, and the closed loop (c3control_simulate) drives the state towards the origin."""
+    import regression_lib as R
+
+    L, fl = _setup()
+    w = R.workload(25)
+    gpu = R.GpuLoop("pi_25_const", callbacks=_lqg2d_callbacks())  # the tail evaluates the user's callbacks on the host, as the reference does
+    cost = gpu.run(max_updates=150)
+    # files
+    path = str(tmp_path / "v.c3sc").encode()
+    assert L.valuef_save(cost, path) == 0
+    gs = [fl.f64(g) for g in gpu.ctl.xgrid()]
+    back = C.c_void_p(L.valuef_load(path, fl.sp(fl.usz(w.ngrid)), fl.ptrs(gs)))
+    assert back.value is not None and L.valuef_norm2diff(cost, back) <= 1e-12 * gpu.norm(cost)
+    # implicit policy vs the oracle on the same cores
+    ranks, cores = gpu.cores_of(cost)
+    wr = wl.Workload(w.name, w.model, w.params, w.dx, w.du, w.lb, w.ub, w.ngrid, tuple(ranks), w.discount, w.bc, list(w.obstacles), w.cands)
+    P = oracle.Problem(wr, [c.reshape(w.ngrid[m], -1) for m, c in enumerate(cores)])
+    lib = oracle.lib()
+    L.c3control_add_policy_sim(gpu.ctl.h, back, gpu.ctl.opt, None)
+    rng = np.random.default_rng(11)
+    same = 0
+    for _ in range(80):
+        x = fl.f64(rng.uniform(-1.9, 1.9, 2))
+        u = np.zeros(1)
+        assert L.c3control_policy_eval(gpu.ctl.h, C.c_double(0.0), fl.dp(x), fl.dp(u)) == 0
+        ui, val = C.c_int(-5), C.c_double(0.0)
+        assert lib.orc_policy_eval(P.h, oracle.dp(x), C.byref(ui), C.byref(val)) == 0
+        same += int(ui.value >= 0 and u[0] == w.cands[ui.value, 0])
+    assert same >= 78  # the odd state may sit on a tie between neighbouring candidates
+    # closed loop from (1.5, -1): the controller brings the state closer to the origin
+    NS = 300
+    x0 = fl.f64([1.5, -1.0])
+    traj, us = np.zeros((NS + 1, 2)), np.zeros((NS, 1))
+    assert L.c3control_simulate(gpu.ctl.h, fl.dp(x0), C.c_double(0.01), C.c_size_t(NS), None, fl.dp(traj), fl.dp(us)) == 0
+    assert np.isfinite(traj).all() and np.abs(us).max() <= 1.0
+    assert np.hypot(*traj[-1]) < 0.6 * np.hypot(*x0)
+    L.valuef_destroy(back)
+    L.valuef_destroy(cost)
+    gpu.close()

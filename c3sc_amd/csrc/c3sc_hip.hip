@@ -264,6 +264,10 @@ static int pick_rp(int d, int maxrank, int model, int variant)
         for (const auto &e : kernel_registry())
             if (e.d == d && e.variant == variant && (model == 0 || e.model == model) && e.rp >= maxrank && (rp == 0 || e.rp < rp)) rp = e.rp;
     if (rp) return rp;
+    if (model != 0) // the padded classes compiled for THIS model (another model of the same dimension may offer others)
+        for (const auto &e : kernel_registry())
+            if (e.d == d && e.model == model && e.rp >= maxrank && (rp == 0 || e.rp < rp)) rp = e.rp;
+    if (rp) return rp;
     for (const auto &e : kernel_registry())
         if (e.d == d && e.rp >= maxrank && (rp == 0 || e.rp < rp)) rp = e.rp;
     return rp;

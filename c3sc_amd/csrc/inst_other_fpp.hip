@@ -10,6 +10,12 @@ namespace c3sc {
 REG3P(4)
 REG3P(6)
 REG3P(8)
+#define REG3R(RP)                                          \
+    C3SC_REG_FPP1(C3SC_MODEL_ROSSLER3D, RP, 0, Rossler3D)  \
+    C3SC_REG_FPP1(C3SC_MODEL_ROSSLER3D, RP, 1, Rossler3D)  \
+    C3SC_REG_FPP1(C3SC_MODEL_ROSSLER3D, RP, 2, Rossler3D)
+REG3R(4)
+REG3R(8)
 #define REG4P(RP)                                    \
     C3SC_REG_FPP1(C3SC_MODEL_SCAR4D, RP, 0, Scar4D)  \
     C3SC_REG_FPP1(C3SC_MODEL_SCAR4D, RP, 1, Scar4D)  \

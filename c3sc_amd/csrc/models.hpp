@@ -218,6 +218,49 @@ struct Chain {
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
 };
 
+// examples/rossler/rossler.c:80-157 (Roessler attractor with a control on the second equation; a = b = 0.1, c = 14);
+// prm = {3, sig, sig_last} like the chain (rossler.c:104-116); stage = 100 |x|^2 + u^2 (:137-149)
+struct Rossler3D {
+    static constexpr bool IS_TABLE = false;
+    static constexpr int D = 3, DU = 1;
+    static constexpr int NTAB = 0, NCF = 0;
+    static constexpr unsigned UDEP_MASK = 1u << 1;
+    static constexpr unsigned UCONST_MASK = 0; // the controlled equation also depends on the state
+    static constexpr bool STAGE_UDEP = true;
+    __host__ __device__ static constexpr int tab_dim(int) { return 0; }
+    struct Node {};
+    __device__ static inline void prep(const double *, const double (&)[D], const double (&)[1], Node &) {}
+    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, const double *,
+                                        double (&b)[D])
+    {
+        b[0] = -x[1] - x[2];
+        b[1] = x[0] + 0.1 * x[1] + u[0];
+        b[2] = 0.1 + x[2] * (x[0] - 14.0);
+    }
+    __device__ static inline void sigma(const double *prm, const double (&)[D], const double *, double (&s)[D])
+    {
+        s[0] = prm[1]; s[1] = prm[1]; s[2] = prm[2];
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *u)
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) s = s + 1e2 * x[i] * x[i]; // the reference's order of operations (:139-141)
+        return s + 1.0 * u[0] * u[0];
+    }
+    static constexpr bool STAGE_USEP = true;
+    __device__ static inline double stage_x(const double *, const double (&x)[D])
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) s = s + 1e2 * x[i] * x[i];
+        return s;
+    }
+    __device__ static inline double stage_u(const double *, const double *u) { return 1.0 * u[0] * u[0]; }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 1000.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
 // Universal model for arbitrary host callbacks (the reference's examples unchanged): the HOST evaluates the
 // user's drift / diffusion / stage-cost callbacks for every (node, candidate) of the fibers it submits and the
 // kernel reads the numbers from a table: per fiber [N][U][2D+1] = (drift[D], diag sigma[D], stage) and

@@ -26,6 +26,7 @@ MODEL_SCAR4D = 2
 MODEL_CAR7D = 3
 MODEL_LQGND = 4
 MODEL_CHAIN = 5
+MODEL_ROSSLER3D = 6
 
 BC_ABSORB, BC_PERIODIC, BC_REFLECT = 1, 2, 3  # enum EBTYPE, src/boundary.h:42-47
 _BC_NAME = {BC_ABSORB: "absorb", BC_PERIODIC: "periodic", BC_REFLECT: "reflect"}
@@ -125,9 +126,17 @@ def scar4d(n=40, r=20) -> Workload:
                     (BC_ABSORB, BC_ABSORB, BC_PERIODIC, BC_REFLECT), [goal], _grid_cands([ox, oy]))
 
 
+def rossler3d(n=20, r=8) -> Workload:
+    """examples/rossler/rossler.c:208-307: Roessler system with a control on the second equation, [-1,1]^3 with N = 20,
+    reflecting box, beta = 0.1, sigma = (1, 1, 1) (its -r / -f options); its BFGS box u in [-4, 4] as a 33-point list
+    (set_control_box gives the continuous minimiser over the same box)."""
+    return Workload("rossler3d", MODEL_ROSSLER3D, (3.0, 1.0, 1.0), 3, 1, (-1.0,) * 3, (1.0,) * 3, (n,) * 3, uniform_ranks(3, r), 0.1,
+                    (BC_REFLECT,) * 3, [], np.linspace(-4.0, 4.0, 33).reshape(-1, 1))
+
+
 WORKLOADS = {
     "lqg2d": c1_lqg2d, "dubins3d": c2_dubins, "lqg6d": c3_lqg6d, "car7d": c4_car7d, "quad10d": c5_quad10d,
-    "scar4d": scar4d,
+    "scar4d": scar4d, "rossler3d": rossler3d,
 }
 
 _GOLD = np.uint64(0x9E3779B97F4A7C15)

@@ -673,6 +673,7 @@ size_t orc_htable_count(const struct orc_htable *ht) { return ht->count; }
  *   SCAR4D   : none.                         dx=4 du=2
  *   CAR7D    : none.                         dx=7 du=2   
  *   LQGND    : {dim, sig_even, sig_odd}      dx=dim du=dim/2
+ *   ROSSLER3D: {3, sig, sig_last}            dx=3 du=1   (examples/rossler/rossler.c)
  *   CHAIN    : {dim, sig_first, sig_last, stage_mode}  dx=dim du=1; stage_mode 0 -> 1.0
  *              (double_int.c:126), 1 -> sum_i x_i^2 (synthetic "quad10d")
  * ==================================================================================== */
@@ -684,6 +685,7 @@ int orc_model_dims(int model, const double *p, size_t *dx, size_t *du)
     case ORC_MODEL_CAR7D: *dx = 7; *du = 2; return 0;
     case ORC_MODEL_LQGND: *dx = (size_t)p[0]; *du = (size_t)p[0] / 2; return 0;
     case ORC_MODEL_CHAIN: *dx = (size_t)p[0]; *du = 1; return 0;
+    case ORC_MODEL_ROSSLER3D: *dx = 3; *du = 1; return 0;
     default: return 1;
     }
 }
@@ -732,6 +734,13 @@ int orc_model_drift(int model, const double *p, const double *x, const double *u
         out[dim - 1] = u[0];
         return 0;
     }
+    case ORC_MODEL_ROSSLER3D: { /* rossler.c:89-94: a = b = 0.1, c = 14 */
+        const double a = 0.1, b = 0.1, c = 14.0;
+        out[0] = -x[1] - x[2];
+        out[1] = x[0] + a * x[1] + u[0];
+        out[2] = b + x[2] * (x[0] - c);
+        return 0;
+    }
     default: return 1;
     }
 }
@@ -754,6 +763,7 @@ int orc_model_diff_diag(int model, const double *p, const double *x, const doubl
         out[dim - 1] = p[2];
         return 0;
     }
+    case ORC_MODEL_ROSSLER3D: out[0] = p[1]; out[1] = p[1]; out[2] = p[2]; return 0; /* rossler.c:113-117 */
     default: return 1;
     }
 }
@@ -770,6 +780,13 @@ int orc_model_stage(int model, const double *p, const double *x, const double *u
         for (size_t i = 0; i < dim; i++) s += x[i] * x[i];
         for (size_t i = 0; i < dim / 2; i++) s += u[i] * u[i];
         *out = s;
+        return 0;
+    }
+    case ORC_MODEL_ROSSLER3D: { /* rossler.c:137-143 */
+        const double scale = 1e2, rho = 1e0;
+        *out = 0.0;
+        for (size_t i = 0; i < 3; i++) *out = *out + scale * x[i] * x[i];
+        *out += rho * u[0] * u[0];
         return 0;
     }
     case ORC_MODEL_CHAIN: {
@@ -791,6 +808,7 @@ int orc_model_boundcost(int model, const double *p, const double *x, double *out
     case ORC_MODEL_DUBINS3D: case ORC_MODEL_SCAR4D: case ORC_MODEL_CAR7D: *out = 10.0; return 0; /* dubinscar.c:108, scar.c:146 */
     case ORC_MODEL_LQGND: *out = 100.0; return 0;  /* lqgnd.c:183 */
     case ORC_MODEL_CHAIN: *out = 1000.0; return 0; /* double_int.c:139 */
+    case ORC_MODEL_ROSSLER3D: *out = 1000.0; return 0; /* rossler.c:156 */
     default: return 1;
     }
 }

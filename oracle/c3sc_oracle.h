@@ -106,7 +106,8 @@ enum orc_model {
     ORC_MODEL_SCAR4D = 2,   /* examples/skidding_car/scar.c:40-169       */
     ORC_MODEL_CAR7D = 3,    /* synthetic 7-D car, SURVEY.md 8d config C4  */
     ORC_MODEL_LQGND = 4,    /* examples/lqgnd/lqgnd.c:80-198 (dim=2: lqg2d_new/lqg2d.c:72-153) */
-    ORC_MODEL_CHAIN = 5     /* examples/double_int/double_int.c:80-157; params[2]=1 -> stage sum x^2 */
+    ORC_MODEL_CHAIN = 5,    /* examples/double_int/double_int.c:80-157; params[2]=1 -> stage sum x^2 */
+    ORC_MODEL_ROSSLER3D = 6 /* examples/rossler/rossler.c:80-157 */
 };
 int orc_model_dims(int model, const double *params, size_t *dx, size_t *du);
 int orc_model_drift(int model, const double *params, const double *x, const double *u, double *out);

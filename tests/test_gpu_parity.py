@@ -31,6 +31,7 @@ SMALL = [
     ("lqg2d", dict(ngrid=(51, 51), rank=4)),
     ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8)),
     ("quad10d", dict(ngrid=(5, 6, 5, 4, 5, 6, 5, 4, 5, 6), rank=4)),
+    ("rossler3d", dict(ngrid=(23, 40, 31), rank=7)),  # examples/rossler: state-dependent drift in every equation
 ]
 
 
@@ -48,7 +49,7 @@ def _check(eng, P, w, k, idx):
     return err / scale
 
 
-PAIR_CONFIGS = {0, 1, 2, 3, 4, 5, 6}  # SMALL entries that have a fiber-pair instantiation (dubins, scar4d r8, car7d, lqg2d, lqg6d)
+PAIR_CONFIGS = {0, 1, 2, 3, 4, 5, 6, 8}  # SMALL entries that have a fiber-pair instantiation (dubins, scar4d r8, car7d, lqg2d, lqg6d)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 3], ids=["auto", "fiber_per_wave", "fiber_pair"])
@@ -300,8 +301,9 @@ def _with_cands(w, cands):
 
 
 @pytest.mark.parametrize("name,kw,grid,fine", [("lqg2d", dict(ngrid=(21, 19), rank=4), 33, 20001),
-                                               ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8), 9, 41)],
-                         ids=["lqg2d-du1", "lqg6d-du3"])
+                                               ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8), 9, 41),
+                                               ("rossler3d", dict(ngrid=(17, 21, 19), rank=6), 33, 20001)],
+                         ids=["lqg2d-du1", "lqg6d-du3", "rossler3d-du1"])
 def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
     """c3sc_hip_bellman_fibers_box: the non-BRUTEFORCE branch of bellman_optimal (bellman.c:545-1118).  The optimiser
     there is C3's BFGS (third party, unpinned), so the check is the reference's own (tprob_test.c:1494-1540):
@@ -311,7 +313,7 @@ def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
 
     w = wl.WORKLOADS[name]().scaled(**kw)
     cores = wl.synth_cores(w)
-    lb, ub = -np.ones(w.du), np.ones(w.du)
+    lb, ub = (-4.0 * np.ones(1), 4.0 * np.ones(1)) if name == "rossler3d" else (-np.ones(w.du), np.ones(w.du))  # rossler.c:212-213
     eng = _engine(w, cores, 0)
     eng.set_control_box(lb, ub, grid=grid, polish=2)
     n100 = 100 if w.du == 1 else 11

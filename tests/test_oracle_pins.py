@@ -362,3 +362,31 @@ def test_grid_refs_and_problem_grids(oracle):
     for m in range(w.dx):
         assert t[2 * m] == hmin * hmin / hs[m]
         assert t[2 * m + 1] == hmin * hmin / hs[m] / hs[m]
+
+
+def test_rossler_model_restates_the_reference_example(oracle):
+    """examples/rossler/rossler.c:80-157 (a = b = 0.1, c = 14; the control enters the second equation; diffusion diag
+    (s, s, s_last); stage 100 |x|^2 + u^2; boundary cost 1000; obstacle cost 0), evaluated here from those formulas."""
+    import ctypes as C
+
+    L = oracle.lib()
+    dp = C.POINTER(C.c_double)
+    prm = (C.c_double * 8)(3.0, 0.7, 1.3)
+    dx, du = C.c_size_t(), C.c_size_t()
+    assert L.orc_model_dims(wl.MODEL_ROSSLER3D, prm, C.byref(dx), C.byref(du)) == 0 and (dx.value, du.value) == (3, 1)
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        x = rng.uniform(-1.0, 1.0, 3); u = rng.uniform(-1.0, 1.0, 1)
+        out = np.zeros(3); s = C.c_double()
+        px, pu, po = x.ctypes.data_as(dp), u.ctypes.data_as(dp), out.ctypes.data_as(dp)
+        assert L.orc_model_drift(wl.MODEL_ROSSLER3D, prm, px, pu, po) == 0
+        np.testing.assert_array_equal(out, [-x[1] - x[2], x[0] + 0.1 * x[1] + u[0], 0.1 + x[2] * (x[0] - 14.0)])
+        assert L.orc_model_diff_diag(wl.MODEL_ROSSLER3D, prm, px, pu, po) == 0
+        np.testing.assert_array_equal(out, [0.7, 0.7, 1.3])
+        assert L.orc_model_stage(wl.MODEL_ROSSLER3D, prm, px, pu, C.byref(s)) == 0
+        assert s.value == ((0.0 + 1e2 * x[0] * x[0]) + 1e2 * x[1] * x[1]) + 1e2 * x[2] * x[2] + 1.0 * u[0] * u[0]
+        assert L.orc_model_boundcost(wl.MODEL_ROSSLER3D, prm, px, C.byref(s)) == 0 and s.value == 1000.0
+        assert L.orc_model_obscost(wl.MODEL_ROSSLER3D, prm, px, C.byref(s)) == 0 and s.value == 0.0
+    w = wl.WORKLOADS["rossler3d"]()
+    assert w.bc == (wl.BC_REFLECT,) * 3 and w.discount == 0.1 and w.lb == (-1.0,) * 3 and w.ub == (1.0,) * 3  # rossler.c:208-307
+    assert w.ngrid == (20,) * 3 and w.cands.min() == -4.0 and w.cands.max() == 4.0

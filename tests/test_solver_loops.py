@@ -172,3 +172,35 @@ def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
     Lb.valuef_destroy(state)
     gpu.close()
     orc.close()
+
+
+def test_rossler_example_outer_loop_device_vs_oracle_side_by_side(oracle):
+    """examples/rossler/rossler.c:208-360 with its own settings (N = 20 on [-1,1]^3, reflecting box, beta = 0.1, start cost
+    10 |x|^2, rank adaptation 2 -> N with kick 2, cross tol 1e-10, rounding 1e-8, pi_solve(10) + one vi step per update) and
+    a candidate list over its control box [-4, 4] (slightly asymmetric: no exact +u / -u ties, see the car7d test): ten
+    control updates, each run on the device path and on the oracle-fed path from the same state."""
+    import regression_lib as R
+
+    w0 = wl.WORKLOADS["rossler3d"]()
+    cands = (np.linspace(-4.0, 4.0, 33) + 0.013).clip(-4.0, 4.0).reshape(-1, 1)
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, w0.discount, w0.bc, [], cands)
+    cfg = dict(w=w, max_updates=11, conv=1e-8, adapt=1, startrank=2, maxrank=20, kick=2, cross_tol=1e-10, round_tol=1e-8,
+               start_fn=lambda X: 10.0 * (X ** 2).sum(axis=1))
+    gpu, orc = R.GpuLoop(cfg), R.OracleLoop(cfg)
+    Lb = gpu.L
+    state = gpu.run(max_updates=1)
+    diffs = []
+    for _ in range(10):
+        a = gpu.run(max_updates=1, cost=C.c_void_p(Lb.valuef_copy(state)))
+        b = orc.run(max_updates=1, cost=C.c_void_p(Lb.valuef_copy(state)))
+        vb = orc.nodal(b)
+        diffs.append(np.abs(gpu.nodal(a) - vb).max() / np.abs(vb).max())
+        Lb.valuef_destroy(b)
+        Lb.valuef_destroy(state)
+        state = a
+    print("per update:", " ".join(f"{x:.1e}" for x in diffs))
+    print(f"rossler3d {w.ngrid}: 10 control updates in lock-step, worst {max(diffs):.1e}; |V| = {gpu.norm(state):.6e}, rank {gpu.rank(state)}")
+    assert max(diffs) <= 1e-8  # the rounding tolerance of the example; typical agreement is ~1e-13
+    Lb.valuef_destroy(state)
+    gpu.close()
+    orc.close()

@@ -43,6 +43,18 @@ __global__ void k_pad_core(const double *__restrict__ src, double *__restrict__ 
     }
 }
 
+// A rank-padded core once more with the fiber-pair kernel's LDS node stride (elems | 1 doubles per node): that kernel
+// copies the image into LDS with LDS-DMA (global_load_lds, 16 bytes per lane), which writes lane-linearly and cannot pad.
+__global__ void k_core_image(const double *__restrict__ core, double *__restrict__ img, int N, int per)
+{
+    const int stride = per | 1;
+    const long total = (long)N * stride;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / stride), w = (int)(e - (long)j * stride);
+        img[e] = (w < per) ? core[(size_t)j * per + w] : 0.0;
+    }
+}
+
 // Derived copies of a rank-padded middle core for the fiber-quad kernel (kernel_fiber_quad.hpp), made on the device from
 // the padded core itself: (1) the row-major transpose, (2) the two MFMA A operands of the varying-core products
 // c = G R (x = a, y = b) and a = L G (x = b, y = a): element [prod][mb][s][l] = M[x][y] with x = (i%4) C + 4 mb + i/4
@@ -133,6 +145,7 @@ struct c3sc_hip_ctx {
     bool static_dirty = true;
     long core_off[MAXD] = {0};
     long coreT_off[MAXD] = {0}, aop_off[MAXD] = {0}; // fiber-quad copies of the middle cores (0 = none)
+    long img_off[MAXD] = {0};                        // fiber-pair LDS images of all cores (padded node stride)
     int obs_off = 0, cands_off = 0, tab_off[4] = {0, 0, 0, 0}, cfeat_off = 0;
     unsigned *d_status = nullptr;
     unsigned long long *d_dbg = nullptr; // diagnostic stamps (C3SC_DBG & 128)
@@ -458,6 +471,12 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
             off += ((size_t)c->ngrid[m] * 2 * MB * C * 64 + 15) & ~(size_t)15;
         }
     }
+    long img_off[MAXD] = {0};
+    for (int m = 0; m < d; m++) { // LDS images for the fiber-pair kernel's LDS-DMA staging (+2: its last 16-byte piece may overhang)
+        const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
+        img_off[m] = (long)off;
+        off += ((size_t)c->ngrid[m] * (per | 1) + 2 + 15) & ~(size_t)15;
+    }
     if (off > c->arena_cap) {
         if (c->arena) HIPCHK(c, hipFree(c->arena));
         c->arena = nullptr;
@@ -468,7 +487,7 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
     }
     if (stat != c->static_doubles) c->static_dirty = true;
     c->static_doubles = stat;
-    for (int m = 0; m < d; m++) { c->core_off[m] = core_off[m]; c->coreT_off[m] = coreT_off[m]; c->aop_off[m] = aop_off[m]; }
+    for (int m = 0; m < d; m++) { c->core_off[m] = core_off[m]; c->coreT_off[m] = coreT_off[m]; c->aop_off[m] = aop_off[m]; c->img_off[m] = img_off[m]; }
     for (int m = 0; m <= d; m++) c->ranks[m] = ranks[m];
     c->rp = rp;
     *cores_doubles = primary_end - stat;
@@ -478,6 +497,13 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
 
 static int make_quad_aux(c3sc_hip_ctx *c, void *stream)
 { // after the padded cores are in the arena (ordered on `stream`)
+    for (int m = 0; m < c->d; m++) {
+        const int per = (m == 0 || m == c->d - 1) ? c->rp : c->rp * c->rp;
+        const long total = (long)c->ngrid[m] * (per | 1);
+        const int grid = (int)std::min<long>((total + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_core_image, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->arena + c->core_off[m],
+                           c->arena + c->img_off[m], c->ngrid[m], per);
+    }
     for (int m = 1; m < c->d - 1; m++) {
         if (c->aop_off[m] == 0) continue;
         const long total = (long)c->ngrid[m] * (c->rp * c->rp + 2 * ((c->rp / 4 + 3) / 4) * (c->rp / 4) * 64);
@@ -566,7 +592,9 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
         A.core_off[m] = c->core_off[m];
         A.quad_coreT_off[m] = c->coreT_off[m];
         A.quad_aop_off[m] = c->aop_off[m];
+        A.pair_img_off[m] = c->img_off[m];
     }
+    A.img_base = c->arena;
     A.nobs = c->nobs;
     A.obs_off = c->obs_off;
     A.cands_off = c->cands_off;

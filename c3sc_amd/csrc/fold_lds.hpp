@@ -1,5 +1,5 @@
 // fold_lds.hpp -- folding helpers of the lane = fiber kernels (kernel_fiber_pair.hpp): a lane applies ITS fiber's matrix
-// (G_m[i_m] with the lane's own i_m), read from a core staged once per tile in LDS with an odd node stride, to up to four
+// (G_m[i_m] with the lane's own i_m), read from a core staged once per tile in LDS with an odd node stride (kernel_fiber_pair.hpp: stage_core_image), to up to four
 // vectors per pass; products are software-pipelined by hand (see the scheduling note below).  These were written for the
 // one-wave-per-64-fibers kernel of round 1 (k_fiber_per_lane), which was retired in round 2: it was capped by the FP64
 // issue rate of one wavefront per SIMD, AUTO never picked it, and it was the last kernel that depended on the "no
@@ -127,36 +127,6 @@ __device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
 #pragma unroll
     for (int i = 0; i < RP; i++) s = fma(a[i], b[i], s);
     return s;
-}
-
-// cooperative global -> LDS copy of one core with the padded node stride
-__device__ inline void stage_core_n(double *sK, const double *__restrict__ src, int n_nodes, int elems, int stride, int nthreads)
-{
-    // The copy is pure latency (33 KB from L2 per core and tile): every thread moves PAIRS of doubles (16-byte
-    // loads; elems is even, so a pair never straddles two nodes) and keeps a batch of 8 loads in flight before
-    // the first LDS write.  dst index of element e = e + (e / elems) * (stride - elems).  Trip counts are the same
-    // for every thread; past the end a thread repeats the last pair (same values to the same slots): no
-    // lane-divergent branch or loop exit.
-    const int pairs = (n_nodes * elems) >> 1, pad = stride - elems;
-    constexpr int B = 8;
-    const int per_batch = B * nthreads;
-    for (int base = 0; base < pairs; base += per_batch) {
-        double2 buf[B];
-        int pe[B];
-#pragma unroll
-        for (int q = 0; q < B; q++) {
-            const int p = base + q * nthreads + (int)threadIdx.x;
-            pe[q] = 2 * (p < pairs ? p : pairs - 1);
-            buf[q] = *reinterpret_cast<const double2 *>(src + pe[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < B; q++) {
-            const int node = pe[q] / elems; // elems is a small wave-uniform value: one multiply-high
-            double *d = sK + pe[q] + node * pad;
-            d[0] = buf[q].x;
-            d[1] = buf[q].y;
-        }
-    }
 }
 
 } // namespace c3sc

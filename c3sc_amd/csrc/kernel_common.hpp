@@ -49,6 +49,9 @@ struct KArgs {
     long quad_coreT_off[MAXD]; // middle cores row-major (a*RP + b): the staged matrix of the suffix-side levels
     long quad_aop_off[MAXD];   // middle cores as MFMA A operands: [N][c | a][MB][C][64]
     int quad_sv_off;           // offset (doubles) of the per-wave node-value rows in dynamic LDS
+    long pair_img_off[MAXD];   // every core once more as the fiber-pair kernel's LDS image: [N][elems | 1] (k_core_image)
+    const double *img_base;    // the arena again, as a pointer that is NOT the kernels' `ro` argument: the LDS-DMA copy reads the
+                               // images through it (see stage_core_image on why it must not be derived from `ro`)
 };
 
 // Output pointers of one launch (separate __restrict__ kernel parameters).

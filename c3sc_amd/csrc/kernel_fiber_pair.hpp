@@ -71,6 +71,33 @@ __device__ inline void pair_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// One fixed core into LDS by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS at wave base + 16 lane).
+// The source is the core's LDS image in HBM (padded node stride, k_core_image), so the copy is lane-linear.  No VGPRs and
+// every piece of the core in flight at once -- the register-staged copy it replaces took three rounds of L2 latency per core
+// with eight 16-byte loads per thread in flight.
+// `img` must come from KArgs::img_base, not from the kernel's `ro` argument: the intrinsic counts as a memory write, and once a
+// pointer based on the __restrict__ `ro` has been handed to it every later load from `ro` is "possibly clobbered" -- the
+// wave-uniform core rows of the node loop would stop being scalar loads.
+template <int H>
+__device__ inline void stage_core_image(double *sK, const double *img, int n_doubles)
+{
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int pieces = (n_doubles + 1) >> 1;
+    const int lane = threadIdx.x & 63;
+    // A wave-instruction writes 64 consecutive pieces.  The last round is moved back so that it ends with the image (it
+    // re-copies a few pieces: same data to the same place) instead of switching lanes off -- the kernel keeps EXEC untouched
+    // (tests/test_kernel_uniform_control_flow.py).  An image of fewer than 64 pieces is followed by repeats of its last piece;
+    // the staging area is never smaller than the 11 KB exchange block, so those stay inside it.
+    for (int base = H * 64; base < pieces; base += FPP_THREADS) {
+        const int b = max(min(base, pieces - 64), 0);
+        const int p = min(b + lane, pieces - 1);
+        __builtin_amdgcn_global_load_lds((glb_void *)(img + 2 * p), (lds_void *)((lds_char *)sK + 16 * b), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // which wave folds the neighbour pair of dim m (m != K): alternate by distance from K so the O(distance)
 // propagation work is balanced
 template <int K>
@@ -187,7 +214,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 constexpr int str = fpl_lds_stride(RP);
                 FPP_STAMP(1)
                 pair_barrier();
-                stage_core_n(sK, ro + A.core_off[0], A.ngrid[0], RP, str, FPP_THREADS);
+                stage_core_image<H>(sK, A.img_base + A.pair_img_off[0], A.ngrid[0] * str);
                 pair_barrier();
                 FPP_STAMP(7)
 #pragma unroll
@@ -205,7 +232,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 constexpr int before = 2 * own_left_before<D, K, H>(m); // own vectors created so far
                 FPP_STAMP(1)
                 pair_barrier();
-                stage_core_n(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str, FPP_THREADS);
+                stage_core_image<H>(sK, A.img_base + A.pair_img_off[m], A.ngrid[m] * str);
                 pair_barrier();
                 FPP_STAMP(7)
                 const double *G = sK + fi[m] * str;
@@ -230,7 +257,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 constexpr int str = fpl_lds_stride(RP);
                 FPP_STAMP(1)
                 pair_barrier();
-                stage_core_n(sK, ro + A.core_off[D - 1], A.ngrid[D - 1], RP, str, FPP_THREADS);
+                stage_core_image<H>(sK, A.img_base + A.pair_img_off[D - 1], A.ngrid[D - 1] * str);
                 pair_barrier();
                 FPP_STAMP(7)
 #pragma unroll
@@ -248,7 +275,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
                 constexpr int after = 2 * own_right_after<D, K, H>(m);
                 FPP_STAMP(1)
                 pair_barrier();
-                stage_core_n(sK, ro + A.core_off[m], A.ngrid[m], RP * RP, str, FPP_THREADS);
+                stage_core_image<H>(sK, A.img_base + A.pair_img_off[m], A.ngrid[m] * str);
                 pair_barrier();
                 FPP_STAMP(7)
                 const double *G = sK + fi[m] * str;

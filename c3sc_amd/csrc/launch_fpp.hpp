@@ -17,7 +17,7 @@ hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
     for (int m = 0; m < D; m++) {
         if (m == K) continue;
         const int elems = (m == 0 || m == D - 1) ? RP : RP * RP;
-        const size_t need = (size_t)A.ngrid[m] * fpl_lds_stride(elems);
+        const size_t need = ((size_t)A.ngrid[m] * fpl_lds_stride(elems) + 1) & ~(size_t)1; // whole 16-byte LDS-DMA pieces
         if (need > doubles) doubles = need;
     }
     // wave-uniform tables (candidates, nodes of dim K) behind everything else: they persist across tiles

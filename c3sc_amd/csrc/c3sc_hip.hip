@@ -55,6 +55,17 @@ __global__ void k_core_image(const double *__restrict__ core, double *__restrict
     }
 }
 
+// the same with the fiber-quad kernels' node stride (elems + 2)
+__global__ void k_core_image2(const double *__restrict__ core, double *__restrict__ img, int N, int per)
+{
+    const int stride = per + 2;
+    const long total = (long)N * stride;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / stride), w = (int)(e - (long)j * stride);
+        img[e] = (w < per) ? core[(size_t)j * per + w] : 0.0;
+    }
+}
+
 // Derived copies of a rank-padded middle core for the fiber-quad kernel (kernel_fiber_quad.hpp), made on the device from
 // the padded core itself: (1) the row-major transpose, (2) the two MFMA A operands of the varying-core products
 // c = G R (x = a, y = b) and a = L G (x = b, y = a): element [prod][mb][s][l] = M[x][y] with x = (i%4) C + 4 mb + i/4
@@ -146,6 +157,7 @@ struct c3sc_hip_ctx {
     long core_off[MAXD] = {0};
     long coreT_off[MAXD] = {0}, aop_off[MAXD] = {0}; // fiber-quad copies of the middle cores (0 = none)
     long img_off[MAXD] = {0};                        // fiber-pair LDS images of all cores (padded node stride)
+    long qimgL_off[MAXD] = {0}, qimgR_off[MAXD] = {0}; // fiber-quad-duo LDS images (node stride elems + 2)
     int obs_off = 0, cands_off = 0, tab_off[4] = {0, 0, 0, 0}, cfeat_off = 0;
     unsigned *d_status = nullptr;
     unsigned long long *d_dbg = nullptr; // diagnostic stamps (C3SC_DBG & 128)
@@ -477,6 +489,15 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
         img_off[m] = (long)off;
         off += ((size_t)c->ngrid[m] * (per | 1) + 2 + 15) & ~(size_t)15;
     }
+    long qimgL_off[MAXD] = {0}, qimgR_off[MAXD] = {0};
+    if (rp % 4 == 0) { // LDS images for the duo kernel's double-buffered LDS-DMA staging
+        for (int m = 0; m < d; m++) {
+            const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
+            const size_t sz = ((size_t)c->ngrid[m] * (per + 2) + 15) & ~(size_t)15;
+            if (m < d - 1) { qimgL_off[m] = (long)off; off += sz; }
+            if (m > 0) { qimgR_off[m] = (long)off; off += sz; }
+        }
+    }
     if (off > c->arena_cap) {
         if (c->arena) HIPCHK(c, hipFree(c->arena));
         c->arena = nullptr;
@@ -487,7 +508,7 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
     }
     if (stat != c->static_doubles) c->static_dirty = true;
     c->static_doubles = stat;
-    for (int m = 0; m < d; m++) { c->core_off[m] = core_off[m]; c->coreT_off[m] = coreT_off[m]; c->aop_off[m] = aop_off[m]; c->img_off[m] = img_off[m]; }
+    for (int m = 0; m < d; m++) { c->core_off[m] = core_off[m]; c->coreT_off[m] = coreT_off[m]; c->aop_off[m] = aop_off[m]; c->img_off[m] = img_off[m]; c->qimgL_off[m] = qimgL_off[m]; c->qimgR_off[m] = qimgR_off[m]; }
     for (int m = 0; m <= d; m++) c->ranks[m] = ranks[m];
     c->rp = rp;
     *cores_doubles = primary_end - stat;
@@ -510,6 +531,17 @@ static int make_quad_aux(c3sc_hip_ctx *c, void *stream)
         const int grid = (int)std::min<long>((total + 255) / 256, 1024);
         hipLaunchKernelGGL(k_quad_aux, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->arena + c->core_off[m],
                            c->arena + c->coreT_off[m], c->arena + c->aop_off[m], c->ngrid[m], c->rp);
+    }
+    for (int m = 0; m < c->d; m++) { // after k_quad_aux: the suffix-side images copy the transposed cores
+        const int per = (m == 0 || m == c->d - 1) ? c->rp : c->rp * c->rp;
+        const long total = (long)c->ngrid[m] * (per + 2);
+        const int grid = (int)std::min<long>((total + 255) / 256, 1024);
+        if (c->qimgL_off[m])
+            hipLaunchKernelGGL(k_core_image2, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->arena + c->core_off[m],
+                               c->arena + c->qimgL_off[m], c->ngrid[m], per);
+        if (c->qimgR_off[m])
+            hipLaunchKernelGGL(k_core_image2, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                               c->arena + ((m == c->d - 1) ? c->core_off[m] : c->coreT_off[m]), c->arena + c->qimgR_off[m], c->ngrid[m], per);
     }
     HIPCHK(c, hipGetLastError());
     return C3SC_OK;
@@ -593,6 +625,8 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
         A.quad_coreT_off[m] = c->coreT_off[m];
         A.quad_aop_off[m] = c->aop_off[m];
         A.pair_img_off[m] = c->img_off[m];
+        A.quad_imgL_off[m] = c->qimgL_off[m];
+        A.quad_imgR_off[m] = c->qimgR_off[m];
     }
     A.img_base = c->arena;
     A.nobs = c->nobs;

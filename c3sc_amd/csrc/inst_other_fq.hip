@@ -15,7 +15,25 @@ namespace c3sc {
     C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 8, NWV, Chain<10>)  \
     C3SC_REG_FQ1(C3SC_MODEL_CHAIN, RP, 9, NWV, Chain<10>)
 REG10Q(4, 8)
-REG10Q(16, 4) // 2(d-1)+2 vectors of 4 doubles per lane: one wave per SIMD with the whole 512-entry register file, no scratch
+#define REG10QD(RP, NWV)                                   \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 0, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 1, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 2, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 3, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 4, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 5, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 6, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 7, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 8, NWV, Chain<10>)  \
+    C3SC_REG_FQD(C3SC_MODEL_CHAIN, RP, 9, NWV, Chain<10>)
+#ifndef FQ_DUO10
+#define FQ_DUO10 1
+#endif
+#if FQ_DUO10
+REG10QD(16, 8) // 20 vectors of 4 doubles per lane do not fit one wavefront: two per 16 fibers, each with half of the neighbour vectors
+#else
+REG10Q(16, 4) // one wave per SIMD with the whole 512-entry register file
+#endif
 #define REG4Q(RP, NWV)                                   \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 0, NWV, Scar4D)  \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 1, NWV, Scar4D)  \

@@ -49,6 +49,11 @@ struct KArgs {
     long quad_coreT_off[MAXD]; // middle cores row-major (a*RP + b): the staged matrix of the suffix-side levels
     long quad_aop_off[MAXD];   // middle cores as MFMA A operands: [N][c | a][MB][C][64]
     int quad_sv_off;           // offset (doubles) of the per-wave node-value rows in dynamic LDS
+    int quad_x_off;            // duo kernel: offset (doubles) of the pairs' exchange rows [2D][64] in dynamic LDS
+    int quad_m1_off;           // duo kernel: offset (doubles) of the second staging buffer; quad_ix_off: the pairs' fiber indices
+    int quad_ix_off;
+    long quad_imgL_off[MAXD];  // duo kernel: LDS images (node stride elems + 2) of the cores as the prefix side stages them
+    long quad_imgR_off[MAXD];  //             and of the transposed cores (suffix side); read through img_base by LDS-DMA
     long pair_img_off[MAXD];   // every core once more as the fiber-pair kernel's LDS image: [N][elems | 1] (k_core_image)
     const double *img_base;    // the arena again, as a pointer that is NOT the kernels' `ro` argument: the LDS-DMA copy reads the
                                // images through it (see stage_core_image on why it must not be derived from `ro`)

@@ -545,4 +545,339 @@ __global__ void __launch_bounds__(64 * NWV, 1)
     if (st) atomicOr(A.status, st);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_fiber_quad_duo: the same lane layout with TWO wavefronts per 16 fibers.  At d = 10, rank 16 one wavefront holds
+// 2(d-1)+2 = 20 folded vectors of four doubles per lane: with the MFMA operands and a round's stencil that is more than 256
+// registers, the kernel above runs one wavefront per SIMD with the whole 512-entry file (and still spills), and FP64 VALU
+// needs two wavefronts per SIMD to get past 40 % of its rate.  Here the neighbour vectors are divided between the two
+// wavefronts of a pair (alternate dimensions by distance from K, the two sides offset so that the halves differ by one
+// dimension at most); both keep the running prefix L and suffix R, so both form c and a of a node on the matrix cores
+// (that pipe is idle otherwise) and each takes the dots of its own vectors.  Folding work per wavefront halves with the
+// vectors.  Node loop in two passes: (1) node values v_j = L G_k[j] R, alternate rounds of four nodes per wavefront, into
+// the pair's LDS row; (2) blocks of two rounds: both wavefronts form their half of both stencils, hand the half of the
+// round they do not finalise to the partner through LDS, and finalise one round each at the same time.
+__device__ inline void quad_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } // LDS traffic only: output stores stay in flight
+
+// whole-workgroup copy of a core's LDS image (HBM layout = LDS layout) by LDS-DMA: 16 bytes per lane straight into LDS, no
+// registers, nothing to wait for until the data is needed (the caller's s_waitcnt vmcnt(0) + barrier)
+template <int NWV>
+__device__ inline void quad_glds(double *dst, const double *img, int n_doubles)
+{
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int pieces = n_doubles >> 1;
+    const int lane = threadIdx.x & 63;
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 64;
+    for (int base = wbase; base < pieces; base += 64 * NWV) {
+        const int p = base + lane;
+        if (p < pieces) __builtin_amdgcn_global_load_lds((glb_void *)(img + 2 * p), (lds_void *)((lds_char *)dst + 16 * base), 16, 0, 0);
+    }
+}
+
+__host__ __device__ constexpr int duo_count(int n, int parity) { return n > parity ? (n - parity + 1) / 2 : 0; } // distances 0..n-1 of that parity
+
+template <class Model, int RP, int K, int NWV, int H>
+__device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs &A, const double *__restrict__ ro,
+                                                                   const int32_t *__restrict__ idx, double *__restrict__ outv,
+                                                                   int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed,
+                                                                   double *smem, unsigned &st)
+{
+    constexpr int D = Model::D, S = 2 * D + 1, C = RP / 4;
+    // own dimensions: left distance i = K-1-m with i % 2 == H, right distance i = m-K-1 with i % 2 == 1-H
+    constexpr int NL = 2 * duo_count(K, H), NR = 2 * duo_count(D - 1 - K, 1 - H);
+    const int lane = threadIdx.x & 63, q = lane >> 4, t = lane & 15;
+    const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7); // pair index in the workgroup
+    const int N = A.N;
+    const int bck = A.bctype[K];
+    double *const sMb[2] = {smem, smem + A.quad_m1_off};    // two staging buffers
+    double *sV = smem + A.quad_sv_off + pw * (N * 16);      // node values of the pair's 16 fibers: [N][16]
+    double *sX = smem + A.quad_x_off + pw * (2 * D * 64);   // half stencils on their way to the partner: [2D][64]
+    int *sIx = reinterpret_cast<int *>(smem + A.quad_ix_off) + pw * (D * 16); // the pair's fiber indices: [D][16]
+    constexpr int NLEV = D - 1, NRL = D - 1 - K;            // folding levels: l < NRL suffix side (m = D-1-l), then prefix (m = l-NRL)
+    auto level_issue = [&](int l) __attribute__((always_inline)) {
+        const bool right = l < NRL;
+        const int m = right ? D - 1 - l : l - NRL;
+        const int elems = (m == 0 || m == D - 1) ? RP : RP * RP;
+        quad_glds<NWV>(sMb[l & 1], A.img_base + (right ? A.quad_imgR_off[m] : A.quad_imgL_off[m]), A.ngrid[m] * quad_stride(elems));
+    };
+    CandLds<Model> cr;
+    {
+        CandRegs<Model> cr0;
+        cr0.load(A, ro);
+        cr.fill(smem + A.tbl_off, cr0, A.ncand); // every wave writes the same rows
+        quad_barrier();
+    }
+    const long per_tile = 16L * (NWV / 2), ntiles = (A.F + per_tile - 1) / per_tile;
+    const double *aopK = ro + A.quad_aop_off[K];
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long f_raw = tile * per_tile + pw * 16 + t;
+        const bool flive = f_raw < A.F;
+        const long f = flive ? f_raw : A.F - 1;
+        int fi[D];
+        double x[D];
+        bool fiber_abs = false;
+#pragma unroll
+        for (int m = 0; m < D; m++) {
+            fi[m] = (m == K) ? 0 : idx[f * D + m];
+            int lo, hi;
+            const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], lo, hi);
+            if (m != K) fiber_abs = fiber_abs || face;
+            x[m] = ro[A.xg_off[m] + fi[m]];
+        }
+        double tvf[Model::NTAB > 0 ? Model::NTAB : 1];
+        table_values<Model>(A, ro, fi, tvf);
+
+        double XL[1 + NL][C], XR[1 + NR][C]; // [0] = L / R, then this wave's neighbour vectors, nearest own dimension first
+#pragma unroll
+        for (int s = 0; s < 1 + NL; s++)
+#pragma unroll
+            for (int i = 0; i < C; i++) XL[s][i] = 0.0;
+#pragma unroll
+        for (int s = 0; s < 1 + NR; s++)
+#pragma unroll
+            for (int i = 0; i < C; i++) XR[s][i] = 0.0;
+
+        // ---- folding, level by level: the suffix side (m = D-1 .. K+1), then the prefix side (m = 0 .. K-1).  Level l's core
+        // image goes into staging buffer l & 1 by LDS-DMA while level l-1 is being applied: one barrier per level, and the copy
+        // (51 KB from L2 at rank 16) is hidden behind the products instead of stopping all eight wavefronts.
+        if (H == 0 && q == 0) {
+#pragma unroll
+            for (int m = 0; m < D; m++) sIx[m * 16 + t] = fi[m]; // the level loops are run-time loops: indices by LDS, not by scratch
+        }
+        level_issue(0);
+        if constexpr (K < D - 1) {
+            int nlive = 1;
+#pragma nounroll
+            for (int l = 0; l < NRL; l++) {
+                const int m = D - 1 - l;
+                const bool mine = (((m - K - 1) & 1) == 1 - H) && NR > 0; // wave-uniform
+                const bool edge = (m == D - 1);
+                const int ns = quad_stride(edge ? RP : RP * RP);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                quad_barrier(); // level l has landed for every wavefront, and every wavefront is done with the other buffer
+                if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
+                const double *sM = sMb[l & 1];
+                const int nd = sIx[m * 16 + t];
+                int lo, hi;
+                (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
+                double T0[C], T1[C];
+#pragma unroll
+                for (int i = 0; i < C; i++) { T0[i] = 0.0; T1[i] = 0.0; }
+                if (edge) {
+#pragma unroll
+                    for (int i = 0; i < C; i++) {
+                        XR[0][i] = sM[nd * ns + q * C + i];
+                        T0[i] = sM[lo * ns + q * C + i];
+                        T1[i] = sM[hi * ns + q * C + i];
+                    }
+                } else if (!(A.dbg & 256)) {
+                    if (mine) apply_quad_pair<RP>(sM + lo * ns, sM + hi * ns, XR[0], T0, T1, q);
+                    apply_live<RP, 1 + NR, 0>(sM + nd * ns, XR, nlive, q);
+                }
+                if constexpr (NR > 0) {
+                    if (mine) {
+#pragma unroll
+                        for (int s = NR; s >= 3; s--)
+#pragma unroll
+                            for (int i = 0; i < C; i++) XR[s][i] = XR[s - 2][i];
+#pragma unroll
+                        for (int i = 0; i < C; i++) { XR[1][i] = T0[i]; XR[2][i] = T1[i]; }
+                        nlive += 2;
+                    }
+                }
+            }
+        }
+        if constexpr (K > 0) {
+            int nlive = 1;
+#pragma nounroll
+            for (int l = NRL; l < NLEV; l++) {
+                const int m = l - NRL;
+                const bool mine = (((K - 1 - m) & 1) == H) && NL > 0;
+                const bool edge = (m == 0);
+                const int ns = quad_stride(edge ? RP : RP * RP);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                quad_barrier();
+                if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
+                const double *sM = sMb[l & 1];
+                const int nd = sIx[m * 16 + t];
+                int lo, hi;
+                (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
+                double T0[C], T1[C];
+#pragma unroll
+                for (int i = 0; i < C; i++) { T0[i] = 0.0; T1[i] = 0.0; }
+                if (edge) {
+#pragma unroll
+                    for (int i = 0; i < C; i++) {
+                        XL[0][i] = sM[nd * ns + q * C + i];
+                        T0[i] = sM[lo * ns + q * C + i];
+                        T1[i] = sM[hi * ns + q * C + i];
+                    }
+                } else if (!(A.dbg & 256)) {
+                    if (mine) apply_quad_pair<RP>(sM + lo * ns, sM + hi * ns, XL[0], T0, T1, q);
+                    apply_live<RP, 1 + NL, 0>(sM + nd * ns, XL, nlive, q);
+                }
+                if constexpr (NL > 0) {
+                    if (mine) {
+#pragma unroll
+                        for (int s = NL; s >= 3; s--)
+#pragma unroll
+                            for (int i = 0; i < C; i++) XL[s][i] = XL[s - 2][i];
+#pragma unroll
+                        for (int i = 0; i < C; i++) { XL[1][i] = T0[i]; XL[2][i] = T1[i]; }
+                        nlive += 2;
+                    }
+                }
+            }
+        }
+
+        // c / a of the four nodes of a round (own components): matrix cores for a middle core, the core itself at the ends
+        auto round_c = [&](const int (&jn)[4], double (&c)[4][C]) __attribute__((always_inline)) {
+            if constexpr (K == D - 1) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                    for (int i = 0; i < C; i++) c[jj][i] = ro[A.core_off[K] + (size_t)jn[jj] * RP + q * C + i];
+            } else mfma_prod4<RP>(aopK, jn, XR[0], c, lane);
+        };
+        auto round_a = [&](const int (&jn)[4], double (&a)[4][C]) __attribute__((always_inline)) {
+            if constexpr (K == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+                    for (int i = 0; i < C; i++) a[jj][i] = ro[A.core_off[K] + (size_t)jn[jj] * RP + q * C + i];
+            } else mfma_prod4<RP>(aopK + quad_aop_node(RP) / 2, jn, XL[0], a, lane);
+        };
+        const bool forced = A.forced != nullptr;
+        const int rounds = (N + 3) / 4;
+
+        // ---- pass 1: node values, alternate rounds per wavefront
+        for (int r = H; r < ((A.dbg & 2048) ? 0 : rounds); r += 2) {
+            const int j0 = 4 * r;
+            const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
+            double vs[4];
+            if constexpr (K > 0) {
+                double c[4][C];
+                round_c(jn, c);
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) vs[jj] = dot_c<C>(XL[0], c[jj]);
+            } else {
+                double a[4][C];
+                round_a(jn, a);
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) vs[jj] = dot_c<C>(a[jj], XR[0]);
+            }
+            const double v = reduce4(vs[0], vs[1], vs[2], vs[3]);
+            if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+        }
+        quad_barrier();
+
+        // own half of the stencil of a round: lane (q, t) ends with the values of node j0 + q of fiber t
+        auto stencil_own = [&](int j0, double (&V)[S]) __attribute__((always_inline)) {
+            const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
+            if constexpr (K > 0 && NL > 0) {
+                double c[4][C];
+                round_c(jn, c);
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    if ((i & 1) != H) continue;
+                    const int m = K - 1 - i, slot = 1 + 2 * (i / 2);
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+                        V[2 * m + s] = reduce4(dot_c<C>(XL[slot + s], c[0]), dot_c<C>(XL[slot + s], c[1]), dot_c<C>(XL[slot + s], c[2]),
+                                               dot_c<C>(XL[slot + s], c[3]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (K < D - 1 && NR > 0) {
+                double a[4][C];
+                round_a(jn, a);
+#pragma unroll
+                for (int i = 0; i < D - 1 - K; i++) {
+                    if ((i & 1) != 1 - H) continue;
+                    const int m = K + 1 + i, slot = 1 + 2 * (i / 2);
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+                        V[2 * m + s] = reduce4(dot_c<C>(a[0], XR[slot + s]), dot_c<C>(a[1], XR[slot + s]), dot_c<C>(a[2], XR[slot + s]),
+                                               dot_c<C>(a[3], XR[slot + s]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto finalize = [&](int j0, double (&V)[S]) __attribute__((always_inline)) {
+            const bool nlive = (j0 + q < N);
+            const int j = nlive ? j0 + q : N - 1;
+            x[K] = ro[A.xg_off[K] + j];
+            int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
+            if (fiber_abs) ab = 1;
+            int lo, hi;
+            ab = vary_neighbors(j, N, bck, ab, lo, hi);
+            V[2 * K] = sV[lo * 16 + t];
+            V[2 * K + 1] = sV[hi * 16 + t];
+            V[2 * D] = sV[j * 16 + t];
+            double tv[Model::NTAB > 0 ? Model::NTAB : 1];
+            tv[0] = 0.0;
+#pragma unroll
+            for (int tt = 0; tt < Model::NTAB; tt++) tv[tt] = (Model::tab_dim(tt) == K) ? ro[A.tab_off[tt] + j] : tvf[tt];
+            int ui = 0;
+            const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
+            double val = V[0] + V[2 * D - 1];
+            if (!(A.dbg & 1024)) val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+            if (nlive && flive) {
+                outv[(size_t)f * N + j] = val;
+                if (uidx) uidx[(size_t)f * N + j] = ui;
+                if (absorbed) absorbed[(size_t)f * N + j] = ab;
+            }
+        };
+        // is stencil entry e = 2m + s (m != K) formed by wavefront h?
+        auto owner_of = [](int m) __attribute__((always_inline)) -> int { return m < K ? ((K - 1 - m) & 1) : 1 - ((m - K - 1) & 1); };
+
+        // ---- pass 2: blocks of two rounds
+        for (int b = 0; 2 * b < ((A.dbg & 4096) ? 0 : rounds); b++) {
+            double Vm[S];
+#pragma unroll
+            for (int s = 0; s < S; s++) Vm[s] = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int r = 2 * b + rr;
+                if (r < rounds) { // wave-uniform
+                    if (rr == H) stencil_own(4 * r, Vm);
+                    else {
+                        double Vh[S];
+#pragma unroll
+                        for (int s = 0; s < S; s++) Vh[s] = 0.0;
+                        stencil_own(4 * r, Vh);
+#pragma unroll
+                        for (int m = 0; m < D; m++)
+                            if (m != K && owner_of(m) == H) { sX[(2 * m) * 64 + lane] = Vh[2 * m]; sX[(2 * m + 1) * 64 + lane] = Vh[2 * m + 1]; }
+                    }
+                }
+            }
+            quad_barrier();
+            if (2 * b + H < rounds) {
+#pragma unroll
+                for (int m = 0; m < D; m++)
+                    if (m != K && owner_of(m) != H) { Vm[2 * m] = sX[(2 * m) * 64 + lane]; Vm[2 * m + 1] = sX[(2 * m + 1) * 64 + lane]; }
+                finalize(4 * (2 * b + H), Vm);
+            }
+            quad_barrier(); // the exchange rows (and, after the last block, the node values) may be overwritten
+        }
+    }
+}
+
+template <class Model, int RP, int K, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 1)
+    k_fiber_quad_duo(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
+                     int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
+{
+    static_assert(RP % 4 == 0 && RP >= 4 && RP <= 32 && NWV % 2 == 0, "padded rank must be a multiple of 4, wavefronts come in pairs");
+    extern __shared__ double smem_duo[];
+    unsigned st = 0;
+    const int h = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 1);
+    if (h == 0) quad_duo_body<Model, RP, K, NWV, 0>(A, ro, idx, outv, uidx, absorbed, smem_duo, st);
+    else quad_duo_body<Model, RP, K, NWV, 1>(A, ro, idx, outv, uidx, absorbed, smem_duo, st);
+    if (st) atomicOr(A.status, st);
+}
+
 } // namespace c3sc

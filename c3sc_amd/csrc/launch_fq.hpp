@@ -51,6 +51,51 @@ hipError_t launch_fq(const KArgs &A, const LaunchIO &io)
     return launch_fq_impl<Model, RP, K, NWV, ONEPASS>(A, io);
 }
 
+// two wavefronts per 16 fibers (k_fiber_quad_duo): NWV / 2 pairs per workgroup
+template <class Model, int RP, int K, int NWV>
+hipError_t launch_fq_duo(const KArgs &A, const LaunchIO &io)
+{
+    constexpr int D = Model::D;
+    if (A.cmode == 1) return hipErrorNotSupported; // candidate lists only
+    if (K > 0 && K < D - 1 && A.quad_aop_off[K] == 0) return hipErrorNotSupported;
+    size_t doubles = 0;
+    for (int m = 0; m < D; m++) {
+        if (m == K) continue;
+        const size_t need = (size_t)A.ngrid[m] * quad_stride((m == 0 || m == D - 1) ? RP : RP * RP);
+        if (need > doubles) doubles = need;
+    }
+    doubles = (doubles + 1) & ~(size_t)1;
+    KArgs B = A;
+    B.quad_m1_off = (int)doubles; // two staging buffers: level l+1 is copied while level l is applied
+    doubles *= 2;
+    B.quad_sv_off = (int)doubles;
+    doubles += (size_t)(NWV / 2) * A.N * 16; // node values of each pair's 16 fibers
+    B.quad_ix_off = (int)doubles;
+    doubles += (size_t)(NWV / 2) * D * 8; // fiber indices [D][16] ints per pair
+    B.quad_x_off = (int)doubles;
+    doubles += (size_t)(NWV / 2) * 2 * D * 64; // half stencils between the wavefronts of a pair
+    B.tbl_off = (int)doubles;
+    doubles += (size_t)CandLds<Model>::doubles(A.ncand);
+    const size_t shmem = doubles * sizeof(double);
+    if (shmem > 160u * 1024u) return hipErrorOutOfMemory;
+    auto kern = k_fiber_quad_duo<Model, RP, K, NWV>;
+    static LaunchCache cache;
+    int blocks_per_cu = 1, num_cu = 256;
+    hipError_t e = cache.prepare((const void *)kern, 64 * NWV, shmem, blocks_per_cu, num_cu);
+    if (e != hipSuccess) return e;
+    const long per_tile = 16L * (NWV / 2), ntiles = (A.F + per_tile - 1) / per_tile;
+    const long cap = (long)num_cu * blocks_per_cu;
+    int grid = (int)(ntiles < cap ? ntiles : cap);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), shmem, io.stream, B, io.ro, io.idx, io.out, io.uidx, io.absorbed);
+    return hipGetLastError();
+}
+
+#define C3SC_REG_FQD(MODEL_ID, RP, K, NWV, ...)                                                                      \
+    static Registrar C3SC_CAT(reg_fqd_, __COUNTER__)(KernelEntry{                                                    \
+        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_QUAD, 128, K, &launch_fq_duo<__VA_ARGS__, RP, K, NWV>,  \
+        "k_fiber_quad_duo<" #__VA_ARGS__ "," #RP ",K=" #K ">"});
+
 #define C3SC_REG_FQ1(MODEL_ID, RP, K, NWV, ...)                                                                  \
     static Registrar C3SC_CAT(reg_fq_, __COUNTER__)(KernelEntry{                                                 \
         MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_QUAD, 128, K, &launch_fq<__VA_ARGS__, RP, K, NWV>,  \

@@ -26,6 +26,7 @@ CASES = [
     ("car7d", dict(), 64),                                                     # C4 at full size: 41^7, rank 10 (padded 12)
     ("quad10d", dict(ngrid=(5, 6, 5, 4, 5, 6, 5, 4, 5, 6), rank=4), 100),
     ("quad10d", dict(ngrid=(7, 6, 5, 8, 7, 6, 5, 8, 7, 25), rank=15), 70),     # C5's rank (padded 16)
+    ("quad10d", dict(ngrid=(6, 25, 7, 5, 9, 6, 26, 5, 8, 7), rank=13), 150),   # ragged grid, three tiles of the duo kernel, last one partial
     ("scar4d", dict(ngrid=(12, 11, 10, 9), rank=8), 200),
     ("scar4d", dict(), 50),                                                    # 40^4, rank 20: two MFMA row blocks
     ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8), 150),
@@ -49,6 +50,8 @@ def test_fiber_quad_vs_oracle(oracle, name, kw, nf):
         ref, ref_ui, ref_ab = P.bellman_fibers(k, idx)
         out, ui, ab = eng.bellman_fibers_host(k, idx)
         assert "fiber_quad" in eng.last_kernel(), eng.last_kernel()
+        if name == "quad10d" and w.ranks[1] > 12:  # rank class 16 at d = 10: two wavefronts per 16 fibers
+            assert "fiber_quad_duo" in eng.last_kernel(), eng.last_kernel()
         assert eng.status() == 0
         np.testing.assert_array_equal(ab, ref_ab)
         scale = np.abs(ref).max()

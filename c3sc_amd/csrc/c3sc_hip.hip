@@ -43,23 +43,22 @@ __global__ void k_pad_core(const double *__restrict__ src, double *__restrict__ 
     }
 }
 
-// A rank-padded core once more with the fiber-pair kernel's LDS node stride (elems | 1 doubles per node): that kernel
-// copies the image into LDS with LDS-DMA (global_load_lds, 16 bytes per lane), which writes lane-linearly and cannot pad.
-__global__ void k_core_image(const double *__restrict__ core, double *__restrict__ img, int N, int per)
+// LDS images of the cores (the arena layout once more with the node stride a kernel uses in LDS), all in ONE launch: the
+// fiber-pair kernel copies its fixed cores into LDS by LDS-DMA (global_load_lds, 16 bytes per lane), which writes
+// lane-linearly and cannot pad, so the padding (elems | 1 doubles per node there, elems + 2 for the fiber-quad kernels) is
+// laid down here.  blockIdx.y = job.
+struct ImgJobs {
+    int n;
+    long src[3 * MAXD], dst[3 * MAXD];
+    int nodes[3 * MAXD], per[3 * MAXD], stride[3 * MAXD];
+};
+__global__ void k_core_images(double *__restrict__ arena, const ImgJobs J)
 {
-    const int stride = per | 1;
-    const long total = (long)N * stride;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(e / stride), w = (int)(e - (long)j * stride);
-        img[e] = (w < per) ? core[(size_t)j * per + w] : 0.0;
-    }
-}
-
-// the same with the fiber-quad kernels' node stride (elems + 2)
-__global__ void k_core_image2(const double *__restrict__ core, double *__restrict__ img, int N, int per)
-{
-    const int stride = per + 2;
-    const long total = (long)N * stride;
+    const int jb = blockIdx.y;
+    const double *core = arena + J.src[jb];
+    double *img = arena + J.dst[jb];
+    const int per = J.per[jb], stride = J.stride[jb];
+    const long total = (long)J.nodes[jb] * stride;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int j = (int)(e / stride), w = (int)(e - (long)j * stride);
         img[e] = (w < per) ? core[(size_t)j * per + w] : 0.0;
@@ -518,13 +517,6 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
 
 static int make_quad_aux(c3sc_hip_ctx *c, void *stream)
 { // after the padded cores are in the arena (ordered on `stream`)
-    for (int m = 0; m < c->d; m++) {
-        const int per = (m == 0 || m == c->d - 1) ? c->rp : c->rp * c->rp;
-        const long total = (long)c->ngrid[m] * (per | 1);
-        const int grid = (int)std::min<long>((total + 255) / 256, 1024);
-        hipLaunchKernelGGL(k_core_image, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->arena + c->core_off[m],
-                           c->arena + c->img_off[m], c->ngrid[m], per);
-    }
     for (int m = 1; m < c->d - 1; m++) {
         if (c->aop_off[m] == 0) continue;
         const long total = (long)c->ngrid[m] * (c->rp * c->rp + 2 * ((c->rp / 4 + 3) / 4) * (c->rp / 4) * 64);
@@ -532,17 +524,22 @@ static int make_quad_aux(c3sc_hip_ctx *c, void *stream)
         hipLaunchKernelGGL(k_quad_aux, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->arena + c->core_off[m],
                            c->arena + c->coreT_off[m], c->arena + c->aop_off[m], c->ngrid[m], c->rp);
     }
-    for (int m = 0; m < c->d; m++) { // after k_quad_aux: the suffix-side images copy the transposed cores
+    ImgJobs J; // after k_quad_aux: the suffix-side images copy the transposed cores
+    J.n = 0;
+    long maxtotal = 1;
+    auto add = [&](long src, long dst, int nodes, int per, int stride) {
+        J.src[J.n] = src; J.dst[J.n] = dst; J.nodes[J.n] = nodes; J.per[J.n] = per; J.stride[J.n] = stride;
+        J.n++;
+        maxtotal = std::max(maxtotal, (long)nodes * stride);
+    };
+    for (int m = 0; m < c->d; m++) {
         const int per = (m == 0 || m == c->d - 1) ? c->rp : c->rp * c->rp;
-        const long total = (long)c->ngrid[m] * (per + 2);
-        const int grid = (int)std::min<long>((total + 255) / 256, 1024);
-        if (c->qimgL_off[m])
-            hipLaunchKernelGGL(k_core_image2, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->arena + c->core_off[m],
-                               c->arena + c->qimgL_off[m], c->ngrid[m], per);
-        if (c->qimgR_off[m])
-            hipLaunchKernelGGL(k_core_image2, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                               c->arena + ((m == c->d - 1) ? c->core_off[m] : c->coreT_off[m]), c->arena + c->qimgR_off[m], c->ngrid[m], per);
+        add(c->core_off[m], c->img_off[m], c->ngrid[m], per, per | 1);
+        if (c->qimgL_off[m]) add(c->core_off[m], c->qimgL_off[m], c->ngrid[m], per, per + 2);
+        if (c->qimgR_off[m]) add((m == c->d - 1) ? c->core_off[m] : c->coreT_off[m], c->qimgR_off[m], c->ngrid[m], per, per + 2);
     }
+    hipLaunchKernelGGL(k_core_images, dim3((unsigned)std::min<long>((maxtotal + 255) / 256, 64), (unsigned)J.n), dim3(256), 0, (hipStream_t)stream,
+                       c->arena, J);
     HIPCHK(c, hipGetLastError());
     return C3SC_OK;
 }

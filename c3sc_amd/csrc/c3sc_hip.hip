@@ -261,12 +261,14 @@ static int upload_static(c3sc_hip_ctx *c)
 // (F = r_k r_{k+1}, a few hundred fibers) are latency-bound and take the per-wave kernel.
 static const size_t SMALL_BATCH_FIBERS = 16384;
 
-static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, int variant, int k, size_t F = (size_t)-1)
+static const KernelEntry *find_kernel(int model, int d, int rank_needed, int N, int variant, int k, size_t F = (size_t)-1,
+                                      const std::vector<const KernelEntry *> *skip = nullptr)
 {
     const KernelEntry *best = nullptr;
     const bool small = (variant == C3SC_VARIANT_AUTO) && F < SMALL_BATCH_FIBERS;
     for (const auto &e : kernel_registry()) {
         if (e.model != model || e.d != d || e.rp < rank_needed || e.max_n < N) continue;
+        if (skip && std::find(skip->begin(), skip->end(), &e) != skip->end()) continue;
         if (e.k >= 0 && e.k != k) continue;
         if (variant != C3SC_VARIANT_AUTO && e.variant != variant) continue;
         auto pref = [small](int v) {
@@ -656,14 +658,26 @@ static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx
     if (F == 0) return C3SC_OK;
     if (!d_idx || !d_out) return fail(c, C3SC_ERR_ARG, "bellman_fibers: null buffer");
     A.forced = d_policy;
-    const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant, k, F);
-    if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
-    c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
+    // A launcher declines (nothing launched) when its LDS layout does not fit this grid or it does not serve this call; the
+    // next-best instantiation of the same padded rank is tried then (e.g. the duo kernel's two staging buffers hold N <= 25 at
+    // rank 16, the one-buffer quad kernel behind it N <= 75, the per-wave kernel behind that only stages the varying core).
+    std::vector<const KernelEntry *> declined;
+    hipError_t he = hipSuccess;
+    for (;;) {
+        const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, c->variant, k, F, &declined);
+        if (!e || e->rp != c->rp) {
+            if (declined.empty()) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: no kernel instantiation for (model, dim, rank, N)");
+            return fail(c, C3SC_ERR_UNSUPPORTED, he == hipErrorOutOfMemory
+                            ? "bellman_fibers: N x rank^2 of the varying core exceeds the 160 KB of LDS the per-wave kernel stages it in"
+                            : "bellman_fibers: no kernel instantiation serves this call (model, dim, rank, N, control mode)");
+        }
+        c->last_kernel = e->name;
+        he = e->fn(A, io);
+        if (he != hipErrorOutOfMemory && he != hipErrorNotSupported) break;
+        declined.push_back(e);
+    }
     g_launches++;
-    const hipError_t he = e->fn(A, io);
-    if (he == hipErrorOutOfMemory)
-        return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers: N x rank^2 of the varying core exceeds the 160 KB of LDS the per-wave kernel stages it in");
     HIPCHK(c, he);
     return C3SC_OK;
 }

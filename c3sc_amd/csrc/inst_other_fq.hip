@@ -31,9 +31,8 @@ REG10Q(4, 8)
 #endif
 #if FQ_DUO10
 REG10QD(16, 8) // 20 vectors of 4 doubles per lane do not fit one wavefront: two per 16 fibers, each with half of the neighbour vectors
-#else
-REG10Q(16, 4) // one wave per SIMD with the whole 512-entry register file
 #endif
+REG10Q(16, 4) // one wave per SIMD with the whole 512-entry register file: behind the duo kernel, for grids its two staging buffers do not hold (N > 25)
 #define REG4Q(RP, NWV)                                   \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 0, NWV, Scar4D)  \
     C3SC_REG_FQ1(C3SC_MODEL_SCAR4D, RP, 1, NWV, Scar4D)  \

@@ -35,7 +35,9 @@ hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
     // Persistent workgroups (one per resident slot, striding over the tiles) amortise the per-workgroup set-up, but a
     // static split leaves the slots that drew the slow tiles running at the end.  Once there are many tiles per slot the
     // hardware dispatcher balances better with one workgroup per tile (car7d, 2^20 fibers = 16 tiles per slot: 1.84 vs
-    // 1.92 ms; at 2 tiles per slot it is the other way round, 0.290 vs 0.270 ms, and at 4 they are equal).
+    // 1.92 ms; at 2 tiles per slot it is the other way round, 0.290 vs 0.270 ms, and at 4 they are equal).  In between is worse
+    // still: 2 / 4 / 8 tiles per workgroup at 2^20 fibers take 1.85 / 1.92 / 2.05 ms against 1.82 (the last round of a coarser
+    // grid leaves slots idle).
     int grid = (int)(ntiles < cap ? ntiles : cap);
     if (ntiles >= 8 * cap && ntiles < 0x7fffffffL) grid = (int)ntiles;
     if (grid < 1) grid = 1;

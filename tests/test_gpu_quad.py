@@ -82,3 +82,21 @@ def test_fiber_quad_policy_evaluation_and_repeatability(oracle):
         same = (ref_ui < 0) | (ui == ref_ui)
         assert np.abs(out - ref)[same].max() <= REL_TOL * np.abs(ref).max()
         assert "fiber_quad" in eng_it.last_kernel()
+
+
+def test_duo_kernel_declines_large_grids_and_the_quad_kernel_takes_over(oracle):
+    """The duo kernel keeps two staging buffers: at rank class 16 they hold cores of N <= 25 nodes.  A launcher that does not fit
+    declines without launching and the next instantiation of the same padded rank runs (here the one-buffer quad kernel)."""
+    w = wl.WORKLOADS["quad10d"]().scaled(ngrid=(5, 6, 30, 4, 5, 6, 5, 4, 5, 7), rank=14)
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    eng = _engine(w, cores)
+    for k in (0, 2, 9):
+        idx = wl.synth_fibers(w, k, 40)
+        idx[:, k] = 0
+        ref, _, ref_ab = P.bellman_fibers(k, idx)
+        out, _, ab = eng.bellman_fibers_host(k, idx)
+        # with dimension 2 varying its own core is not staged: everything else fits the duo kernel
+        assert ("k_fiber_quad_duo<" if k == 2 else "k_fiber_quad<") in eng.last_kernel(), eng.last_kernel()
+        np.testing.assert_array_equal(ab, ref_ab)
+        assert np.abs(out - ref).max() <= REL_TOL * np.abs(ref).max()

@@ -590,7 +590,10 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
     const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7); // pair index in the workgroup
     const int N = A.N;
     const int bck = A.bctype[K];
-    double *const sMb[2] = {smem, smem + A.quad_m1_off};    // two staging buffers
+    // two staging buffers, level l in buffer l & 1.  The address is formed by arithmetic on the LDS base: a pointer picked from an
+    // array at run time loses its address space and every matrix read becomes a flat load (16 M vector-memory reads per launch
+    // in the first version of this kernel, and the copy/compute overlap bought nothing)
+    auto sMbuf = [&](int l) __attribute__((always_inline)) -> double * { return smem + (l & 1) * A.quad_m1_off; };
     double *sV = smem + A.quad_sv_off + pw * (N * 16);      // node values of the pair's 16 fibers: [N][16]
     double *sX = smem + A.quad_x_off + pw * (2 * D * 64);   // half stencils on their way to the partner: [2D][64]
     int *sIx = reinterpret_cast<int *>(smem + A.quad_ix_off) + pw * (D * 16); // the pair's fiber indices: [D][16]
@@ -599,7 +602,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
         const bool right = l < NRL;
         const int m = right ? D - 1 - l : l - NRL;
         const int elems = (m == 0 || m == D - 1) ? RP : RP * RP;
-        quad_glds<NWV>(sMb[l & 1], A.img_base + (right ? A.quad_imgR_off[m] : A.quad_imgL_off[m]), A.ngrid[m] * quad_stride(elems));
+        quad_glds<NWV>(sMbuf(l), A.img_base + (right ? A.quad_imgR_off[m] : A.quad_imgL_off[m]), A.ngrid[m] * quad_stride(elems));
     };
     CandLds<Model> cr;
     {
@@ -658,7 +661,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 quad_barrier(); // level l has landed for every wavefront, and every wavefront is done with the other buffer
                 if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
-                const double *sM = sMb[l & 1];
+                const double *sM = sMbuf(l);
                 const int nd = sIx[m * 16 + t];
                 int lo, hi;
                 (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
@@ -700,7 +703,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 quad_barrier();
                 if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
-                const double *sM = sMb[l & 1];
+                const double *sM = sMbuf(l);
                 const int nd = sIx[m * 16 + t];
                 int lo, hi;
                 (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);

@@ -577,7 +577,7 @@ __device__ inline void quad_glds(double *dst, const double *img, int n_doubles)
 
 __host__ __device__ constexpr int duo_count(int n, int parity) { return n > parity ? (n - parity + 1) / 2 : 0; } // distances 0..n-1 of that parity
 
-template <class Model, int RP, int K, int NWV, int H>
+template <class Model, int RP, int K, int NWV, bool DBUF, int H>
 __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs &A, const double *__restrict__ ro,
                                                                    const int32_t *__restrict__ idx, double *__restrict__ outv,
                                                                    int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed,
@@ -593,7 +593,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
     // two staging buffers, level l in buffer l & 1.  The address is formed by arithmetic on the LDS base: a pointer picked from an
     // array at run time loses its address space and every matrix read becomes a flat load (16 M vector-memory reads per launch
     // in the first version of this kernel, and the copy/compute overlap bought nothing)
-    auto sMbuf = [&](int l) __attribute__((always_inline)) -> double * { return smem + (l & 1) * A.quad_m1_off; };
+    auto sMbuf = [&](int l) __attribute__((always_inline)) -> double * { return DBUF ? smem + (l & 1) * A.quad_m1_off : smem; };
     double *sV = smem + A.quad_sv_off + pw * (N * 16);      // node values of the pair's 16 fibers: [N][16]
     double *sX = smem + A.quad_x_off + pw * (2 * D * 64);   // half stencils on their way to the partner: [2D][64]
     int *sIx = reinterpret_cast<int *>(smem + A.quad_ix_off) + pw * (D * 16); // the pair's fiber indices: [D][16]
@@ -649,7 +649,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
 #pragma unroll
             for (int m = 0; m < D; m++) sIx[m * 16 + t] = fi[m]; // the level loops are run-time loops: indices by LDS, not by scratch
         }
-        level_issue(0);
+        if constexpr (DBUF) level_issue(0);
         if constexpr (K < D - 1) {
             int nlive = 1;
 #pragma nounroll
@@ -658,9 +658,16 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                 const bool mine = (((m - K - 1) & 1) == 1 - H) && NR > 0; // wave-uniform
                 const bool edge = (m == D - 1);
                 const int ns = quad_stride(edge ? RP : RP * RP);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                quad_barrier(); // level l has landed for every wavefront, and every wavefront is done with the other buffer
-                if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
+                if constexpr (DBUF) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    quad_barrier(); // level l has landed for every wavefront, and every wavefront is done with the other buffer
+                    if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
+                } else { // one buffer (two workgroups per CU cover each other's copies instead)
+                    quad_barrier();
+                    if (!(A.dbg & 512)) level_issue(l);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    quad_barrier();
+                }
                 const double *sM = sMbuf(l);
                 const int nd = sIx[m * 16 + t];
                 int lo, hi;
@@ -700,9 +707,16 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                 const bool mine = (((K - 1 - m) & 1) == H) && NL > 0;
                 const bool edge = (m == 0);
                 const int ns = quad_stride(edge ? RP : RP * RP);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                quad_barrier();
-                if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
+                if constexpr (DBUF) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    quad_barrier();
+                    if (l + 1 < NLEV && !(A.dbg & 512)) level_issue(l + 1);
+                } else { // one buffer (two workgroups per CU cover each other's copies instead)
+                    quad_barrier();
+                    if (!(A.dbg & 512)) level_issue(l);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    quad_barrier();
+                }
                 const double *sM = sMbuf(l);
                 const int nd = sIx[m * 16 + t];
                 int lo, hi;
@@ -869,8 +883,8 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
     }
 }
 
-template <class Model, int RP, int K, int NWV>
-__global__ void __launch_bounds__(64 * NWV, 1)
+template <class Model, int RP, int K, int NWV, bool DBUF>
+__global__ void __launch_bounds__(64 * NWV, DBUF ? 1 : 2)
     k_fiber_quad_duo(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
                      int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
 {
@@ -878,8 +892,8 @@ __global__ void __launch_bounds__(64 * NWV, 1)
     extern __shared__ double smem_duo[];
     unsigned st = 0;
     const int h = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 1);
-    if (h == 0) quad_duo_body<Model, RP, K, NWV, 0>(A, ro, idx, outv, uidx, absorbed, smem_duo, st);
-    else quad_duo_body<Model, RP, K, NWV, 1>(A, ro, idx, outv, uidx, absorbed, smem_duo, st);
+    if (h == 0) quad_duo_body<Model, RP, K, NWV, DBUF, 0>(A, ro, idx, outv, uidx, absorbed, smem_duo, st);
+    else quad_duo_body<Model, RP, K, NWV, DBUF, 1>(A, ro, idx, outv, uidx, absorbed, smem_duo, st);
     if (st) atomicOr(A.status, st);
 }
 

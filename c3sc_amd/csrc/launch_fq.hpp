@@ -52,7 +52,7 @@ hipError_t launch_fq(const KArgs &A, const LaunchIO &io)
 }
 
 // two wavefronts per 16 fibers (k_fiber_quad_duo): NWV / 2 pairs per workgroup
-template <class Model, int RP, int K, int NWV>
+template <class Model, int RP, int K, int NWV, bool DBUF>
 hipError_t launch_fq_duo(const KArgs &A, const LaunchIO &io)
 {
     constexpr int D = Model::D;
@@ -67,7 +67,7 @@ hipError_t launch_fq_duo(const KArgs &A, const LaunchIO &io)
     doubles = (doubles + 1) & ~(size_t)1;
     KArgs B = A;
     B.quad_m1_off = (int)doubles; // two staging buffers: level l+1 is copied while level l is applied
-    doubles *= 2;
+    if (DBUF) doubles *= 2;
     B.quad_sv_off = (int)doubles;
     doubles += (size_t)(NWV / 2) * A.N * 16; // node values of each pair's 16 fibers
     B.quad_ix_off = (int)doubles;
@@ -78,7 +78,7 @@ hipError_t launch_fq_duo(const KArgs &A, const LaunchIO &io)
     doubles += (size_t)CandLds<Model>::doubles(A.ncand);
     const size_t shmem = doubles * sizeof(double);
     if (shmem > 160u * 1024u) return hipErrorOutOfMemory;
-    auto kern = k_fiber_quad_duo<Model, RP, K, NWV>;
+    auto kern = k_fiber_quad_duo<Model, RP, K, NWV, DBUF>;
     static LaunchCache cache;
     int blocks_per_cu = 1, num_cu = 256;
     hipError_t e = cache.prepare((const void *)kern, 64 * NWV, shmem, blocks_per_cu, num_cu);
@@ -91,9 +91,12 @@ hipError_t launch_fq_duo(const KArgs &A, const LaunchIO &io)
     return hipGetLastError();
 }
 
-#define C3SC_REG_FQD(MODEL_ID, RP, K, NWV, ...)                                                                      \
-    static Registrar C3SC_CAT(reg_fqd_, __COUNTER__)(KernelEntry{                                                    \
-        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_QUAD, 128, K, &launch_fq_duo<__VA_ARGS__, RP, K, NWV>,  \
+#ifndef FQD_DBUF
+#define FQD_DBUF true
+#endif
+#define C3SC_REG_FQD(MODEL_ID, RP, K, NWV, ...)                                                                                \
+    static Registrar C3SC_CAT(reg_fqd_, __COUNTER__)(KernelEntry{                                                              \
+        MODEL_ID, __VA_ARGS__::D, RP, 0, C3SC_VARIANT_FIBER_QUAD, 128, K, &launch_fq_duo<__VA_ARGS__, RP, K, NWV, FQD_DBUF>,  \
         "k_fiber_quad_duo<" #__VA_ARGS__ "," #RP ",K=" #K ">"});
 
 #define C3SC_REG_FQ1(MODEL_ID, RP, K, NWV, ...)                                                                  \

@@ -171,13 +171,13 @@ __device__ __forceinline__ void apply_quad1(const double *Mn, const double (&v)[
 }
 
 // all live vectors of one side through the matrix of this level, up to four per pass; blocks past the live count are skipped
-template <int RP, int NX, int B0>
+template <int RP, int NX, int B0, int NVBMAX = FQ_NVB>
 __device__ __forceinline__ void apply_live(const double *Mn, double (&X)[NX][RP / 4], int nlive, int q)
 {
     if constexpr (B0 < NX) {
-        constexpr int NVB = (NX - B0) < FQ_NVB ? (NX - B0) : FQ_NVB;
+        constexpr int NVB = (NX - B0) < NVBMAX ? (NX - B0) : NVBMAX;
         if (B0 < nlive) apply_quad<RP, NX, B0, NVB>(Mn, X, q); // wave-uniform
-        apply_live<RP, NX, B0 + NVB>(Mn, X, nlive, q);
+        apply_live<RP, NX, B0 + NVB, NVBMAX>(Mn, X, nlive, q);
     }
 }
 
@@ -575,6 +575,9 @@ __device__ inline void quad_glds(double *dst, const double *img, int n_doubles)
     }
 }
 
+#ifndef FQD_NVB
+#define FQD_NVB 3 // vectors per pass in the duo kernel's fold: a wavefront's live count is 1, 3, 5, ... (3: 0.656, 4: 0.661, 2: 0.668, 5: 0.690 ms on quad10d)
+#endif
 __host__ __device__ constexpr int duo_count(int n, int parity) { return n > parity ? (n - parity + 1) / 2 : 0; } // distances 0..n-1 of that parity
 
 template <class Model, int RP, int K, int NWV, bool DBUF, int H>
@@ -684,7 +687,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                     }
                 } else if (!(A.dbg & 256)) {
                     if (mine) apply_quad_pair<RP>(sM + lo * ns, sM + hi * ns, XR[0], T0, T1, q);
-                    apply_live<RP, 1 + NR, 0>(sM + nd * ns, XR, nlive, q);
+                    apply_live<RP, 1 + NR, 0, FQD_NVB>(sM + nd * ns, XR, nlive, q);
                 }
                 if constexpr (NR > 0) {
                     if (mine) {
@@ -733,7 +736,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                     }
                 } else if (!(A.dbg & 256)) {
                     if (mine) apply_quad_pair<RP>(sM + lo * ns, sM + hi * ns, XL[0], T0, T1, q);
-                    apply_live<RP, 1 + NL, 0>(sM + nd * ns, XL, nlive, q);
+                    apply_live<RP, 1 + NL, 0, FQD_NVB>(sM + nd * ns, XL, nlive, q);
                 }
                 if constexpr (NL > 0) {
                     if (mine) {
@@ -769,26 +772,29 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
         const bool forced = A.forced != nullptr;
         const int rounds = (N + 3) / 4;
 
-        // ---- pass 1: node values, alternate rounds per wavefront
-        for (int r = H; r < ((A.dbg & 2048) ? 0 : rounds); r += 2) {
-            const int j0 = 4 * r;
-            const int jn[4] = {min(j0, N - 1), min(j0 + 1, N - 1), min(j0 + 2, N - 1), min(j0 + 3, N - 1)};
-            double vs[4];
-            if constexpr (K > 0) {
-                double c[4][C];
-                round_c(jn, c);
+        // Node values v_j = L G_k[j] R (the dim-K neighbours of a node and its own value) come out of the c products wavefront 0
+        // forms anyway: it writes the values of a block's eight nodes into the pair's LDS row, wavefront 1 adds the one node after
+        // the block (and, under a periodic boundary, node N-2 before the first block) with a single-node product.
+        static_assert(H != 0 || (K > 0 ? NL > 0 : NR > 0), "wavefront 0 forms the product the node values come from");
+        auto one_value = [&](int jx) __attribute__((always_inline)) { // lanes q == 0 write v[jx]
+            double vs = 0.0;
+            if constexpr (K == 0) {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) vs[jj] = dot_c<C>(XL[0], c[jj]);
+                for (int i = 0; i < C; i++) vs = fma(ro[A.core_off[K] + (size_t)jx * RP + q * C + i], XR[0][i], vs);
+            } else if constexpr (K == D - 1) {
+#pragma unroll
+                for (int i = 0; i < C; i++) vs = fma(XL[0][i], ro[A.core_off[K] + (size_t)jx * RP + q * C + i], vs);
             } else {
-                double a[4][C];
-                round_a(jn, a);
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) vs[jj] = dot_c<C>(a[jj], XR[0]);
+                double c1[C];
+                mfma_prod<RP>(aopK + (size_t)jx * quad_aop_node(RP), XR[0], c1, lane);
+                vs = dot_c<C>(XL[0], c1);
             }
-            const double v = reduce4(vs[0], vs[1], vs[2], vs[3]);
-            if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+            const double v = reduce4(vs, 0.0, 0.0, 0.0);
+            if (q == 0) sV[jx * 16 + t] = v;
+        };
+        if constexpr (H == 1) {
+            if (bck == C3SC_PERIODIC && N > 2) one_value(N - 2); // wave-uniform
         }
-        quad_barrier();
 
         // own half of the stencil of a round: lane (q, t) ends with the values of node j0 + q of fiber t
         auto stencil_own = [&](int j0, double (&V)[S]) __attribute__((always_inline)) {
@@ -796,6 +802,10 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
             if constexpr (K > 0 && NL > 0) {
                 double c[4][C];
                 round_c(jn, c);
+                if constexpr (H == 0) {
+                    const double v = reduce4(dot_c<C>(XL[0], c[0]), dot_c<C>(XL[0], c[1]), dot_c<C>(XL[0], c[2]), dot_c<C>(XL[0], c[3]));
+                    if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+                }
 #pragma unroll
                 for (int i = 0; i < K; i++) {
                     if ((i & 1) != H) continue;
@@ -810,6 +820,10 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
             if constexpr (K < D - 1 && NR > 0) {
                 double a[4][C];
                 round_a(jn, a);
+                if constexpr (H == 0 && K == 0) {
+                    const double v = reduce4(dot_c<C>(a[0], XR[0]), dot_c<C>(a[1], XR[0]), dot_c<C>(a[2], XR[0]), dot_c<C>(a[3], XR[0]));
+                    if (j0 + q < N) sV[(j0 + q) * 16 + t] = v;
+                }
 #pragma unroll
                 for (int i = 0; i < D - 1 - K; i++) {
                     if ((i & 1) != 1 - H) continue;
@@ -850,7 +864,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
         // is stencil entry e = 2m + s (m != K) formed by wavefront h?
         auto owner_of = [](int m) __attribute__((always_inline)) -> int { return m < K ? ((K - 1 - m) & 1) : 1 - ((m - K - 1) & 1); };
 
-        // ---- pass 2: blocks of two rounds
+        // ---- node loop: blocks of two rounds
         for (int b = 0; 2 * b < ((A.dbg & 4096) ? 0 : rounds); b++) {
             double Vm[S];
 #pragma unroll
@@ -870,6 +884,9 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                             if (m != K && owner_of(m) == H) { sX[(2 * m) * 64 + lane] = Vh[2 * m]; sX[(2 * m + 1) * 64 + lane] = Vh[2 * m + 1]; }
                     }
                 }
+            }
+            if constexpr (H == 1) {
+                if (8 * b + 8 < N) one_value(8 * b + 8); // the right neighbour of the block's last node
             }
             quad_barrier();
             if (2 * b + H < rounds) {

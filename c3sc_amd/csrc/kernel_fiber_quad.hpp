@@ -621,19 +621,23 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
         const long f_raw = tile * per_tile + pw * 16 + t;
         const bool flive = f_raw < A.F;
         const long f = flive ? f_raw : A.F - 1;
-        int fi[D];
-        double x[D];
+        // The fiber's indices go to LDS (the run-time level loops and the node loop read them there); coordinates and table
+        // values are fetched again where a node is finalised instead of living in 30 registers through the fold.
         bool fiber_abs = false;
+        {
+            int fi[D];
 #pragma unroll
-        for (int m = 0; m < D; m++) {
-            fi[m] = (m == K) ? 0 : idx[f * D + m];
-            int lo, hi;
-            const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], lo, hi);
-            if (m != K) fiber_abs = fiber_abs || face;
-            x[m] = ro[A.xg_off[m] + fi[m]];
+            for (int m = 0; m < D; m++) {
+                fi[m] = (m == K) ? 0 : idx[f * D + m];
+                int lo, hi;
+                const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], lo, hi);
+                if (m != K) fiber_abs = fiber_abs || face;
+            }
+            if (H == 0 && q == 0) {
+#pragma unroll
+                for (int m = 0; m < D; m++) sIx[m * 16 + t] = fi[m];
+            }
         }
-        double tvf[Model::NTAB > 0 ? Model::NTAB : 1];
-        table_values<Model>(A, ro, fi, tvf);
 
         double XL[1 + NL][C], XR[1 + NR][C]; // [0] = L / R, then this wave's neighbour vectors, nearest own dimension first
 #pragma unroll
@@ -648,10 +652,6 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
         // ---- folding, level by level: the suffix side (m = D-1 .. K+1), then the prefix side (m = 0 .. K-1).  Level l's core
         // image goes into staging buffer l & 1 by LDS-DMA while level l-1 is being applied: one barrier per level, and the copy
         // (51 KB from L2 at rank 16) is hidden behind the products instead of stopping all eight wavefronts.
-        if (H == 0 && q == 0) {
-#pragma unroll
-            for (int m = 0; m < D; m++) sIx[m * 16 + t] = fi[m]; // the level loops are run-time loops: indices by LDS, not by scratch
-        }
         if constexpr (DBUF) level_issue(0);
         if constexpr (K < D - 1) {
             int nlive = 1;
@@ -839,7 +839,15 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
         auto finalize = [&](int j0, double (&V)[S]) __attribute__((always_inline)) {
             const bool nlive = (j0 + q < N);
             const int j = nlive ? j0 + q : N - 1;
-            x[K] = ro[A.xg_off[K] + j];
+            int fi[D];
+            double x[D];
+#pragma unroll
+            for (int m = 0; m < D; m++) {
+                fi[m] = (m == K) ? j : sIx[m * 16 + t];
+                x[m] = ro[A.xg_off[m] + fi[m]];
+            }
+            double tvf[Model::NTAB > 0 ? Model::NTAB : 1];
+            table_values<Model>(A, ro, fi, tvf);
             int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
@@ -850,7 +858,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
             double tv[Model::NTAB > 0 ? Model::NTAB : 1];
             tv[0] = 0.0;
 #pragma unroll
-            for (int tt = 0; tt < Model::NTAB; tt++) tv[tt] = (Model::tab_dim(tt) == K) ? ro[A.tab_off[tt] + j] : tvf[tt];
+            for (int tt = 0; tt < Model::NTAB; tt++) tv[tt] = tvf[tt]; // fi[K] = j: tables indexed by dim K included
             int ui = 0;
             const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
             double val = V[0] + V[2 * D - 1];

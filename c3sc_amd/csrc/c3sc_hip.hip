@@ -675,6 +675,7 @@ static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx
         c->last_kernel = e->name;
         he = e->fn(A, io);
         if (he != hipErrorOutOfMemory && he != hipErrorNotSupported) break;
+        if (getenv("C3SC_VERBOSE")) fprintf(stderr, "c3sc: %s declined (%s), trying the next instantiation\n", e->name, hipGetErrorName(he));
         declined.push_back(e);
     }
     g_launches++;

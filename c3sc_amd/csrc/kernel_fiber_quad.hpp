@@ -575,6 +575,12 @@ __device__ inline void quad_glds(double *dst, const double *img, int n_doubles)
     }
 }
 
+#ifndef FQD_PREFETCH
+#define FQD_PREFETCH 1 // the next tile's indices and first core are requested during this tile's node loop (0: at the top of the tile)
+#endif
+#ifndef FQD_CG
+#define FQD_CG 1 // control candidates in flight in the duo kernel's scan (3: 0.597 vs 0.588 ms on quad10d)
+#endif
 #ifndef FQD_NVB
 #define FQD_NVB 3 // vectors per pass in the duo kernel's fold: a wavefront's live count is 1, 3, 5, ... (3: 0.656, 4: 0.661, 2: 0.668, 5: 0.690 ms on quad10d)
 #endif
@@ -599,7 +605,10 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
     auto sMbuf = [&](int l) __attribute__((always_inline)) -> double * { return DBUF ? smem + (l & 1) * A.quad_m1_off : smem; };
     double *sV = smem + A.quad_sv_off + pw * (N * 16);      // node values of the pair's 16 fibers: [N][16]
     double *sX = smem + A.quad_x_off + pw * (2 * D * 64);   // half stencils on their way to the partner: [2D][64]
-    int *sIx = reinterpret_cast<int *>(smem + A.quad_ix_off) + pw * (D * 16); // the pair's fiber indices: [D][16]
+    // the pair's fiber indices [16][D], two sets: the next tile's arrive by LDS-DMA while this tile's nodes are finalised
+    auto sIxb = [&](int par) __attribute__((always_inline)) -> int * {
+        return reinterpret_cast<int *>(smem + A.quad_ix_off) + pw * (2 * 16 * D) + par * (16 * D);
+    };
     constexpr int NLEV = D - 1, NRL = D - 1 - K;            // folding levels: l < NRL suffix side (m = D-1-l), then prefix (m = l-NRL)
     auto level_issue = [&](int l) __attribute__((always_inline)) {
         const bool right = l < NRL;
@@ -616,26 +625,40 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
     }
     const long per_tile = 16L * (NWV / 2), ntiles = (A.F + per_tile - 1) / per_tile;
     const double *aopK = ro + A.quad_aop_off[K];
+    // The 16 x D indices of a pair's fibers are contiguous in the batch: copied as they are (fibers past the end of the batch
+    // repeat the last one), 4 bytes per lane, both wavefronts of the pair take part.
+    auto idx_issue = [&](long tl, int par) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        const long f0 = tl * per_tile + pw * 16;
+        int *dst = sIxb(par);
+#pragma unroll
+        for (int p0 = H * 64; p0 < 16 * D; p0 += 128) {
+            const int p = p0 + lane;
+            if (p < 16 * D) {
+                long fb = f0 + p / D;
+                fb = fb < A.F ? fb : A.F - 1;
+                __builtin_amdgcn_global_load_lds((glb_void *)(idx + fb * D + p % D), (lds_void *)(dst + p0), 4, 0, 0);
+            }
+        }
+    };
+    int par = 0;
+    if constexpr (DBUF) { // the first tile's indices and first core; later ones are requested during the previous tile's node loop
+        if (FQD_PREFETCH && (long)blockIdx.x < ntiles) { idx_issue(blockIdx.x, 0); level_issue(0); }
+    }
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
         const long f_raw = tile * per_tile + pw * 16 + t;
         const bool flive = f_raw < A.F;
         const long f = flive ? f_raw : A.F - 1;
-        // The fiber's indices go to LDS (the run-time level loops and the node loop read them there); coordinates and table
-        // values are fetched again where a node is finalised instead of living in 30 registers through the fold.
-        bool fiber_abs = false;
-        {
-            int fi[D];
-#pragma unroll
-            for (int m = 0; m < D; m++) {
-                fi[m] = (m == K) ? 0 : idx[f * D + m];
-                int lo, hi;
-                const bool face = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], lo, hi);
-                if (m != K) fiber_abs = fiber_abs || face;
-            }
+        // The fiber's indices live in LDS (the run-time level loops and the node loop read them there); coordinates, table values
+        // and boundary flags are formed where a node is finalised instead of living in 30 registers through the fold.
+        const int *sI = sIxb(par);
+        if constexpr (DBUF && !FQD_PREFETCH) { idx_issue(tile, par); level_issue(0); }
+        if constexpr (!DBUF) {
             if (H == 0 && q == 0) {
 #pragma unroll
-                for (int m = 0; m < D; m++) sIx[m * 16 + t] = fi[m];
+                for (int m = 0; m < D; m++) sIxb(par)[t * D + m] = idx[f * D + m];
             }
         }
 
@@ -652,7 +675,6 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
         // ---- folding, level by level: the suffix side (m = D-1 .. K+1), then the prefix side (m = 0 .. K-1).  Level l's core
         // image goes into staging buffer l & 1 by LDS-DMA while level l-1 is being applied: one barrier per level, and the copy
         // (51 KB from L2 at rank 16) is hidden behind the products instead of stopping all eight wavefronts.
-        if constexpr (DBUF) level_issue(0);
         if constexpr (K < D - 1) {
             int nlive = 1;
 #pragma nounroll
@@ -672,7 +694,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                     quad_barrier();
                 }
                 const double *sM = sMbuf(l);
-                const int nd = sIx[m * 16 + t];
+                const int nd = sI[t * D + m];
                 int lo, hi;
                 (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
                 double T0[C], T1[C];
@@ -721,7 +743,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                     quad_barrier();
                 }
                 const double *sM = sMbuf(l);
-                const int nd = sIx[m * 16 + t];
+                const int nd = sI[t * D + m];
                 int lo, hi;
                 (void)fixed_neighbors(nd, A.ngrid[m], A.bctype[m], lo, hi);
                 double T0[C], T1[C];
@@ -841,10 +863,15 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
             const int j = nlive ? j0 + q : N - 1;
             int fi[D];
             double x[D];
+            bool fiber_abs = false; // an absorbing face in a fixed dimension absorbs the whole fiber (nodeutil.c:515-523)
 #pragma unroll
             for (int m = 0; m < D; m++) {
-                fi[m] = (m == K) ? j : sIx[m * 16 + t];
+                fi[m] = (m == K) ? j : sI[t * D + m];
                 x[m] = ro[A.xg_off[m] + fi[m]];
+                if (m != K) {
+                    int flo, fhi;
+                    fiber_abs = fixed_neighbors(fi[m], A.ngrid[m], A.bctype[m], flo, fhi) || fiber_abs;
+                }
             }
             double tvf[Model::NTAB > 0 ? Model::NTAB : 1];
             table_values<Model>(A, ro, fi, tvf);
@@ -862,7 +889,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
             int ui = 0;
             const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
             double val = V[0] + V[2 * D - 1];
-            if (!(A.dbg & 1024)) val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+            if (!(A.dbg & 1024)) val = node_backup<Model, FQD_CG, FQD_CG, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
             if (nlive && flive) {
                 outv[(size_t)f * N + j] = val;
                 if (uidx) uidx[(size_t)f * N + j] = ui;
@@ -897,6 +924,9 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
                 if (8 * b + 8 < N) one_value(8 * b + 8); // the right neighbour of the block's last node
             }
             quad_barrier();
+            if constexpr (DBUF) { // every wavefront is past the fold: both staging buffers are free until the next tile
+                if (FQD_PREFETCH && b == 0 && tile + gridDim.x < ntiles) { idx_issue(tile + gridDim.x, par ^ 1); level_issue(0); }
+            }
             if (2 * b + H < rounds) {
 #pragma unroll
                 for (int m = 0; m < D; m++)

@@ -71,7 +71,7 @@ hipError_t launch_fq_duo(const KArgs &A, const LaunchIO &io)
     B.quad_sv_off = (int)doubles;
     doubles += (size_t)(NWV / 2) * A.N * 16; // node values of each pair's 16 fibers
     B.quad_ix_off = (int)doubles;
-    doubles += (size_t)(NWV / 2) * D * 8; // fiber indices [D][16] ints per pair
+    doubles += (size_t)(NWV / 2) * 2 * D * 8; // fiber indices [16][D] ints per pair, this tile's and the next one's
     B.quad_x_off = (int)doubles;
     doubles += (size_t)(NWV / 2) * 2 * D * 64; // half stencils between the wavefronts of a pair
     B.tbl_off = (int)doubles;

@@ -27,6 +27,15 @@
 
 /* ------------------------------------------------------------------------------ small dense kernels */
 
+/* The dense loops below are compiled twice, for AVX2 and for the baseline ISA, and picked at load time (GNU ifunc): four
+ * doubles per vector instead of two.  Contraction into FMAs stays off (ISO C mode), so both clones compute the same bits. */
+#if defined(__GNUC__) && defined(__x86_64__) && !defined(__clang__)
+#define C3SC_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define C3SC_CLONES
+#endif
+
+
 /* dot product with four independent partial sums (the compiler may not reassociate a single one) */
 static inline double dotn(const double *x, const double *y, size_t n)
 {
@@ -40,7 +49,7 @@ static inline double dotn(const double *x, const double *y, size_t n)
 /* Householder QR of the m x n (m >= n) column-major matrix A: on exit A holds the thin orthonormal Q (m x n),
  * R (n x n, column-major, upper triangular) is written if not NULL.  Works for rank-deficient A (Q stays
  * orthonormal). */
-static void qr_thin(size_t m, size_t n, double *A, double *R)
+C3SC_CLONES static void qr_thin(size_t m, size_t n, double *A, double *R)
 {
     assert(m >= n);
     double *V = xcalloc(m * n, sizeof(double)); /* Householder vectors */
@@ -88,7 +97,7 @@ static void qr_thin(size_t m, size_t n, double *A, double *R)
 
 /* X = Q inv(S) (m x r) where S = Q[rows] is r x r: invert S by Gauss-Jordan with partial pivoting, then r^2
  * axpys over contiguous columns of Q. */
-static void right_solve(size_t m, size_t r, const double *Q, const size_t *rows, double *X)
+C3SC_CLONES static void right_solve(size_t m, size_t r, const double *Q, const size_t *rows, double *X)
 {
     double *T = xcalloc(r * 2 * r, sizeof(double)); /* [S | I], row-major, 2r per row */
     for (size_t i = 0; i < r; i++) {
@@ -124,9 +133,26 @@ static void right_solve(size_t m, size_t r, const double *Q, const size_t *rows,
 }
 
 #define TIE_EPS 1e-9
+/* The swap search of maxvol over one column: the running maximum with its tie margin (a later entry replaces the best so far
+ * only if it is larger by more than TIE_EPS relative) is a sequential rule, but a block of 16 entries none of which beats the
+ * current best cannot change it -- the block maximum is a vectorisable reduction, and the sequential rule then runs only
+ * inside the few blocks that matter.  Same result as scanning every entry. */
+static inline void scan_col_max(const double *col, size_t m, size_t j, double *best, size_t *bi, size_t *bj)
+{
+    size_t i0 = 0;
+    for (; i0 + 16 <= m; i0 += 16) {
+        double bm = 0.0;
+        for (size_t i = 0; i < 16; i++) { const double a = fabs(col[i0 + i]); bm = a > bm ? a : bm; }
+        if (!(bm > *best * (1.0 + TIE_EPS))) continue;
+        for (size_t i = i0; i < i0 + 16; i++)
+            if (fabs(col[i]) > *best * (1.0 + TIE_EPS)) { *best = fabs(col[i]); *bi = i; *bj = j; }
+    }
+    for (size_t i = i0; i < m; i++)
+        if (fabs(col[i]) > *best * (1.0 + TIE_EPS)) { *best = fabs(col[i]); *bi = i; *bj = j; }
+}
 /* maxvol: r rows of the m x r matrix Q (full column rank) whose submatrix has (locally) maximal volume;
  * B = Q inv(Q[rows]) has entries bounded by 1 + delta on exit. */
-static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
+C3SC_CLONES static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
 {
     /* start: pivoted Gaussian elimination picks r well-conditioned rows */
     double *W = xcalloc(m * r, sizeof(double));
@@ -156,29 +182,37 @@ static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
     free(W);
     free(used);
     right_solve(m, r, Q, rows, B);
+    /* Swap loop.  The largest entry is searched in column order (ties to the first, see above); the search for the NEXT swap
+     * rides along with the rank-1 update of the current one (each column is scanned right after it is updated), so B is
+     * walked once per swap instead of twice -- same arithmetic, same scan order, same result. */
+    double *rowv = xcalloc(r, sizeof(double)), *colv = xcalloc(m, sizeof(double));
+    size_t bi = 0, bj = 0;
+    double best = 0.0;
+    for (size_t j = 0; j < r; j++) scan_col_max(B + j * m, m, j, &best, &bi, &bj);
     for (int it = 0; it < 200; it++) {
-        size_t bi = 0, bj = 0;
-        double best = 0.0;
-        for (size_t j = 0; j < r; j++)
-            for (size_t i = 0; i < m; i++)
-                if (fabs(B[i + j * m]) > best * (1.0 + TIE_EPS)) { best = fabs(B[i + j * m]); bi = i; bj = j; }
         if (best <= 1.0 + 1e-2) break;
         /* swap row rows[bj] for row bi: B <- B - B[:,bj] (B[bi,:] - e_bj) / B[bi,bj] */
         const double piv = B[bi + bj * m];
-        double *rowv = xcalloc(r, sizeof(double)), *colv = xcalloc(m, sizeof(double));
         for (size_t j = 0; j < r; j++) rowv[j] = B[bi + j * m] - (j == bj ? 1.0 : 0.0);
         for (size_t i = 0; i < m; i++) colv[i] = B[i + bj * m] / piv;
-        for (size_t j = 0; j < r; j++)
-            if (rowv[j] != 0.0)
-                for (size_t i = 0; i < m; i++) B[i + j * m] -= colv[i] * rowv[j];
         rows[bj] = bi;
-        free(rowv); free(colv);
+        size_t nbi = 0, nbj = 0;
+        double nbest = 0.0;
+        for (size_t j = 0; j < r; j++) {
+            double *bcol = B + j * m;
+            const double rj = rowv[j];
+            if (rj != 0.0)
+                for (size_t i = 0; i < m; i++) bcol[i] -= colv[i] * rj;
+            scan_col_max(bcol, m, j, &nbest, &nbi, &nbj);
+        }
+        best = nbest; bi = nbi; bj = nbj;
     }
+    free(rowv); free(colv);
 }
 
 /* One-sided Jacobi SVD of the m x n (m >= n) column-major A: on exit A = U diag(S) (columns sorted by
  * decreasing S), V (n x n) the right singular vectors. */
-static void svd_jacobi(size_t m, size_t n, double *A, double *S, double *V)
+C3SC_CLONES static void svd_jacobi(size_t m, size_t n, double *A, double *S, double *V)
 {
     for (size_t i = 0; i < n * n; i++) V[i] = 0.0;
     for (size_t i = 0; i < n; i++) V[i + i * n] = 1.0;
@@ -281,7 +315,7 @@ static struct ValueF *valuef_from_tt(const struct tt *t, double **grid)
 
 /* right-to-left orthogonalisation: afterwards cores 1..d-1 have orthonormal rows (right unfolding) and
  * ||T||_F = ||G_0||_F.  Ranks may shrink when r_k > N_k r_{k+1}. */
-static void tt_orthogonalize_rl(struct tt *t)
+C3SC_CLONES static void tt_orthogonalize_rl(struct tt *t)
 {
     for (size_t k = t->d - 1; k >= 1; k--) {
         const size_t r0 = t->r[k], N = t->N[k], r1 = t->r[k + 1], cols = N * r1;
@@ -338,7 +372,7 @@ static double tt_frob_of_core0(const struct tt *t)
 }
 
 /* TT rounding to relative accuracy eps in the nodal Frobenius norm (ranks never exceed maxrank) */
-static void tt_round(struct tt *t, double eps)
+C3SC_CLONES static void tt_round(struct tt *t, double eps)
 {
     if (t->d < 2) return;
     tt_orthogonalize_rl(t);
@@ -411,7 +445,7 @@ static struct tt *tt_diff(const struct tt *a, const struct tt *b)
 /* <a, b> = sum over all nodes of a*b, by carrying the r^a_k x r^b_k Gram matrix through the cores.  Cheap (two small
  * matrix products per core) but a difference of such products resolves ||a - b|| only down to ~1e-7 ||a||: callers
  * use it when the answer is far above that and fall back to orthogonalisation otherwise. */
-static double tt_dot(const struct tt *a, const struct tt *b)
+C3SC_CLONES static double tt_dot(const struct tt *a, const struct tt *b)
 {
     const size_t d = a->d;
     size_t rmax = 1;

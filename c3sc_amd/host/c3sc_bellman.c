@@ -691,6 +691,8 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
     char key[256];
     struct FmFiber ff;
     unsigned char *need = xcalloc(F, 1), *hit = xcalloc(F * N, 1);
+    size_t *slot = fast ? xcalloc(F * N, sizeof(size_t)) : NULL; /* where a missing node will be stored (fastmemo_fiber_put_at) */
+    const size_t cap_then = fast ? fastmemo_cap(fm) : 0;
     for (size_t f = 0; f < F; f++) {
         for (size_t m = 0; m < dx; m++) ser[m] = (size_t)idx[f * dx + m];
         ser[dx] = 0;           /* bellman.c:1337 */
@@ -700,7 +702,8 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
             double v = 0.0;
             int found;
             if (fast) {
-                found = c3sc_memo_bypass ? 0 : fastmemo_fiber_get(fm, &ff, j, &v);
+                found = fastmemo_fiber_get_slot(fm, &ff, j, &v, &slot[f * N + j]);
+                if (c3sc_memo_bypass) found = 0;
             } else {
                 ser[k0] = j;
                 size_t_a_to_char(ser, dx + 2, key);
@@ -767,7 +770,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
                 if (hit[f * N + j]) continue;
                 out[f * N + j] = rout[r * N + j];
                 if (fast) {
-                    if (!c3sc_memo_bypass) fastmemo_fiber_put(fm, &ff, j, out[f * N + j]);
+                    if (!c3sc_memo_bypass) fastmemo_fiber_put_at(fm, &ff, j, out[f * N + j], slot[f * N + j], cap_then);
                 } else {
                     ser[k0] = j;
                     size_t_a_to_char(ser, dx + 2, key);
@@ -781,7 +784,7 @@ static int vi_core(struct VIparam *vi, size_t F, size_t k0, const int32_t *idx, 
         free(ridx); free(rout); free(rabs); free(x_own);
         g_t_store += now_s() - t_dev;
     }
-    free(need); free(hit);
+    free(need); free(hit); free(slot);
     return 0;
 }
 

@@ -630,6 +630,31 @@ int fastmemo_fiber_get(const struct FastMemo *m, struct FmFiber *ff, size_t j, d
     *val = e->v;
     return 1;
 }
+void fastmemo_fiber_put(struct FastMemo *m, struct FmFiber *ff, size_t j, double val);
+/* Lookup that also reports where the key would go (the first empty slot of its probe sequence), and an insert that uses
+ * that slot if the table has not been rebuilt and the slot is still empty -- then it is still the first empty slot of the
+ * sequence and the key cannot have been stored in between (it would sit there).  The batch entry points look every node up,
+ * launch the misses and store them: the second probe sequence per stored node goes away. */
+size_t fastmemo_cap(const struct FastMemo *m) { return m->cap; }
+int fastmemo_fiber_get_slot(const struct FastMemo *m, struct FmFiber *ff, size_t j, double *val, size_t *slot)
+{
+    ff->key[ff->word] = ff->base | ((uint64_t)(j & 0xffffu) << ff->shift);
+    const size_t i = fm_find_pre(m, ff->pre0 + (uint64_t)(j & 0xffffu) * ff->step, ff->key);
+    *slot = i;
+    if (m->e[i].epoch != m->epoch) return 0;
+    *val = m->e[i].v;
+    return 1;
+}
+void fastmemo_fiber_put_at(struct FastMemo *m, struct FmFiber *ff, size_t j, double val, size_t slot, size_t cap_then)
+{
+    if (m->cap != cap_then || 2 * (m->used + 1) > m->cap || m->e[slot].epoch == m->epoch) { fastmemo_fiber_put(m, ff, j, val); return; }
+    ff->key[ff->word] = ff->base | ((uint64_t)(j & 0xffffu) << ff->shift);
+    struct FmEntry *e = &m->e[slot];
+    memcpy(e->k, ff->key, 4 * sizeof(uint64_t));
+    e->v = val;
+    e->epoch = m->epoch;
+    m->used++;
+}
 void fastmemo_fiber_put(struct FastMemo *m, struct FmFiber *ff, size_t j, double val)
 {
     ff->key[ff->word] = ff->base | ((uint64_t)(j & 0xffffu) << ff->shift);

@@ -129,6 +129,9 @@ void fastmemo_fiber_counter(struct FmFiber *ff, uint64_t c0, uint64_t c1);
 void fastmemo_fiber_prefetch(const struct FastMemo *, const struct FmFiber *ff, size_t n); /* warm the n home slots */
 int fastmemo_fiber_get(const struct FastMemo *, struct FmFiber *ff, size_t j, double *val);
 void fastmemo_fiber_put(struct FastMemo *, struct FmFiber *ff, size_t j, double val);
+size_t fastmemo_cap(const struct FastMemo *);
+int fastmemo_fiber_get_slot(const struct FastMemo *, struct FmFiber *ff, size_t j, double *val, size_t *slot); /* + where the key would go */
+void fastmemo_fiber_put_at(struct FastMemo *, struct FmFiber *ff, size_t j, double val, size_t slot, size_t cap_then); /* insert there if still valid */
 struct FastMemo *workspace_get_vi_fastmemo(const struct Workspace *);
 struct FastMemo *workspace_get_pi_prob_fastmemo(const struct Workspace *);
 /* new: the MI355X engine this workspace drives (created on first use; aborts if no GPU) */

@@ -127,7 +127,7 @@ def solver_measurements(workload, budget_s):
     L.diag_count.restype = C.c_size_t
     w = wl.WORKLOADS[workload]()
     d = w.dx
-    ctl = facade_lib.Control(w)
+    ctl = facade_lib.Control(w, consistent_ends=None)  # the library's default (c3control_set_consistent_ends: on)
     rmax = max(w.ranks)
 
     def aargs(cross, rnd, kick, start, maxrank):

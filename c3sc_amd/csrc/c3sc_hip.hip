@@ -132,6 +132,7 @@ struct c3sc_hip_ctx {
     std::vector<double> xgrid_flat;
     int xg_off_rel[MAXD] = {0};
     int bctype[MAXD] = {0};
+    int cends = 0; // c3sc_hip_set_consistent_ends
     bool have_boundary = false;
     int nobs = 0;
     std::vector<double> obs; // [nobs][2][d]
@@ -395,6 +396,13 @@ int c3sc_hip_set_boundary(c3sc_hip_ctx *c, const int *bctype, int nobs, const do
     return C3SC_OK;
 }
 
+int c3sc_hip_set_consistent_ends(c3sc_hip_ctx *c, int on)
+{
+    if (!c) return C3SC_ERR_ARG;
+    c->cends = on ? 1 : 0;
+    return C3SC_OK;
+}
+
 int c3sc_hip_set_mca(c3sc_hip_ctx *c, double h2, const double *t, double discount)
 {
     if (!c || c->d == 0 || !t) return fail(c, C3SC_ERR_ARG, "set_mca: set_grid first");
@@ -628,6 +636,7 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
         A.quad_imgR_off[m] = c->qimgR_off[m];
     }
     A.img_base = c->arena;
+    A.cends = c->cends;
     A.nobs = c->nobs;
     A.obs_off = c->obs_off;
     A.cands_off = c->cands_off;

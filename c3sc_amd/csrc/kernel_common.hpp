@@ -55,6 +55,7 @@ struct KArgs {
     long quad_imgL_off[MAXD];  // duo kernel: LDS images (node stride elems + 2) of the cores as the prefix side stages them
     long quad_imgR_off[MAXD];  //             and of the transposed cores (suffix side); read through img_base by LDS-DMA
     long pair_img_off[MAXD];   // every core once more as the fiber-pair kernel's LDS image: [N][elems | 1] (k_core_image)
+    int cends;                 // c3sc_hip_set_consistent_ends: see vary_neighbors
     const double *img_base;    // the arena again, as a pointer that is NOT the kernels' `ro` argument: the LDS-DMA copy reads the
                                // images through it (see stage_core_image on why it must not be derived from `ro`)
 };
@@ -96,17 +97,21 @@ __device__ inline bool fixed_neighbors(int i, int n, int bc, int &lo, int &hi)
 // Neighbour indices of node j along the VARYING dimension and the final absorbed flag:
 // nodeutil.c:570-624 (end points are overwritten by dim_vary's own boundary type -- quirk Q3).
 // `ab_in` is the flag after the obstacle test and the fixed-face test.
-__device__ inline int vary_neighbors(int j, int n, int bc, int ab_in, int &lo, int &hi)
+// keep_ends (KArgs::cends, c3sc_hip_set_consistent_ends; NOT the reference's behaviour, default 0): the end points of a
+// reflecting / periodic fiber keep `ab_in` instead of being reset to 0, i.e. the flag every other fiber direction gives that
+// node -- the value of a node then no longer depends on the direction of the fiber it is computed in.
+__device__ inline int vary_neighbors(int j, int n, int bc, int ab_in, int &lo, int &hi, int keep_ends = 0)
 {
     int ab = ab_in;
+    const int ab_end = keep_ends ? ab_in : 0;
     if (j == 0) {
         if (bc == C3SC_ABSORB) { lo = 0; hi = 0; ab = 1; }
-        else if (bc == C3SC_REFLECT) { lo = 0; hi = 1; ab = 0; }
-        else { lo = n - 2; hi = 1; ab = 0; }
+        else if (bc == C3SC_REFLECT) { lo = 0; hi = 1; ab = ab_end; }
+        else { lo = n - 2; hi = 1; ab = ab_end; }
     } else if (j == n - 1) {
         if (bc == C3SC_ABSORB) { lo = n - 1; hi = n - 1; ab = 1; }
-        else if (bc == C3SC_REFLECT) { lo = n - 2; hi = n - 1; ab = 0; }
-        else { lo = n - 2; hi = 1; ab = 0; }
+        else if (bc == C3SC_REFLECT) { lo = n - 2; hi = n - 1; ab = ab_end; }
+        else { lo = n - 2; hi = 1; ab = ab_end; }
     } else if (ab == 0) {
         lo = j - 1;
         hi = j + 1;

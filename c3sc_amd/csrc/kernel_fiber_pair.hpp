@@ -530,7 +530,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             int ab = (obs_fixed & nr.mask_at(jn)) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
-            ab = vary_neighbors(jn, N, bck, ab, lo, hi);
+            ab = vary_neighbors(jn, N, bck, ab, lo, hi, A.cends);
             int ui;
             FPP_STAMP(8) // exchange reads + stencil assembly + flags
             // FORCED (policy evaluation) is a separate instantiation: as a run-time flag it costs the minimising kernel 4 %

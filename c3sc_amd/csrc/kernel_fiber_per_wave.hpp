@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
             int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
-            ab = vary_neighbors(jj, N, A.bctype[k], ab, lo, hi);
+            ab = vary_neighbors(jj, N, A.bctype[k], ab, lo, hi, A.cends);
             if constexpr (STENCIL) {
                 if (nbv) {
                     lo = nbv[(f * N + jj) * 2];

@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
-            ab = vary_neighbors(j, N, bck, ab, lo, hi);
+            ab = vary_neighbors(j, N, bck, ab, lo, hi, A.cends);
             V[2 * K] = sV[svslot(lo) * 16 + t];
             V[2 * K + 1] = sV[svslot(hi) * 16 + t];
             V[2 * D] = sV[svslot(j) * 16 + t];
@@ -878,7 +878,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
             int ab = in_obstacle<D>(A, ro, x) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
-            ab = vary_neighbors(j, N, bck, ab, lo, hi);
+            ab = vary_neighbors(j, N, bck, ab, lo, hi, A.cends);
             V[2 * K] = sV[lo * 16 + t];
             V[2 * K + 1] = sV[hi * 16 + t];
             V[2 * D] = sV[j * 16 + t];

@@ -294,7 +294,8 @@ int process_fibers_neighbor(size_t d, const size_t *fixed_ind, size_t dim_vary, 
     /* end points follow dim_vary's own boundary type and overwrite the flags above (quirk Q3) */
     const enum EBTYPE b = boundary_type_dim(bound, dim_vary, 0);
     if (b != ABSORB && b != REFLECT && b != PERIODIC) { fprintf(stderr, "Should not be here!\n"); assert(0); }
-    absorbed[0] = absorbed[N - 1] = (b == ABSORB);
+    if (b == ABSORB) absorbed[0] = absorbed[N - 1] = 1;
+    else if (!boundary_get_consistent_ends(bound)) absorbed[0] = absorbed[N - 1] = 0; /* else: boundary_set_consistent_ends keeps them */
     for (size_t j = 0; j < N; j++) {
         size_t lo = j, hi = j;
         if (j == 0) { if (b == REFLECT) hi = 1; else if (b == PERIODIC) { lo = N - 2; hi = 1; } }
@@ -543,6 +544,8 @@ static struct c3sc_hip_ctx *sync_device_ctx(struct ControlParams *cp, struct c3s
     sig = fnv(sig, &dp->model, sizeof(int));
     sig = fnv(sig, dp->prm, sizeof(dp->prm));
     sig = fnv(sig, &brute, sizeof(int));
+    const int cends = boundary_get_consistent_ends(dp->bound);
+    sig = fnv(sig, &cends, sizeof(int));
     if (brute) sig = fnv(sig, c3opt_get_brute_vals(cp->opt), c3opt_get_nbrute(cp->opt) * odu * sizeof(double));
     else {
         const size_t g = c3opt_get_box_grid(cp->opt), pl = c3opt_get_box_polish(cp->opt);
@@ -556,6 +559,7 @@ static struct c3sc_hip_ctx *sync_device_ctx(struct ControlParams *cp, struct c3s
         hipok(ctx, c3sc_hip_set_grid(ctx, (int)d, mca->ngrid, (const double *const *)mca->xgrid), "c3sc_hip_set_grid");
         hipok(ctx, c3sc_hip_set_boundary(ctx, bc, (int)nobs, lb, ub), "c3sc_hip_set_boundary");
         hipok(ctx, c3sc_hip_set_mca(ctx, mca->h2, mca->t, dp->discount), "c3sc_hip_set_mca");
+        hipok(ctx, c3sc_hip_set_consistent_ends(ctx, cends), "c3sc_hip_set_consistent_ends");
         if (dp->model != 0) hipok(ctx, c3sc_hip_set_model(ctx, dp->model, dp->prm, dp->nprm), "c3sc_hip_set_model");
         if (brute)
             hipok(ctx, c3sc_hip_set_controls(ctx, (int)c3opt_get_nbrute(cp->opt), (int)odu, c3opt_get_brute_vals(cp->opt)), "c3sc_hip_set_controls");
@@ -1093,6 +1097,7 @@ struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, 
         if (ngrid[m] > maxn) maxn = ngrid[m];
     }
     c->bound = boundary_alloc(dx, lb, ub);
+    boundary_set_consistent_ends(c->bound, getenv("C3SC_LITERAL_ENDS") == NULL); /* see c3control_set_consistent_ends */
     c->mca = mca_param_create(dx, du);
     mca_add_grid_refs(c->mca, c->ngrid, c->xgrid, c->hmin, c->h);
     c->dp = dp_param_create(dx, du, dw, discount);
@@ -1121,6 +1126,14 @@ void c3control_add_stagecost(struct C3Control *c, int (*f)(double, const double 
 void c3control_add_boundcost(struct C3Control *c, int (*f)(double, const double *, double *)) { dp_param_add_boundcost(c->dp, f); }
 void c3control_add_obscost(struct C3Control *c, int (*f)(const double *, double *)) { dp_param_add_obscost(c->dp, f); }
 void c3control_set_device_model(struct C3Control *c, int model, const double *params, size_t n) { dp_param_set_device_model(c->dp, model, params, n); }
+
+void c3control_set_consistent_ends(struct C3Control *c, int on)
+{ /* new, default ON for a C3Control (c3control_create): the solver's fiber function is a function of the node.  The reference's
+     own value at the nodes concerned depends on the order in which C3's cross approximation happens to visit them (first memo
+     entry wins, bellman.c:1349-1353) -- every value produced here is one the reference can produce.  0 restores
+     the literal end-point rule of process_fibers_neighbor (nodeutil.c:570-612). */
+    boundary_set_consistent_ends(c->bound, on);
+}
 
 void c3control_set_fiber_sharding(struct C3Control *c, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg)
 { /* one process per GPU: every rank runs the same solver; step_vi / step_pi evaluate 1/world of each core step's fibers

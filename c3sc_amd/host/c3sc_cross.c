@@ -815,6 +815,26 @@ static int *resize_tuples(const int *old, size_t nold, size_t nnew, size_t len, 
     return out;
 }
 
+/* diagnostics (C3SC_CROSS_TRACE=1): do the index sets survive a cross iteration? */
+static size_t set_len(const struct cross *c, size_t k, int right) { return right ? c->r[k + 1] * (c->d - 1 - k) : c->r[k] * k; }
+static int **copy_sets(const struct cross *c, int **S, int right)
+{
+    int **o = xcalloc(c->d, sizeof(int *));
+    for (size_t k = 0; k < c->d; k++) {
+        const size_t n = set_len(c, k, right);
+        o[k] = xcalloc(n ? n : 1, sizeof(int));
+        memcpy(o[k], S[k], n * sizeof(int));
+    }
+    return o;
+}
+static int same_sets(const struct cross *c, int **A, int **B, int right)
+{
+    for (size_t k = 0; k < c->d; k++)
+        if (memcmp(A[k], B[k], set_len(c, k, right) * sizeof(int)) != 0) return 0;
+    return 1;
+}
+static void free_sets(const struct cross *c, int **S) { for (size_t k = 0; k < c->d; k++) free(S[k]); free(S); }
+
 static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber_idx_fn fi, void *args, const size_t *N, double **grid,
                                   struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 {
@@ -857,13 +877,21 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
 
     struct tt *best = NULL;
     const double t_all = tnow();
+    const int trace = getenv("C3SC_CROSS_TRACE") != NULL;
     for (int round = 0; round < 50; round++) {
         struct tt *prev = NULL, *cur = NULL;
         double rel = 1.0, prev2 = -1.0; /* prev2 = <prev, prev> once known */
         for (size_t it = 0; it < maxiter; it++) {
             c.deficient = 0;
+            int **Iold = NULL, **Jold = NULL;
+            if (trace) { Iold = copy_sets(&c, c.I, 0); Jold = copy_sets(&c, c.J, 1); }
             struct tt *t1 = cross_sweep_lr(&c);
             struct tt *t2 = cross_sweep_rl(&c);
+            if (trace) {
+                fprintf(stderr, "c3sc cross trace: round %d iteration %zu: left sets %s, right sets %s, fibers so far %zu\n", round, it + 1,
+                        same_sets(&c, c.I, Iold, 0) ? "unchanged" : "changed", same_sets(&c, c.J, Jold, 1) ? "unchanged" : "changed", c.nfibers);
+                free_sets(&c, Iold); free_sets(&c, Jold);
+            }
             tt_free(t1);
             tt_free(cur);
             cur = t2;
@@ -872,6 +900,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             if (prev != NULL) {
                 rel = tt_rel_change(cur, prev, prev2, &cur2, cross_tol);
                 if (verbose > 1) printf("  cross sweep %zu: relative change %.3e (fibers so far %zu)\n", it + 1, rel, c.nfibers);
+                if (trace) fprintf(stderr, "c3sc cross trace:   relative change %.3e (tol %.1e)\n", rel, cross_tol);
             }
             tt_free(prev);
             prev = tt_copy(cur);

@@ -29,6 +29,7 @@ struct Boundary {
     double *lo, *hi;
     size_t nobs;
     struct Box obs[MAX_OBS];
+    int consistent_ends; /* boundary_set_consistent_ends */
 };
 
 struct Boundary *boundary_alloc(size_t d, double *lb, double *ub)
@@ -43,8 +44,16 @@ struct Boundary *boundary_alloc(size_t d, double *lb, double *ub)
         b->lo[m] = lb[m];
         b->hi[m] = ub[m];
     }
+    b->nobs = 0;
+    b->consistent_ends = 0;
     return b;
 }
+
+/* NOT in the reference (default 0 = literal): with on = 1, process_fibers_neighbor leaves the flags of a reflecting / periodic
+ * fiber's two end points as the fixed dimensions and obstacles set them instead of resetting them (nodeutil.c:570-612, SURVEY.md
+ * 9 Q3), so that a node's flag -- and value -- no longer depends on the direction of the fiber it is computed in. */
+void boundary_set_consistent_ends(struct Boundary *b, int on) { b->consistent_ends = on ? 1 : 0; }
+int boundary_get_consistent_ends(const struct Boundary *b) { return b->consistent_ends; }
 
 struct Boundary *boundary_copy_deep(struct Boundary *o)
 {
@@ -58,6 +67,7 @@ struct Boundary *boundary_copy_deep(struct Boundary *o)
         memcpy(b->obs[i].ub, o->obs[i].ub, o->d * sizeof(double));
     }
     b->nobs = o->nobs;
+    b->consistent_ends = o->consistent_ends;
     return b;
 }
 

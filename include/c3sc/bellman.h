@@ -86,6 +86,11 @@ void c3control_add_stagecost(struct C3Control *, int (*)(double, const double *,
 void c3control_add_boundcost(struct C3Control *, int (*)(double, const double *, double *));
 void c3control_add_obscost(struct C3Control *, int (*)(const double *, double *));
 void c3control_set_device_model(struct C3Control *, int model, const double *params, size_t nparams); /* new */
+/* new: ON by default for a C3Control.  The end points of a reflecting / periodic fiber keep the absorbed flag the fixed
+ * dimensions and obstacles give them, so a node's value does not depend on the direction of the fiber that computes it
+ * (process_fibers_neighbor resets them, nodeutil.c:570-612: the reference's memo then keeps whichever direction came first).
+ * 0, or C3SC_LITERAL_ENDS=1 in the environment, restores the literal rule. */
+void c3control_set_consistent_ends(struct C3Control *, int on);
 /* new: multi-GPU (one process per GPU, every rank runs the same solver): the fibers of every core step of step_vi /
  * step_pi are split over `world` ranks and all-gathered by `exchange` (valuefunc.h: valuef_interp_idx_sharded) */
 void c3control_set_fiber_sharding(struct C3Control *, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg);

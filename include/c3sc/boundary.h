@@ -19,6 +19,10 @@ enum EBTYPE boundary_type_dim(const struct Boundary *b, size_t dim, int right); 
 /* boundary.c:577-597: x at/past a PERIODIC face -> the opposite face, *map = 1 (left->right) or 2 (right->left); else x, *map = 0 */
 double outer_bound_dim(const struct Boundary *b, size_t dim, double x, int *map);
 int boundary_in_obstacle(const struct Boundary *b, const double *x);             /* boundary.c:668-680 */
+/* new (not in the reference; default off): end points of a reflecting / periodic fiber keep the absorbed flag the fixed
+ * dimensions and obstacles give them (process_fibers_neighbor resets them, nodeutil.c:570-612) */
+void boundary_set_consistent_ends(struct Boundary *b, int on);
+int boundary_get_consistent_ends(const struct Boundary *b);
 size_t boundary_get_dim(const struct Boundary *b);
 
 /* where a state sits relative to the faces / obstacles (boundary.c:491-801) */

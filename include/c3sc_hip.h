@@ -89,6 +89,15 @@ int c3sc_hip_set_grid(c3sc_hip_ctx *ctx, int d, const size_t *ngrid, const doubl
 /* c3control_set_external_boundary / c3control_add_obstacle (bellman.c:2047-2062): bctype[d];
  * obstacles as inclusive boxes lb/ub (nobs x d row-major), lb = center - width/2 (boundary.c:264-267) */
 int c3sc_hip_set_boundary(c3sc_hip_ctx *ctx, const int *bctype, int nobs, const double *obs_lb, const double *obs_ub);
+/* NOT in the reference (default 0 = the reference's literal behaviour).  process_fibers_neighbor resets the absorbed flag of
+ * a fiber's two end points from the varying dimension's own boundary type (nodeutil.c:570-612): a node on an absorbing face
+ * of a fixed dimension, or inside an obstacle, is an ordinary node when it is the end point of a reflecting / periodic fiber
+ * and a boundary / obstacle node along every other direction, so its value depends on the direction of the fiber it is
+ * computed in (and, through the reference's memo, on which direction reached it first, bellman.c:1349-1353).  on = 1: end
+ * points keep the flag the fixed dimensions and obstacles give them -- the batched Bellman operator becomes a function of
+ * the node.  The solver loops of libc3sc.so switch it on (c3control_set_consistent_ends); the per-fiber entry points used
+ * through the reference's callback ABI keep the literal behaviour. */
+int c3sc_hip_set_consistent_ends(c3sc_hip_ctx *ctx, int on);
 /* mca_add_grid_refs (bellman.c:171-188) + dp_param_create's discount (bellman.c:220-235) */
 int c3sc_hip_set_mca(c3sc_hip_ctx *ctx, double h2, const double *t, double discount);
 /* replaces c3control_add_drift/diff/stagecost/boundcost/obscost (bellman.c:2064-2103) */

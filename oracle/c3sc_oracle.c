@@ -195,7 +195,18 @@ struct orc_boundary {
     size_t n;
     double *olb[ORC_MAX_OBS];
     double *oub[ORC_MAX_OBS];
+    int consistent_ends; /* not in the reference: see orc_boundary_set_consistent_ends */
 };
+
+/* NOT the reference's behaviour (default 0 = literal).  The reference resets the absorbed flag of a fiber's two end points
+ * from the varying dimension's own boundary type (nodeutil.c:570-612): a node on an absorbing face of a
+ * FIXED dimension, or inside an obstacle, is an ordinary node when it happens to be the end point of a reflecting / periodic
+ * fiber and a boundary / obstacle node along every other direction -- its value depends on the direction of the fiber it is
+ * computed in, and with the memo on the first direction that reaches it (bellman.c:1349-1353).  With this switch the end
+ * points keep the flag every other direction gives them (any dimension on an absorbing face -> 1, else obstacle -> -1), so
+ * the fiber function handed to the cross approximation is a function of the node.  Used by the solver-level tests that
+ * mirror libc3sc.so's c3control_set_consistent_ends. */
+void orc_boundary_set_consistent_ends(struct orc_boundary *b, int on) { b->consistent_ends = on; }
 
 struct orc_boundary *orc_boundary_alloc(size_t d, const double *lb, const double *ub)
 {
@@ -303,13 +314,13 @@ int orc_process_fibers_neighbor(size_t d, const size_t *fixed_ind, size_t dim_va
     /* the two fiber end points are then overwritten by dim_vary's own BC: :570-612 (quirk Q3) */
     enum orc_ebtype b = orc_boundary_type_dim(bound, dim_vary, 0);
     if (b == ORC_ABSORB) { nv[0] = 0; nv[1] = 0; absorbed[0] = 1; }
-    else if (b == ORC_REFLECT) { nv[0] = 0; nv[1] = 1; absorbed[0] = 0; }
-    else if (b == ORC_PERIODIC) { nv[0] = N - 2; nv[1] = 1; absorbed[0] = 0; }
+    else if (b == ORC_REFLECT) { nv[0] = 0; nv[1] = 1; if (!bound->consistent_ends) absorbed[0] = 0; }
+    else if (b == ORC_PERIODIC) { nv[0] = N - 2; nv[1] = 1; if (!bound->consistent_ends) absorbed[0] = 0; }
     else return 1;
     b = orc_boundary_type_dim(bound, dim_vary, 1);
     if (b == ORC_ABSORB) { nv[2 * (N - 1)] = N - 1; nv[2 * (N - 1) + 1] = N - 1; absorbed[N - 1] = 1; }
-    else if (b == ORC_REFLECT) { nv[2 * (N - 1)] = N - 2; nv[2 * (N - 1) + 1] = N - 1; absorbed[N - 1] = 0; }
-    else if (b == ORC_PERIODIC) { nv[2 * (N - 1)] = N - 2; nv[2 * (N - 1) + 1] = 1; absorbed[N - 1] = 0; }
+    else if (b == ORC_REFLECT) { nv[2 * (N - 1)] = N - 2; nv[2 * (N - 1) + 1] = N - 1; if (!bound->consistent_ends) absorbed[N - 1] = 0; }
+    else if (b == ORC_PERIODIC) { nv[2 * (N - 1)] = N - 2; nv[2 * (N - 1) + 1] = 1; if (!bound->consistent_ends) absorbed[N - 1] = 0; }
     else return 1;
 
     for (size_t j = 1; j + 1 < N; j++) { /* :615-624 */

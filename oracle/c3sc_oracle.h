@@ -53,6 +53,7 @@ int orc_boundary_external_set_type(struct orc_boundary *b, size_t dim, const cha
 int orc_boundary_add_obstacle(struct orc_boundary *b, const double *center, const double *lengths);
 enum orc_ebtype orc_boundary_type_dim(const struct orc_boundary *b, size_t dim, int right);
 int orc_boundary_in_obstacle(const struct orc_boundary *b, const double *x);
+void orc_boundary_set_consistent_ends(struct orc_boundary *b, int on); /* not the reference's behaviour: see the .c file */
 size_t orc_boundary_get_nobs(const struct orc_boundary *b);
 const double *orc_boundary_obstacle_lb(const struct orc_boundary *b, size_t i);
 const double *orc_boundary_obstacle_ub(const struct orc_boundary *b, size_t i);

@@ -73,12 +73,16 @@ def ptrs(arrs):
 class Control:
     """c3control_create + problem wiring from a workloads.Workload (device model + optional host callbacks)."""
 
-    def __init__(self, w, callbacks=None, device_model=True, box=None):
+    def __init__(self, w, callbacks=None, device_model=True, box=None, consistent_ends=False):
+        """consistent_ends: False = the reference's literal end-point rule (what the per-fiber parity tests compare with the
+        literal oracle), True = the library's solver default (c3control_set_consistent_ends), None = leave the default."""
         L = lib()
         self.L, self.w = L, w
         self._lb, self._ub, self._ng = f64(w.lb), f64(w.ub), usz(w.ngrid)
         self.h = C.c_void_p(L.c3control_create(C.c_size_t(w.dx), C.c_size_t(w.du), C.c_size_t(w.dw), dp(self._lb), dp(self._ub),
                                                sp(self._ng), C.c_double(w.discount)))
+        if consistent_ends is not None:
+            L.c3control_set_consistent_ends(self.h, C.c_int(1 if consistent_ends else 0))
         for m, name in enumerate(w.bc_names()):
             L.c3control_set_external_boundary(self.h, C.c_size_t(m), name.encode())
         for cen, wid in w.obstacles:

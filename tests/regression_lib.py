@@ -67,8 +67,10 @@ class _Base:
                        cross_tol=1e-8, round_tol=1e-7, kick=5, maxrank=20, start_value=0.2, pi_sweeps=10)  # tprob_test.c:2303-2309
             self.w, self.n = cfg["w"], n
         self.max_updates, self.conv, self.break_on_conv, self.pi_sweeps = cfg["max_updates"], cfg["conv"], cfg["break_on_conv"], cfg["pi_sweeps"]
-        box = None if minimiser == "bruteforce" else ([-1.0], [1.0])  # tprob_test.c:2290-2299
-        self.ctl = facade_lib.Control(self.w, callbacks=callbacks, box=box)  # callbacks: host functions beside the device model
+        box = None if minimiser == "bruteforce" else cfg.get("box", ([-1.0], [1.0]))  # tprob_test.c:2290-2299
+        # the solver's default: end points keep their flags (c3control_set_consistent_ends); "literal_ends" in a dict case = the reference's rule
+        self.consistent_ends = not (isinstance(case, dict) and case.get("literal_ends"))
+        self.ctl = facade_lib.Control(self.w, callbacks=callbacks, box=box, consistent_ends=self.consistent_ends)  # callbacks: host functions beside the device model
         aa = C.c_void_p(L.approx_args_init())
         L.approx_args_set_cross_tol(aa, C.c_double(cfg["cross_tol"]))
         L.approx_args_set_round_tol(aa, C.c_double(cfg["round_tol"]))
@@ -174,7 +176,7 @@ class OracleLoop(_Base):
 
         self.ol = oracle_lib
         self.O = oracle_lib.lib()
-        self.P = oracle_lib.Problem(self.w)
+        self.P = oracle_lib.Problem(self.w, consistent_ends=self.consistent_ends)
         self.xg = [self.fl.f64(g) for g in self.ctl.xgrid()]
         for m in range(self.w.dx):
             assert np.array_equal(self.xg[m], self.P.xgrid(m))  # both sides' linspace (bellman.c:1977-1979) agree bit for bit

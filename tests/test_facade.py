@@ -69,8 +69,10 @@ def test_keys_and_hash_match_oracle(oracle):
     L.htable_destroy(ht)
 
 
-def test_host_integer_functions_match_oracle(oracle):
-    """convert_fiber_to_ind / process_fibers_neighbor of the C host side vs the oracle: bit-exact."""
+@pytest.mark.parametrize("consistent", [False, True], ids=["literal", "consistent_ends"])
+def test_host_integer_functions_match_oracle(oracle, consistent):
+    """convert_fiber_to_ind / process_fibers_neighbor of the C host side vs the oracle: bit-exact -- with the reference's literal
+    end-point rule and with the solver's consistent one (boundary_set_consistent_ends / orc_boundary_set_consistent_ends)."""
     import facade_lib
 
     L = facade_lib.lib()
@@ -88,7 +90,11 @@ def test_host_integer_functions_match_oracle(oracle):
     for cen, wid in w.obstacles:
         bnd.add_obstacle(cen, wid)
         L.boundary_add_obstacle(fb, facade_lib.dp(facade_lib.f64(cen)), facade_lib.dp(facade_lib.f64(wid)))
+    if consistent:
+        oracle.lib().orc_boundary_set_consistent_ends(bnd.h, C.c_int(1))
+        L.boundary_set_consistent_ends(fb, C.c_int(1))
     ng = facade_lib.usz(w.ngrid)
+    kept = 0
     for k in range(w.dx):
         idx = wl.synth_fibers(w, k, 40)
         idx[0, :] = 0
@@ -111,6 +117,8 @@ def test_host_integer_functions_match_oracle(oracle):
             np.testing.assert_array_equal(ab, ab0)
             np.testing.assert_array_equal(nv, nv0)
             np.testing.assert_array_equal(nf, nf0)
+            kept += int(w.bc[k] != wl.BC_ABSORB and (ab[0] != 0 or ab[-1] != 0))
+    assert (kept > 0) == consistent  # the literal rule never leaves a flag on a reflecting / periodic fiber's end point
     L.boundary_free(fb)
     ctl.close()
 

@@ -16,8 +16,10 @@ def _engine(w, cores, variant=0):
     from c3sc_amd.engine import BellmanEngine
 
     eng = BellmanEngine(0)
+    if variant == 4:  # the quad kernels' padded rank (multiples of 4) follows the variant: set it before the upload
+        eng.set_variant(variant)
     eng.configure(w, cores)
-    if variant:
+    if variant and variant != 4:
         eng.set_variant(variant)
     return eng
 
@@ -47,6 +49,39 @@ def _check(eng, P, w, k, idx):
     bad = ui != ref_ui
     assert not bad.any() or np.abs(out - ref)[bad].max() <= REL_TOL * scale
     return err / scale
+
+
+@pytest.mark.parametrize("variant", [1, 3, 4], ids=["fiber_per_wave", "fiber_pair", "fiber_quad"])
+@pytest.mark.parametrize("name,kw", [("dubins3d", dict(ngrid=(21, 17, 16), rank=4)), ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)),
+                                     ("scar4d", dict(ngrid=(12, 11, 10, 9), rank=8))], ids=["dubins3d", "car7d", "scar4d"])
+def test_consistent_ends_vs_oracle(oracle, name, kw, variant):
+    """c3sc_hip_set_consistent_ends (the solver loops' rule, not the reference's): end points of reflecting / periodic fibers
+    keep the flags the fixed dimensions / obstacles give them.  Flags bit-exact and values to 1e-12 against the oracle with
+    the same switch, on every kernel family; a fiber through an absorbing face must actually show kept flags."""
+    w = wl.WORKLOADS[name]().scaled(**kw)
+    if variant == 4 and name == "dubins3d":
+        pytest.skip("no fiber-quad instantiation for the 3-D models")
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores, consistent_ends=True)
+    Plit = oracle.Problem(w, cores)
+    eng = _engine(w, cores, variant)
+    eng.set_consistent_ends(True)
+    seen = 0
+    for k in range(w.dx):
+        idx = wl.synth_fibers(w, k, 300)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        idx[2, :] = 1
+        idx[:, k] = 0
+        _check(eng, P, w, k, idx)
+        _, _, ab = eng.bellman_fibers_host(k, idx)
+        _, _, ab_lit = Plit.bellman_fibers(k, idx)
+        seen += int((ab != ab_lit).sum())
+    assert seen > 0
+    eng.set_consistent_ends(False)  # and back: the literal rule again
+    idx = wl.synth_fibers(w, w.dx - 1, 100)
+    idx[0, :] = 0
+    _check(eng, Plit, w, w.dx - 1, idx)
 
 
 PAIR_CONFIGS = {0, 1, 2, 3, 4, 5, 6, 8}  # SMALL entries that have a fiber-pair instantiation (dubins, scar4d r8, car7d, lqg2d, lqg6d)
@@ -494,6 +529,7 @@ FULL = [
     ("car7d", dict(), 3, "fiber_pair<Car7D,10", 64),            # C4: N=41, r=10 -- the code object bench.py times
     ("car7d", dict(), 1, "fiber_per_wave<Car7D,10", 64),        # the kernel the solver's small batches take
     ("quad10d", dict(ngrid=(7, 6, 5, 8, 7, 6, 5, 8, 7, 25)), 0, "Chain<10>,16", 48),  # C5 at rank 15 (padded rank 16)
+    ("quad10d", dict(), 4, "fiber_quad_duo<Chain<10>,16", 48),  # C5 at FULL size 25^10, rank 15: the duo kernel the bench times
     ("dubins3d", dict(), 3, "fiber_pair<Dubins3D,6", 40),       # C2: 101^3, r=6
     ("dubins3d", dict(), 1, "fiber_per_wave<Dubins3D,6", 40),
     ("lqg6d", dict(), 3, "fiber_pair<LqgNd<6>,8", 40),          # C3: 31^6, r=8
@@ -502,7 +538,7 @@ FULL = [
 ]
 
 
-@pytest.mark.parametrize("name,kw,variant,tag,nf", FULL, ids=[f"{f[0]}-v{f[2]}" for f in FULL])
+@pytest.mark.parametrize("name,kw,variant,tag,nf", FULL, ids=[f"{f[0]}-v{f[2]}" + ("-full" if f[0] == "quad10d" and not f[1] else "") for f in FULL])
 def test_baseline_configs_at_the_benched_instantiation(oracle, name, kw, variant, tag, nf):
     """Oracle comparison at the exact (model, padded rank, N) instantiations of BASELINE.json's configs: every varying
     dimension, faces and wrap-around included; a few dozen fibers per dimension cost the oracle milliseconds."""

@@ -26,6 +26,7 @@ CASES = [
     ("car7d", dict(), 64),                                                     # C4 at full size: 41^7, rank 10 (padded 12)
     ("quad10d", dict(ngrid=(5, 6, 5, 4, 5, 6, 5, 4, 5, 6), rank=4), 100),
     ("quad10d", dict(ngrid=(7, 6, 5, 8, 7, 6, 5, 8, 7, 25), rank=15), 70),     # C5's rank (padded 16)
+    ("quad10d", dict(), 48),                                                   # C5 at FULL size: 25^10, rank 15 -- the benched launch's LDS layout (158 of 160 KB)
     ("quad10d", dict(ngrid=(6, 25, 7, 5, 9, 6, 24, 5, 8, 7), rank=13), 150),   # ragged grid, three tiles of the duo kernel, last one partial
     ("scar4d", dict(ngrid=(12, 11, 10, 9), rank=8), 200),
     ("scar4d", dict(), 50),                                                    # 40^4, rank 20: two MFMA row blocks

@@ -210,6 +210,92 @@ def test_ref_bellman_grad1(oracle):
         assert abs((v2 - val) / delta - grad[0]) <= 1e-5
 
 
+# ------------------------------------------------- tprob_test.c:1251-1378 Test_bellman_grad3d
+@pytest.mark.parametrize("side", ["oracle", "libc3sc"])
+def test_ref_bellman_grad3d(oracle, side):
+    """The reference's 3-state / 3-control gradient test: drift f2 (:172-195), diffusion s2 = I (:197-220), stage cost
+    stagecost3d (:273-300), h = (0.1, 0.01, 0.2), discount 0.1, 1000 random (point, control, neighbour-cost) draws plus the
+    fixed first draw (:1291-1298); analytic gradients of the stage cost, every transition probability and of bellmanrhs
+    against one-sided differences (delta 1e-7) to the reference's tolerance 1e-3 (relative once |fd| > 1, :1366-1370).
+    Run on the oracle and on libc3sc.so's host functions (transition_assemble_old, bellmanrhs: pure host code)."""
+    import ctypes as C
+
+    dx = du = dw = 3
+    h = [1e-1, 1e-2, 2e-1]
+    hmin = h[1]
+    diff, gdiff = np.eye(3).ravel(), np.zeros(27)
+    discount = 0.1
+
+    if side == "oracle":
+        def assemble(drift, jac=None):
+            res, prob, dt, gp, gdt = oracle.transition_assemble(dx, du, dw, hmin, h, drift, diff, jac, None if jac is None else gdiff, old=True)
+            return res, prob, dt, gp, gdt
+
+        def rhs(stage, prob, dt, cost, sg=None, gp=None, gdt=None):
+            return oracle.bellmanrhs(dx, du, stage, discount, prob, dt, cost, sg, gp, gdt)
+    else:
+        import facade_lib as F
+
+        L = F.lib()
+        L.bellmanrhs.restype = C.c_double
+        sz, cd = C.c_size_t, C.c_double
+
+        def assemble(drift, jac=None):
+            prob, dt = np.full(7, np.nan), C.c_double(np.nan)
+            if jac is None:
+                res = L.transition_assemble_old(sz(dx), sz(du), sz(dw), cd(hmin), F.dp(F.f64(h)), F.dp(F.f64(drift)), None,
+                                                F.dp(diff), None, F.dp(prob), None, C.byref(dt), None, None)
+                return res, prob, dt.value, None, None
+            gp, gdt, space = np.zeros(21), np.zeros(3), np.zeros(3)
+            res = L.transition_assemble_old(sz(dx), sz(du), sz(dw), cd(hmin), F.dp(F.f64(h)), F.dp(F.f64(drift)), F.dp(F.f64(jac)),
+                                            F.dp(diff), F.dp(gdiff), F.dp(prob), F.dp(gp), C.byref(dt), F.dp(gdt), F.dp(space))
+            return res, prob, dt.value, gp, gdt
+
+        def rhs(stage, prob, dt, cost, sg=None, gp=None, gdt=None):
+            if sg is None:
+                return L.bellmanrhs(sz(dx), sz(du), cd(stage), None, cd(discount), F.dp(F.f64(prob)), None, cd(dt), None, F.dp(F.f64(cost)), None), None
+            g = np.zeros(du)
+            v = L.bellmanrhs(sz(dx), sz(du), cd(stage), F.dp(F.f64(sg)), cd(discount), F.dp(F.f64(prob)), F.dp(F.f64(gp)), cd(dt),
+                             F.dp(F.f64(gdt)), F.dp(F.f64(cost)), F.dp(g))
+            return v, g
+
+    def stage3d(x, u):  # tprob_test.c:273-300
+        v = 0.2 * x[0] * x[0] + 0.5 * x[1] * x[1] + 2.0 * x[2] * x[2] + 0.1 * u[0] * u[0] + 0.5 * u[1] * u[1] + 3.0 * u[2] * u[2]
+        return v, np.array([0.2 * u[0], 1.0 * u[1], 6.0 * u[2]])
+
+    rng = np.random.default_rng(14)
+    delta = 1e-7
+    for kk in range(1000):
+        pt, u = rng.uniform(-1.5, 1.5, 3), rng.uniform(-1.5, 1.5, 3)
+        if kk == 0:
+            pt, u = np.array([-0.951613, -1.305556, -2.615385]), np.array([-5.0, -5.0, 0.0])
+        cost = rng.uniform(0, 1, 7)
+        stage, gstage = stage3d(pt, u)
+        drift, jac = _f2(pt, u)
+        res, prob, dt, gp, gdt = assemble(drift, jac)
+        assert res != 1
+        val, grad = rhs(stage, prob, dt, cost, gstage, gp, gdt)
+        d0, _ = _f2(pt, u)
+        _, prob3, dt3, _, _ = assemble(d0)
+        new3, _ = rhs(stage, prob3, dt3, cost)
+        assert new3 == val  # the value does not depend on whether gradients were requested
+        for zz in range(du):
+            v = u.copy()
+            v[zz] += delta
+            d2, _ = _f2(pt, v)
+            res2, prob2, dt2, _, _ = assemble(d2)
+            assert res2 == 0
+            stage2, _ = stage3d(pt, v)
+            new2, _ = rhs(stage2, prob2, dt2, cost)
+            assert abs((stage2 - stage) / delta - gstage[zz]) <= 1e-3
+            np.testing.assert_allclose((prob2 - prob3) / delta, gp.reshape(2 * dx + 1, du)[:, zz], rtol=0, atol=1e-3)
+            fd = (new2 - new3) / delta
+            err = abs(fd - grad[zz])
+            if abs(fd) > 1:
+                err /= abs(fd)
+            assert err <= 1e-3
+
+
 # ----------------------------------------- tprob_test.c:921-961 Test_valuef_fiber_to_ind
 def test_ref_fiber_to_ind(oracle):
     N = [30, 43, 24]
@@ -390,3 +476,39 @@ def test_rossler_model_restates_the_reference_example(oracle):
     w = wl.WORKLOADS["rossler3d"]()
     assert w.bc == (wl.BC_REFLECT,) * 3 and w.discount == 0.1 and w.lb == (-1.0,) * 3 and w.ub == (1.0,) * 3  # rossler.c:208-307
     assert w.ngrid == (20,) * 3 and w.cands.min() == -4.0 and w.cands.max() == 4.0
+
+
+# ------------------------------------------------- not in the reference: the consistent end-point rule of the solver loops
+def test_consistent_ends_make_the_fiber_function_a_function_of_the_node(oracle):
+    """process_fibers_neighbor resets the flags of a fiber's end points from the varying dimension's own boundary type
+    (nodeutil.c:570-612): on a problem with absorbing AND reflecting / periodic dimensions the value of a node
+    on an absorbing face then depends on the direction of the fiber it is computed in -- the literal oracle shows it (that is
+    the reference's behaviour), and with orc_boundary_set_consistent_ends the same backup gives ONE value per node whatever
+    the direction.  The consistent value is always one of the literal ones (the one every non-end-point direction gives),
+    and nodes off the absorbing faces / obstacle end points are untouched."""
+    import itertools
+
+    from c3sc_amd import workloads as wl
+
+    w = wl.c2_dubins().scaled(ngrid=(7, 6, 9), rank=3)
+    cores = wl.smooth_cores(w)
+    lit, con = oracle.Problem(w, cores), oracle.Problem(w, cores, consistent_ends=True)
+    dense = {}
+    for name, P in (("lit", lit), ("con", con)):
+        for k in range(3):
+            dims = [range(n) if m != k else [0] for m, n in enumerate(w.ngrid)]
+            idx = np.array(list(itertools.product(*dims)), dtype=np.int32)
+            out, _, ab = P.bellman_fibers(k, idx)
+            shp = [n for m, n in enumerate(w.ngrid) if m != k] + [w.ngrid[k]]
+            dense[name, k] = (np.moveaxis(out.reshape(shp), -1, k), np.moveaxis(ab.reshape(shp), -1, k))
+    # literal: x / y absorbing, theta periodic -> direction 2 disagrees with direction 0 at theta's end points on the x / y faces
+    assert np.abs(dense["lit", 2][0] - dense["lit", 0][0]).max() > 1.0
+    for k in (1, 2):
+        np.testing.assert_array_equal(dense["con", k][1], dense["con", 0][1])                       # flags: bit-exact
+        assert np.abs(dense["con", k][0] - dense["con", 0][0]).max() <= 1e-13 * np.abs(dense["con", 0][0]).max()
+    # the consistent tensor equals the literal one of a direction whose end points are absorbing anyway (x: dim 0)
+    np.testing.assert_array_equal(dense["con", 0][1], dense["lit", 0][1])
+    assert np.abs(dense["con", 0][0] - dense["lit", 0][0]).max() == 0.0
+    # and along theta it differs from the literal rule at end points only
+    d = dense["con", 2][0] != dense["lit", 2][0]
+    assert d.any() and not d[:, :, 1:-1].any()

@@ -1,0 +1,91 @@
+"""Replay of the reference's closed-loop expectations -- test/transition_prob/tprob_test.c:1817-1897 (Test_bellman_vi):
+solve the 2-D regression problem by VALUE ITERATION ONLY (c3control_vi_solve, 10 000 sweeps / 1e-5) with u in [-3, 3], hand
+the result to c3control_add_policy_sim, integrate the closed loop from (-0.5, 0.5) for 3 time units (run_sim_2d_1d, :61-85)
+and assert the final state inside the goal box |x_i| < 0.2 (:1883-1886).
+
+Two paths, as everywhere: (a) the oracle-fed loop (tests/golden/closed_loop_vi_oracle.npz, made by
+tools/run_reference_closed_loop.py; its implicit policy is evaluated by the oracle's restatement of c3control_policy_eval),
+(b) libc3sc.so with every fiber on the device (-m gpu), the reference's call sequence and its own optimiser set-up
+(c3opt_alloc(BFGS) + bounds -> the library's box minimiser), closed loop through c3control_controller."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import closed_loop_lib as CL
+import regression_lib as R
+from c3sc_amd import workloads as wl
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOAL_HALF = 0.2  # goal_width / 2, tprob_test.c:1827, 1883-1886
+
+
+def _f1b(x, u):  # tprob_test.c:132-145
+    return np.array([x[1], u[0]])
+
+
+def test_ref_bellman_vi_closed_loop_oracle_path(oracle):
+    g = np.load(os.path.join(GOLDEN, "closed_loop_vi_oracle.npz"))
+    hist = g["history"]
+    # the run the reference asks for: 10 000 value-iteration sweeps unless the step fell below 1e-5 earlier (:1869-1873)
+    assert len(hist) == 10000 or hist[-1, 1] < 1e-5
+    assert (np.diff(hist[100:, 1]) <= 1e-9).mean() > 0.95  # the step shrinks along the solve: slow contraction at discount 0.1
+    w0 = CL.vi_workload()
+    ranks = tuple(int(r) for r in g["ranks"])
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, ranks, w0.discount, w0.bc, [], g["cands"])
+    P = oracle.Problem(w, [g["core0"].reshape(w.ngrid[0], -1), g["core1"].reshape(w.ngrid[1], -1)])
+    ctl = CL.oracle_controller(oracle, P, w.cands)
+    xT = CL.simulate_rk4(_f1b, ctl, [-0.5, 0.5], 3.0, 1e-2, 1e-3)
+    print(f"oracle path: |V| = {float(g['norm']):.6f} after {len(hist)} sweeps (last step {hist[-1, 1]:.3e}); closed loop ends at {xT}")
+    assert np.all(np.abs(xT) < GOAL_HALF)
+    # a few more oracle sweeps from the fixture keep stepping by the recorded step size (the file is a state of that loop)
+    loop = CL.vi_loop("oracle")
+    loop.ctl.w = w
+    cost = loop.ctl.valuef([g["core0"], g["core1"]])
+    loop.ctl.w = loop.w
+    gs = [loop.fl.f64(x) for x in loop.ctl.xgrid()]
+    loop.L.valuef_attach_grid(cost, loop.fl.ptrs(gs))
+    assert loop.norm(cost) == pytest.approx(float(g["norm"]), rel=1e-12)
+    nxt = loop.vi_solve(1, 1e-5, cost)
+    step = loop.L.valuef_norm2diff(cost, nxt)
+    assert step == pytest.approx(hist[-1, 1], rel=0.05)
+    loop.L.valuef_destroy(nxt)
+    loop.L.valuef_destroy(cost)
+    loop.close()
+
+
+@pytest.mark.gpu
+def test_ref_bellman_vi_closed_loop_on_the_device(oracle):
+    """The reference's sequence verbatim through libc3sc.so: c3control_create, add_*, reflect/reflect, init_value(0.2),
+    c3control_vi_solve(10000, 1e-5) with the c3opt_alloc(BFGS)+[-3,3] set-up, c3control_add_policy_sim, closed loop from
+    (-0.5, 0.5) with c3control_controller as the feedback law; final state inside the goal box.  The same solve with the
+    oracle path's 49-candidate list is compared node by node with the oracle path's fixture."""
+    import test_policy_tail as T
+
+    g = np.load(os.path.join(GOLDEN, "closed_loop_vi_oracle.npz"))
+    for minimiser in ("bfgs", "bruteforce"):
+        gpu = CL.vi_loop("gpu", minimiser, callbacks=T._lqg2d_callbacks())
+        L, fl = gpu.L, gpu.fl
+        cost = C.c_void_p(L.c3control_vi_solve(gpu.ctl.h, C.c_size_t(10000), C.c_double(1e-5), gpu.init_value(), gpu.aa, gpu.ctl.opt, 0, None))
+        L.c3control_add_policy_sim(gpu.ctl.h, cost, gpu.ctl.opt, None)
+        L.c3control_controller.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
+
+        def ctl(t, x):
+            u = np.zeros(1)
+            xx = np.ascontiguousarray(np.clip(x, -2.0, 2.0))
+            assert L.c3control_controller(C.c_double(t), fl.dp(xx), fl.dp(u), gpu.ctl.h) == 0
+            return u
+
+        xT = CL.simulate_rk4(_f1b, ctl, [-0.5, 0.5], 3.0, 1e-2, 1e-3)
+        norm = gpu.norm(cost)
+        print(f"device path ({minimiser}): |V| = {norm:.6f} (oracle path {float(g['norm']):.6f}), rank {gpu.rank(cost)}; closed loop ends at {xT}")
+        assert np.all(np.abs(xT) < GOAL_HALF)
+        if minimiser == "bruteforce":  # same candidate list as the fixture: 10 000 free-running sweeps on both paths
+            err = np.abs(gpu.nodal(cost) - g["nodal"]).max() / np.abs(g["nodal"]).max()
+            print(f"  10 000 free-running sweeps, device vs oracle path: nodal L-inf / max|V| = {err:.3e}")
+            assert err <= 1e-4
+        else:  # the continuous minimiser can only be better than the 49-point scan, by at most the scan's resolution
+            assert norm <= float(g["norm"]) * (1 + 1e-6) and norm >= float(g["norm"]) * (1 - 5e-3)
+        L.valuef_destroy(cost)
+        gpu.close()

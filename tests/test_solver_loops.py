@@ -102,33 +102,6 @@ def test_value_iteration_gpu_path_matches_cpu_path(oracle):
     ctl.close()
 
 
-def test_policy_and_value_iteration_loops_contract():
-    """The reference's own regression (tprob_test.c:2275-2364, Test_bellman_pi_100) interleaves pi_solve(10) and one
-    vi_solve step on the 2-D LQG problem until the iterates stop moving.  Here: same loop on a coarser grid and a
-    stronger discount so that it contracts within the test budget; differences must shrink and the Diag log fills."""
-    w0 = wl.c1_lqg2d().scaled(ngrid=(41, 41))
-    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, 8.0, w0.bc, [], w0.cands)
-    L, fl, ctl, aa = _setup(w)
-    const = FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.2), 0)[1])
-    cost = C.c_void_p(L.c3control_init_value(ctl.h, const, None, aa, 0))
-    diag = C.c_void_p(None)
-    diffs = []
-    for upd in range(6):
-        nxt = C.c_void_p(L.c3control_pi_solve(ctl.h, C.c_size_t(10), C.c_double(1e-7), cost, aa, ctl.opt, 0, C.byref(diag)))
-        L.valuef_destroy(cost)
-        tmp = C.c_void_p(L.c3control_vi_solve(ctl.h, C.c_size_t(1), C.c_double(1e-7), nxt, aa, ctl.opt, 0, C.byref(diag)))
-        diffs.append(L.valuef_norm2diff(nxt, tmp))
-        L.valuef_destroy(nxt)
-        cost = tmp
-    assert diffs[-1] < diffs[0] and diffs[-1] < 0.5 * diffs[1]
-    assert np.isfinite(L.valuef_norm(cost)) and L.valuef_norm(cost) > 0
-    assert 12 <= L.diag_count(diag) <= 66
-    L.diag_destroy(C.byref(diag))
-    L.valuef_destroy(cost)
-    L.approx_args_free(aa)
-    ctl.close()
-
-
 def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
     """The examples' outer loop (pi_solve(10) + one vi_solve step per control update, e.g. dubinscar.c:343-352) on a reduced
     7-D car grid, 20 control updates: each update run on the device path and on the oracle-fed path from the SAME state

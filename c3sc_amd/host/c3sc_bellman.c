@@ -1306,8 +1306,22 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
 { /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
     struct VIparam *vi = c3control_begin_vi(c, vf, opt);
     struct ApproxArgs *aa = device_rank_cap(c, apargs);
-    struct ValueF *next = c3sc_interp_idx_sharded(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose, c->shard_world,
-                                                  c->shard_rank, c->shard_exchange, c->shard_xarg, vi_absorb_foreign);
+    struct ValueF *next;
+    /* Whole cross iterations on the device (c3sc_hip_cross_*: index lists, Bellman launches, node memo and factorisations of all
+     * core steps on one stream) when the fibers are the device model's; the host-driven path below serves host callbacks
+     * (tables), sharded runs, the very first sweep while the device model is still to be cross-checked against the user's
+     * callbacks (vi_core does that on its first fiber), and C3SC_HOST_CROSS=1.  Same results either way. */
+    const int sharded = c->shard_world > 1 && c->shard_exchange != NULL;
+    const int checked = c->dp->model_checked || c->dp->stagecost == NULL || c->dp->boundcost == NULL || c->dp->obscost == NULL;
+    if (dp_has_device_model(c->dp) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL) {
+        struct c3sc_hip_ctx *ctx = sync_device(vi);
+        size_t nodes = 0;
+        next = c3sc_interp_device(c->dx, ctx, !c3opt_is_bruteforce(opt), c->ngrid, c->xgrid, vf, aa, verbose, &nodes);
+        vi->nnode_evals += nodes;
+        vi->nstate_evals += nodes;
+    } else
+        next = c3sc_interp_idx_sharded(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose, c->shard_world,
+                                       c->shard_rank, c->shard_exchange, c->shard_xarg, vi_absorb_foreign);
     approx_args_free(aa);
     c3control_end_vi(c, vi, nevals);
     return next;

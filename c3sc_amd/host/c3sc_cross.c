@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include "c3sc/c3sc.h"
+#include "c3sc_hip.h"
 #include "c3sc_private.h"
 
 /* ------------------------------------------------------------------------------ small dense kernels */
@@ -95,119 +96,85 @@ C3SC_CLONES static void qr_thin(size_t m, size_t n, double *A, double *R)
     free(Rf);
 }
 
-/* X = Q inv(S) (m x r) where S = Q[rows] is r x r: invert S by Gauss-Jordan with partial pivoting, then r^2
- * axpys over contiguous columns of Q. */
-C3SC_CLONES static void right_solve(size_t m, size_t r, const double *Q, const size_t *rows, double *X)
+/* Rows of maximal volume of the tall matrix A (m x n, column-major, full column rank up to rounding) and B = A inv(A[rows]),
+ * without forming an orthonormal basis first: a tall LU with row pivoting, A = P L U with |L| <= 1, gives B = L inv(L[rows]) --
+ * U, and with it the conditioning of A's columns, cancels, and L[rows] is unit lower triangular in pivot order.  Then maxvol's
+ * row swaps until max |B| <= 1.01.  On exit A holds B; returns 1 if a pivot is below 1e-12 of the largest (the fiber matrix is
+ * numerically rank deficient: the rows picked in those directions carry no information).
+ * No floating-point sum is reordered anywhere in here and every pivot search is an exact comparison of integer keys (magnitude
+ * with 22 mantissa bits dropped, then the LOWER index: entries that tie to 2e-10 relative -- mirror-image nodes of a symmetric
+ * value function -- go to the first), so the device twin (c3sc_amd/csrc/cross_device.hip: k_cross_core, contraction off)
+ * returns the same bits. */
+#define PIV_IDX_BITS 22
+#define PIV_IDX_MASK ((((uint64_t)1) << PIV_IDX_BITS) - 1)
+static inline uint64_t pivot_key(double x, uint64_t index)
 {
-    double *T = xcalloc(r * 2 * r, sizeof(double)); /* [S | I], row-major, 2r per row */
-    for (size_t i = 0; i < r; i++) {
-        for (size_t j = 0; j < r; j++) T[i * 2 * r + j] = Q[rows[i] + j * m];
-        T[i * 2 * r + r + i] = 1.0;
-    }
-    for (size_t k = 0; k < r; k++) {
-        size_t p = k;
-        for (size_t i = k + 1; i < r; i++) if (fabs(T[i * 2 * r + k]) > fabs(T[p * 2 * r + k])) p = i;
-        if (p != k) for (size_t j = 0; j < 2 * r; j++) { const double t = T[k * 2 * r + j]; T[k * 2 * r + j] = T[p * 2 * r + j]; T[p * 2 * r + j] = t; }
-        const double dg = T[k * 2 * r + k];
-        if (dg == 0.0) continue; /* singular pivot: leave (maxvol never selects dependent rows of an orthonormal Q) */
-        const double inv = 1.0 / dg;
-        for (size_t j = 0; j < 2 * r; j++) T[k * 2 * r + j] *= inv;
-        for (size_t i = 0; i < r; i++) {
-            if (i == k) continue;
-            const double f = T[i * 2 * r + k];
-            if (f == 0.0) continue;
-            for (size_t j = 0; j < 2 * r; j++) T[i * 2 * r + j] -= f * T[k * 2 * r + j];
-        }
-    }
-    for (size_t j = 0; j < r; j++) {
-        double *xj = X + j * m;
-        for (size_t c = 0; c < m; c++) xj[c] = 0.0;
-        for (size_t i = 0; i < r; i++) {
-            const double w = T[i * 2 * r + r + j]; /* inv(S)[i][j] */
-            if (w == 0.0) continue;
-            const double *qi = Q + i * m;
-            for (size_t c = 0; c < m; c++) xj[c] += w * qi[c];
-        }
-    }
-    free(T);
+    const double ax = fabs(x);
+    uint64_t bits;
+    memcpy(&bits, &ax, sizeof(bits));
+    return ((bits >> PIV_IDX_BITS) << PIV_IDX_BITS) | (PIV_IDX_MASK - index);
 }
 
-#define TIE_EPS 1e-9
-/* The swap search of maxvol over one column: the running maximum with its tie margin (a later entry replaces the best so far
- * only if it is larger by more than TIE_EPS relative) is a sequential rule, but a block of 16 entries none of which beats the
- * current best cannot change it -- the block maximum is a vectorisable reduction, and the sequential rule then runs only
- * inside the few blocks that matter.  Same result as scanning every entry. */
-static inline void scan_col_max(const double *col, size_t m, size_t j, double *best, size_t *bi, size_t *bj)
+C3SC_CLONES static int lu_maxvol(size_t m, size_t n, double *A, size_t *rows, size_t *nswaps)
 {
-    size_t i0 = 0;
-    for (; i0 + 16 <= m; i0 += 16) {
-        double bm = 0.0;
-        for (size_t i = 0; i < 16; i++) { const double a = fabs(col[i0 + i]); bm = a > bm ? a : bm; }
-        if (!(bm > *best * (1.0 + TIE_EPS))) continue;
-        for (size_t i = i0; i < i0 + 16; i++)
-            if (fabs(col[i]) > *best * (1.0 + TIE_EPS)) { *best = fabs(col[i]); *bi = i; *bj = j; }
-    }
-    for (size_t i = i0; i < m; i++)
-        if (fabs(col[i]) > *best * (1.0 + TIE_EPS)) { *best = fabs(col[i]); *bi = i; *bj = j; }
-}
-/* maxvol: r rows of the m x r matrix Q (full column rank) whose submatrix has (locally) maximal volume;
- * B = Q inv(Q[rows]) has entries bounded by 1 + delta on exit. */
-C3SC_CLONES static void maxvol(size_t m, size_t r, const double *Q, size_t *rows, double *B)
-{
-    /* start: pivoted Gaussian elimination picks r well-conditioned rows */
-    double *W = xcalloc(m * r, sizeof(double));
-    memcpy(W, Q, m * r * sizeof(double));
+    if (m * n > PIV_IDX_MASK) DIE("lu_maxvol: matrix too large");
     unsigned char *used = xcalloc(m, 1);
-    for (size_t k = 0; k < r; k++) {
-        size_t p = m;
-        double best = -1.0;
-        /* ties (mirror-image nodes of a symmetric value function have equal entries up to rounding) go to the lower
-         * index: a later row must exceed the best so far by more than rounding noise to replace it, so that fiber
-         * values that differ in the last bits (device vs host arithmetic) select the same rows */
+    double *pivabs = xcalloc(n, sizeof(double)), *Lr = xcalloc(n * n, sizeof(double)), *rowv = xcalloc(n, sizeof(double)), *colv = xcalloc(m, sizeof(double));
+    for (size_t kc = 0; kc < n; kc++) {
+        double *ak = A + kc * m;
+        uint64_t key = 0;
         for (size_t i = 0; i < m; i++)
-            if (!used[i] && (p == m || fabs(W[i + k * m]) > best * (1.0 + TIE_EPS))) { best = fabs(W[i + k * m]); p = i; }
-        rows[k] = p;
+            if (!used[i]) { const uint64_t kk = pivot_key(ak[i], i); if (kk > key) key = kk; }
+        const size_t p = (size_t)(PIV_IDX_MASK - (key & PIV_IDX_MASK));
+        const double dp = ak[p];
+        rows[kc] = p;
+        pivabs[kc] = fabs(dp);
         used[p] = 1;
-        const double d = W[p + k * m];
-        if (d == 0.0) continue;
-        double *fk = W + k * m; /* column k becomes the multipliers (rows already used keep 0) */
-        for (size_t i = 0; i < m; i++) fk[i] = used[i] ? 0.0 : fk[i] / d;
-        for (size_t j = k + 1; j < r; j++) {
-            double *wj = W + j * m;
-            const double pj = wj[p];
-            if (pj == 0.0) continue;
-            for (size_t i = 0; i < m; i++) wj[i] -= fk[i] * pj;
+        const double inv = dp != 0.0 ? 1.0 / dp : 0.0;
+        for (size_t i = 0; i < m; i++) colv[i] = used[i] ? 0.0 : ak[i] * inv;
+        for (size_t i = 0; i < m; i++) if (!used[i]) ak[i] = colv[i];
+        for (size_t c = kc + 1; c < n; c++) {
+            double *ac = A + c * m;
+            const double pc = ac[p];
+            for (size_t i = 0; i < m; i++) if (colv[i] != 0.0) ac[i] -= colv[i] * pc;
         }
     }
-    free(W);
-    free(used);
-    right_solve(m, r, Q, rows, B);
-    /* Swap loop.  The largest entry is searched in column order (ties to the first, see above); the search for the NEXT swap
-     * rides along with the rank-1 update of the current one (each column is scanned right after it is updated), so B is
-     * walked once per swap instead of twice -- same arithmetic, same scan order, same result. */
-    double *rowv = xcalloc(r, sizeof(double)), *colv = xcalloc(m, sizeof(double));
-    size_t bi = 0, bj = 0;
-    double best = 0.0;
-    for (size_t j = 0; j < r; j++) scan_col_max(B + j * m, m, j, &best, &bi, &bj);
+    for (size_t q = 0; q < n; q++)
+        for (size_t j = 0; j < n; j++) Lr[q * n + j] = j < q ? A[rows[q] + j * m] : (j == q ? 1.0 : 0.0);
+    for (size_t j = n; j-- > 0;) /* x Lr = l for every non-pivot row, in place (column j needs columns > j final) */
+        for (size_t t = j + 1; t < n; t++) {
+            const double w = Lr[t * n + j];
+            const double *at = A + t * m;
+            double *aj = A + j * m;
+            for (size_t i = 0; i < m; i++) if (!used[i]) aj[i] -= at[i] * w;
+        }
+    for (size_t q = 0; q < n; q++)
+        for (size_t j = 0; j < n; j++) A[rows[q] + j * m] = (j == q) ? 1.0 : 0.0;
+    size_t ns = 0;
     for (int it = 0; it < 200; it++) {
-        if (best <= 1.0 + 1e-2) break;
-        /* swap row rows[bj] for row bi: B <- B - B[:,bj] (B[bi,:] - e_bj) / B[bi,bj] */
-        const double piv = B[bi + bj * m];
-        for (size_t j = 0; j < r; j++) rowv[j] = B[bi + j * m] - (j == bj ? 1.0 : 0.0);
-        for (size_t i = 0; i < m; i++) colv[i] = B[i + bj * m] / piv;
-        rows[bj] = bi;
-        size_t nbi = 0, nbj = 0;
-        double nbest = 0.0;
-        for (size_t j = 0; j < r; j++) {
-            double *bcol = B + j * m;
-            const double rj = rowv[j];
-            if (rj != 0.0)
-                for (size_t i = 0; i < m; i++) bcol[i] -= colv[i] * rj;
-            scan_col_max(bcol, m, j, &nbest, &nbi, &nbj);
+        uint64_t key = 0;
+        for (size_t c = 0; c < n; c++) {
+            const double *ac = A + c * m;
+            for (size_t i = 0; i < m; i++) { const uint64_t kk = pivot_key(ac[i], c * m + i); if (kk > key) key = kk; }
         }
-        best = nbest; bi = nbi; bj = nbj;
+        const size_t lin = (size_t)(PIV_IDX_MASK - (key & PIV_IDX_MASK)), bj = lin / m, bi = lin % m;
+        const double piv = A[bi + bj * m];
+        if (!(fabs(piv) > 1.0 + 1e-2)) break;
+        for (size_t c = 0; c < n; c++) rowv[c] = A[bi + c * m] - (c == bj ? 1.0 : 0.0);
+        for (size_t i = 0; i < m; i++) colv[i] = A[i + bj * m] / piv;
+        for (size_t c = 0; c < n; c++) {
+            double *ac = A + c * m;
+            const double rc = rowv[c];
+            for (size_t i = 0; i < m; i++) if (colv[i] != 0.0) ac[i] -= colv[i] * rc;
+        }
+        rows[bj] = bi;
+        ns++;
     }
-    free(rowv); free(colv);
+    double mx = 0.0, mn = INFINITY;
+    for (size_t c = 0; c < n; c++) { if (pivabs[c] > mx) mx = pivabs[c]; if (pivabs[c] < mn) mn = pivabs[c]; }
+    if (nswaps) *nswaps += ns;
+    free(used); free(pivabs); free(Lr); free(rowv); free(colv);
+    return !(mn > 1e-12 * mx);
 }
 
 /* One-sided Jacobi SVD of the m x n (m >= n) column-major A: on exit A = U diag(S) (columns sorted by
@@ -656,6 +623,12 @@ struct cross {
     size_t nfibers; /* fibers requested so far */
     int verbose;
     int deficient;  /* a core step of the current cross iteration saw an (exactly) rank-deficient fiber matrix */
+    size_t nswaps;  /* maxvol row swaps so far (diagnostics) */
+    /* device-resident core steps (c3sc_hip_cross_*): the fibers of this interpolation are the batched Bellman operator of dev */
+    struct c3sc_hip_ctx *dev;
+    int dev_box, dev_fresh; /* control box instead of a candidate list; index sets / ranks changed since the last upload */
+    int dev_new_sweep;      /* the next upload starts a new memo epoch */
+    unsigned long long dev_nodes; /* nodes stored in the device memo during this interpolation (the reference's nnode_evals) */
 };
 
 /* evaluate the core tensor C[a + r_k*(j + N_k*b)] = f(I_k[a], j, J_k[b]): r_k r_{k+1} fibers along dim k */
@@ -712,15 +685,6 @@ static double g_tc[6]; /* callback+gather, qr, maxvol, convergence check, roundi
 static double tnow(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #define TIMED(slot, stmt) do { const double t__ = tnow(); stmt; g_tc[slot] += tnow() - t__; } while (0)
 
-/* exact rank deficiency of the matrix just factored (duplicate index tuples, mirror-image rows of a symmetric
- * function, a function of lower rank than asked for): the pivots chosen in the null directions carry no information */
-static int r_is_deficient(size_t n, const double *R)
-{
-    double mx = 0.0, mn = INFINITY;
-    for (size_t k = 0; k < n; k++) { const double a = fabs(R[k + k * n]); if (a > mx) mx = a; if (a < mn) mn = a; }
-    return !(mn > 1e-12 * mx);
-}
-
 /* left-to-right half sweep: new left index sets, interpolatory cores; returns the TT */
 static struct tt *cross_sweep_lr(struct cross *c)
 {
@@ -732,12 +696,9 @@ static struct tt *cross_sweep_lr(struct cross *c)
         TIMED(0, C = cross_eval_core(c, k));
         if (k == d - 1) { memcpy(t->G[k], C, m * r1 * sizeof(double)); free(C); break; }
         assert(m >= r1);
-        double *Rk = xcalloc(r1 * r1, sizeof(double));
-        TIMED(1, qr_thin(m, r1, C, Rk));
-        if (r_is_deficient(r1, Rk)) c->deficient = 1;
-        free(Rk);
         size_t *rows = xcalloc(r1, sizeof(size_t));
-        TIMED(2, maxvol(m, r1, C, rows, t->G[k]));
+        memcpy(t->G[k], C, m * r1 * sizeof(double));
+        TIMED(2, if (lu_maxvol(m, r1, t->G[k], rows, &c->nswaps)) c->deficient = 1);
         /* I_{k+1}[b] = (I_k[a], j) with row = a + r0*j */
         int *In = xcalloc(r1 * (k + 1), sizeof(int));
         for (size_t b = 0; b < r1; b++) {
@@ -766,15 +727,10 @@ static struct tt *cross_sweep_rl(struct cross *c)
         double *Ct = xcalloc(cols * r0, sizeof(double)); /* (N r1) x r0 */
         for (size_t cc = 0; cc < cols; cc++)
             for (size_t a = 0; a < r0; a++) Ct[cc + a * cols] = C[a + r0 * cc];
-        double *Rk = xcalloc(r0 * r0, sizeof(double));
-        TIMED(1, qr_thin(cols, r0, Ct, Rk));
-        if (r_is_deficient(r0, Rk)) c->deficient = 1;
-        free(Rk);
         size_t *rows = xcalloc(r0, sizeof(size_t));
-        double *B = xcalloc(cols * r0, sizeof(double));
-        TIMED(2, maxvol(cols, r0, Ct, rows, B));
+        TIMED(2, if (lu_maxvol(cols, r0, Ct, rows, &c->nswaps)) c->deficient = 1);
         for (size_t cc = 0; cc < cols; cc++)
-            for (size_t a = 0; a < r0; a++) t->G[k][a + r0 * cc] = B[cc + a * cols];
+            for (size_t a = 0; a < r0; a++) t->G[k][a + r0 * cc] = Ct[cc + a * cols];
         /* J_{k-1}[a] = (j, J_k[b]) with col = j + N*b */
         const size_t len = d - k; /* tuple length over dims k..d-1 */
         int *Jn = xcalloc(r0 * len, sizeof(int));
@@ -785,8 +741,35 @@ static struct tt *cross_sweep_rl(struct cross *c)
         }
         free(c->J[k - 1]);
         c->J[k - 1] = Jn;
-        free(rows); free(B); free(Ct); free(C);
+        free(rows); free(Ct); free(C);
     }
+    return t;
+}
+
+/* One cross iteration (both half sweeps) on the device: c3sc_hip_cross_* keep the fiber index lists, the Bellman launches, the
+ * node memo and the factorisations of all 2 d core steps on one stream; the host only uploads the index sets when they were
+ * resized and reads the iteration's cores and index sets back.  Same arithmetic as cross_sweep_lr + cross_sweep_rl above
+ * (lu_maxvol and k_cross_core return the same bits). */
+static struct tt *cross_iteration_device(struct cross *c)
+{
+    const size_t d = c->d;
+    if (c->dev_fresh) {
+        int rc = c3sc_hip_cross_setup(c->dev, c->r, (const int32_t *const *)c->I, (const int32_t *const *)c->J, c->dev_new_sweep);
+        if (rc != 0) DIE("c3sc_hip_cross_setup: %s", c3sc_hip_last_error(c->dev));
+        c->dev_fresh = 0;
+        c->dev_new_sweep = 0;
+    }
+    int rc = c3sc_hip_cross_iteration(c->dev, c->dev_box, NULL);
+    if (rc != 0) DIE("c3sc_hip_cross_iteration: %s", c3sc_hip_last_error(c->dev));
+    struct tt *t = tt_alloc(d, c->N, c->r);
+    unsigned long long info[4] = {0, 0, 0, 0};
+    rc = c3sc_hip_cross_fetch(c->dev, t->G, (int32_t *const *)c->I, (int32_t *const *)c->J, info, NULL);
+    if (rc != 0) DIE("c3sc_hip_cross_fetch: %s", c3sc_hip_last_error(c->dev));
+    if (info[3]) DIE("valuef_interp: the device node memo overflowed");
+    c->dev_nodes += info[0];
+    if (info[1]) c->deficient = 1;
+    c->nswaps += (size_t)info[2];
+    for (size_t k = 0; k < d; k++) c->nfibers += 2 * c->r[k] * c->r[k + 1];
     return t;
 }
 
@@ -835,8 +818,10 @@ static int same_sets(const struct cross *c, int **A, int **B, int right)
 }
 static void free_sets(const struct cross *c, int **S) { for (size_t k = 0; k < c->d; k++) free(S[k]); free(S); }
 
+struct dev_fibers { struct c3sc_hip_ctx *ctx; int box; unsigned long long nodes; };
+
 static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber_idx_fn fi, void *args, const size_t *N, double **grid,
-                                  struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
+                                  struct ValueF *vref, struct ApproxArgs *aargs, int verbose, struct dev_fibers *dev)
 {
     if (d < 2) DIE("valuef_interp: need at least two dimensions");
     const int elem_class = (int)approx_args_get_function_class(aargs);
@@ -853,6 +838,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     struct cross c;
     memset(&c, 0, sizeof(c));
     c.d = d; c.N = N; c.grid = grid; c.f = f; c.fb = fb; c.fi = fi; c.args = args; c.verbose = verbose;
+    if (dev != NULL) { c.dev = dev->ctx; c.dev_box = dev->box; c.dev_fresh = 1; c.dev_new_sweep = 1; }
     c.r = xcalloc(d + 1, sizeof(size_t));
     c.r[0] = c.r[d] = 1;
     size_t base = approx_args_get_startrank(aargs);
@@ -883,18 +869,25 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
         double rel = 1.0, prev2 = -1.0; /* prev2 = <prev, prev> once known */
         for (size_t it = 0; it < maxiter; it++) {
             c.deficient = 0;
-            int **Iold = NULL, **Jold = NULL;
-            if (trace) { Iold = copy_sets(&c, c.I, 0); Jold = copy_sets(&c, c.J, 1); }
-            struct tt *t1 = cross_sweep_lr(&c);
-            struct tt *t2 = cross_sweep_rl(&c);
-            if (trace) {
-                fprintf(stderr, "c3sc cross trace: round %d iteration %zu: left sets %s, right sets %s, fibers so far %zu\n", round, it + 1,
-                        same_sets(&c, c.I, Iold, 0) ? "unchanged" : "changed", same_sets(&c, c.J, Jold, 1) ? "unchanged" : "changed", c.nfibers);
-                free_sets(&c, Iold); free_sets(&c, Jold);
+            int **Iold = copy_sets(&c, c.I, 0), **Jold = copy_sets(&c, c.J, 1);
+            struct tt *t2;
+            if (c.dev) t2 = cross_iteration_device(&c);
+            else {
+                struct tt *t1 = cross_sweep_lr(&c);
+                t2 = cross_sweep_rl(&c);
+                tt_free(t1);
             }
-            tt_free(t1);
+            /* Both families of index sets came back unchanged: the next iteration would ask for the same fibers (all of them in
+             * the memo), factor the same matrices and return this train again -- its relative change would be exactly 0.  Stop
+             * here with the same result and one iteration's worth of core steps saved. */
+            const int fixed_point = same_sets(&c, c.I, Iold, 0) && same_sets(&c, c.J, Jold, 1);
+            if (trace)
+                fprintf(stderr, "c3sc cross trace: round %d iteration %zu: index sets %s, fibers so far %zu, swaps %zu\n", round, it + 1,
+                        fixed_point ? "unchanged" : "changed", c.nfibers, c.nswaps);
+            free_sets(&c, Iold); free_sets(&c, Jold);
             tt_free(cur);
             cur = t2;
+            if (fixed_point) { if (verbose > 1) printf("  cross sweep %zu: index sets reproduced (fixed point)\n", it + 1); break; }
             const double t_conv = tnow();
             double cur2 = -1.0;
             if (prev != NULL) {
@@ -937,6 +930,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                     free(c.J[k - 1]); c.J[k - 1] = Jn;
                     c.r[k] = rn;
                     kicked = 1;
+                    c.dev_fresh = 1;
                 }
         }
         tt_free(best);
@@ -950,7 +944,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     vf->elem_class = elem_class;
     if (getenv("C3SC_PROFILE")) {
         g_tc[5] = tnow() - t_all;
-        fprintf(stderr, "c3sc cross profile: total %.2f ms = fibers (callback + gather) %.2f, qr %.2f, maxvol %.2f, convergence check %.2f, rounding %.2f\n",
+        fprintf(stderr, "c3sc cross profile: total %.2f ms = fibers (callback + gather, or whole device iterations) %.2f, (unused) %.2f, lu + maxvol %.2f, convergence check %.2f, rounding %.2f\n",
                 1e3 * g_tc[5], 1e3 * g_tc[0], 1e3 * g_tc[1], 1e3 * g_tc[2], 1e3 * g_tc[3], 1e3 * g_tc[4]);
     }
     memset(g_tc, 0, sizeof(g_tc));
@@ -963,25 +957,26 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     tt_free(best);
     for (size_t k = 0; k < d; k++) { free(c.I[k]); free(c.J[k]); }
     free(c.I); free(c.J); free(c.r);
+    if (dev != NULL) dev->nodes = c.dev_nodes;
     return vf;
 }
 
 struct ValueF *valuef_interp(size_t d, int (*f)(size_t, const double *, double *, void *), void *args, const size_t *N,
                              double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 { /* valuefunc.c:603-767 */
-    return interp_impl(d, f, NULL, NULL, args, N, grid, vref, aargs, verbose);
+    return interp_impl(d, f, NULL, NULL, args, N, grid, vref, aargs, verbose, NULL);
 }
 
 struct ValueF *valuef_interp_batch(size_t d, int (*fb)(size_t, size_t, const double *, double *, void *), void *args,
                                    const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 {
-    return interp_impl(d, NULL, fb, NULL, args, N, grid, vref, aargs, verbose);
+    return interp_impl(d, NULL, fb, NULL, args, N, grid, vref, aargs, verbose, NULL);
 }
 
 struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
                                  const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs, int verbose)
 { /* fibers handed over as grid indices: fi(F, dim_vary, idx[F*d], out[F*N], args) */
-    return interp_impl(d, NULL, NULL, fi, args, N, grid, vref, aargs, verbose);
+    return interp_impl(d, NULL, NULL, fi, args, N, grid, vref, aargs, verbose, NULL);
 }
 
 /* fibers of a core step sharded over ranks: the wrapper the cross driver sees in place of fi */
@@ -1032,7 +1027,19 @@ struct ValueF *c3sc_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const
     if (world <= 1 || exchange == NULL) return valuef_interp_idx(d, fi, args, N, grid, vref, aargs, verbose);
     if (rank >= world) DIE("valuef_interp_idx_sharded: rank %zu of %zu", rank, world);
     struct shard_args s = {fi, args, d, world, rank, N, exchange, xarg, absorb};
-    return interp_impl(d, NULL, NULL, sharded_fibers_idx, &s, N, grid, vref, aargs, verbose);
+    return interp_impl(d, NULL, NULL, sharded_fibers_idx, &s, N, grid, vref, aargs, verbose, NULL);
+}
+
+/* The interpolation whose fibers are the batched Bellman operator of a device context (c3sc_hip_bellman_fibers[_box] on the value
+ * function uploaded to ctx): whole cross iterations run on the device (cross_iteration_device).  *nodes returns the number of
+ * nodes stored in the device memo, the reference's nnode_evals (bellman.c:1374-1386). */
+struct ValueF *c3sc_interp_device(size_t d, struct c3sc_hip_ctx *ctx, int box, const size_t *N, double **grid, struct ValueF *vref,
+                                  struct ApproxArgs *aargs, int verbose, size_t *nodes)
+{
+    struct dev_fibers dv = {ctx, box, 0};
+    struct ValueF *vf = interp_impl(d, NULL, NULL, NULL, NULL, N, grid, vref, aargs, verbose, &dv);
+    if (nodes) *nodes = (size_t)dv.nodes;
+    return vf;
 }
 
 struct ValueF *valuef_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,

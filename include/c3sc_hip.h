@@ -199,6 +199,24 @@ int c3sc_hip_bellman_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32
 int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, double *h_costs,
                                  int32_t *h_absorbed);
 
+/* Device-resident core steps of the cross approximation that calls the path (valuefunc.c:603-767 hands bellman_vi to C3's
+ * ftapprox_cross; c3sc_amd/host/c3sc_cross.c is this library's driver).  A cross iteration is 2 d sequential core steps of
+ * r_k r_{k+1} fibers each; with fibers on the GPU and factorisation + node memo on the host a sweep is host-bound.  These
+ * entry points keep a whole iteration on one stream: fiber index lists from the device-resident index sets, the batched
+ * Bellman kernel, the node memo (first value stays: bellman.c:1333-1353, 1412-1417; keyed by node id and sweep epoch) and a
+ * one-workgroup pivoted factorisation + maxvol that writes the interpolatory core and the next index set.
+ *   ranks[d+1]; I[k]: ranks[k] tuples over dims 0..k-1 (int32, row-major); J[k]: ranks[k+1] tuples over dims k+1..d-1
+ *   new_sweep != 0 starts a new memo epoch (workspace_increment_vi_iter, bellman.c:2199)
+ *   box: 0 = candidate list (set_controls), 1 = control box (set_control_box)
+ *   fetch waits for the stream and returns the cores of the last half sweep in the layout G_k[a + r_k (j + N_k b)], both
+ *   families of index sets, and info[4] = {nodes stored in the memo since the last fetch (the reference's nnode_evals),
+ *   1 if a fiber matrix was numerically rank deficient, maxvol row swaps, 1 if the memo overflowed} */
+int c3sc_hip_cross_setup(c3sc_hip_ctx *ctx, const size_t *ranks, const int32_t *const *I, const int32_t *const *J, int new_sweep);
+int c3sc_hip_cross_iteration(c3sc_hip_ctx *ctx, int box, void *stream);
+int c3sc_hip_cross_fetch(c3sc_hip_ctx *ctx, double *const *h_cores, int32_t *const *h_I, int32_t *const *h_J, unsigned long long *info,
+                         void *stream);
+void c3sc_hip_cross_free(c3sc_hip_ctx *ctx);
+
 int c3sc_hip_sync(c3sc_hip_ctx *ctx, void *stream);
 int c3sc_hip_get_status(c3sc_hip_ctx *ctx, unsigned *flags, int clear);
 /* name of the kernel the last launch used (for profiles) */

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 FIBER_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 
-def _setup(w, maxrank=12, startrank=3, round_tol=1e-9):
+def _setup(w, maxrank=12, startrank=3, round_tol=1e-9, kick=3):
     import facade_lib
 
     L = facade_lib.lib()
@@ -33,7 +33,7 @@ def _setup(w, maxrank=12, startrank=3, round_tol=1e-9):
     aa = C.c_void_p(L.approx_args_init())
     L.approx_args_set_cross_tol(aa, C.c_double(1e-10))
     L.approx_args_set_round_tol(aa, C.c_double(round_tol))
-    L.approx_args_set_kickrank(aa, C.c_size_t(3))
+    L.approx_args_set_kickrank(aa, C.c_size_t(kick))
     L.approx_args_set_startrank(aa, C.c_size_t(startrank))
     L.approx_args_set_maxrank(aa, C.c_size_t(maxrank))
     return L, facade_lib, ctl, aa
@@ -105,17 +105,17 @@ def test_value_iteration_gpu_path_matches_cpu_path(oracle):
 def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
     """The examples' outer loop (pi_solve(10) + one vi_solve step per control update, e.g. dubinscar.c:343-352) on a reduced
     7-D car grid, 20 control updates: each update run on the device path and on the oracle-fed path from the SAME state
-    is compared node by node.  Most updates agree to ~1e-14 of max |V|; a few do not agree at all (0.1 ... 0.3): at a rank
-    cap of 5 this value function is far from representable, the cross approximation's error is of that size, and which of
-    several equally bad approximations comes out depends on pivot decisions that flip with the last bit of the fiber values
-    -- the ORACLE-fed loop shows the same jumps against itself when 1e-16 relative noise is added to its fiber values
-    (update 0 of this very configuration: 0.12).  So the statement tested is: the median update agrees to 1e-12 and at least
-    three quarters of the updates to 1e-6; the outliers are printed.  The data avoid EXACT ties between candidates (the
-    tie-break of the brute-force scan lives in C3): with the symmetric 3 x 3 candidate grid and a start value that does not
-    depend on the steering / acceleration states, +u and -u tie at every node, the policy's pick among them is decided by
-    the last bit (oracle: division per candidate; device: cross-multiplied comparison), and ten evaluation sweeps of two such
-    policies drift apart by 20 % -- so the candidate list is slightly asymmetric and the start value depends on every
-    coordinate."""
+    is compared node by node -- every one of them must agree to 1e-6 of max |V| (north_star; measured 3e-14).
+    Round 2 had to tolerate a quarter of the updates disagreeing by 15-27 %.  The cause was not the rank cap: with the
+    reference's literal end-point rule (nodeutil.c:570-612) a node on an absorbing face has one value as the
+    end point of a reflecting / periodic fiber and another along every other direction, the memo keeps whichever came first,
+    and the function handed to the cross approximation is then inconsistent at a few per cent of the nodes by the size of the
+    boundary cost -- its rank-5 cross approximation was off by 88 % where 0.4 % is attainable.  The solver
+    loops now keep the end points' flags (c3control_set_consistent_ends, mirrored in the oracle); "literal_ends" in the
+    configuration restores the reference's rule.
+    The data avoid EXACT ties between candidates (the tie-break of the brute-force scan lives in C3): with the
+    symmetric 3 x 3 candidate grid and a start value that does not depend on the steering / acceleration states, +u and -u tie
+    at every node -- so the candidate list is slightly asymmetric and the start value depends on every coordinate."""
     import regression_lib as R
 
     w0 = wl.c4_car7d().scaled(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)
@@ -138,10 +138,8 @@ def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
         Lb.valuef_destroy(state)
         state = a
     print("per update:", " ".join(f"{x:.1e}" for x in diffs))
-    good = [x for x in diffs if x <= 1e-6]
-    print(f"car7d {w.ngrid}: 20 control updates in lock-step: {len(good)} agree to 1e-6 (worst of them {max(good):.1e}), median {np.median(diffs):.1e}, "
-          f"pivot-flip outliers {[f'{x:.2f}' for x in diffs if x > 1e-6]}; |V| = {gpu.norm(state):.6e}, rank {gpu.rank(state)}")
-    assert np.median(diffs) <= 1e-12 and len(good) >= 15 and max(good) <= 1e-12
+    print(f"car7d {w.ngrid}: 20 control updates in lock-step: worst {worst:.1e}, median {np.median(diffs):.1e}; |V| = {gpu.norm(state):.6e}, rank {gpu.rank(state)}")
+    assert worst <= 1e-6
     Lb.valuef_destroy(state)
     gpu.close()
     orc.close()
@@ -177,3 +175,55 @@ def test_rossler_example_outer_loop_device_vs_oracle_side_by_side(oracle):
     Lb.valuef_destroy(state)
     gpu.close()
     orc.close()
+
+
+@pytest.mark.parametrize("name,kw,aargs", [
+    ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=2)),
+    ("car7d", dict(), dict(maxrank=10, kick=2)),                       # the bench's vi_sweep configuration: 41^7, rank cap 10
+    ("dubins3d", dict(ngrid=(41, 41, 41), rank=4), dict(maxrank=12, kick=3)),
+    ("lqg2d", dict(ngrid=(60, 60), rank=4), dict(maxrank=20, kick=5)),  # core steps of up to 60 x 20 x 20: the factorisation leaves LDS
+], ids=["car7d-small", "car7d-41", "dubins3d", "lqg2d"])
+def test_device_resident_cross_iterations_match_the_host_driver(name, kw, aargs):
+    """c3control_step_vi with whole cross iterations on the device (c3sc_hip_cross_*: fiber index lists, Bellman launches, node
+    memo, pivoted factorisation + maxvol of every core step on one stream) against the same sweeps driven from the host
+    (C3SC_HOST_CROSS=1: index lists, memo and factorisations in c3sc_cross.c / c3sc_bellman.c, one kernel launch per core step).
+    lu_maxvol and its device twin reorder no floating-point sum and search pivots with exact integer keys: cores, ranks and the
+    number of node evaluations must be IDENTICAL, bit for bit, sweep after sweep."""
+    w = wl.WORKLOADS[name]().scaled(**kw) if kw else wl.WORKLOADS[name]()
+    L, fl, ctl, aa = _setup(w, **aargs)
+    d = w.dx
+
+    def start(n, x, out, a):
+        X = np.ctypeslib.as_array(x, shape=(n, d))
+        np.ctypeslib.as_array(out, shape=(n,))[:] = 1.0 + 0.1 * ((X - 0.05) ** 2).sum(axis=1)
+        return 0
+
+    v0 = C.c_void_p(L.c3control_init_value(ctl.h, FIBER_FN(start), None, aa, 0))
+    results = {}
+    for path in ("device", "host"):
+        if path == "host":
+            os.environ["C3SC_HOST_CROSS"] = "1"
+        else:
+            os.environ.pop("C3SC_HOST_CROSS", None)
+        v = C.c_void_p(L.valuef_copy(v0))
+        rows = []
+        ne = C.c_size_t(0)
+        for it in range(4):
+            nxt = C.c_void_p(L.c3control_step_vi(ctl.h, v, aa, ctl.opt, 0, C.byref(ne)))
+            L.valuef_destroy(v)
+            v = nxt
+            ranks, cores = _cores_of(L, v, w)
+            rows.append((ne.value, ranks, cores))
+        results[path] = rows
+        L.valuef_destroy(v)
+    os.environ.pop("C3SC_HOST_CROSS", None)
+    for it, (a, b) in enumerate(zip(results["device"], results["host"])):
+        assert a[1] == b[1], f"sweep {it}: ranks {a[1]} vs {b[1]}"
+        assert a[0] == b[0], f"sweep {it}: node evaluations {a[0]} vs {b[0]}"
+        for m in range(d):
+            assert np.array_equal(a[2][m], b[2][m]), f"sweep {it}, core {m}: max diff {np.abs(a[2][m] - b[2][m]).max():.3e}"
+    print(f"{name} {w.ngrid}: 4 sweeps, device-resident and host-driven cross iterations bit-identical; ranks {results['device'][-1][1]}, "
+          f"node evaluations per sweep {[r[0] for r in results['device']]}")
+    L.valuef_destroy(v0)
+    L.approx_args_free(aa)
+    ctl.close()

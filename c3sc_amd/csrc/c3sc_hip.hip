@@ -576,6 +576,7 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
     }
     A.img_base = c->arena;
     A.cends = c->cends;
+    A.memo_keys = nullptr; // only the launch paths that found a fiber-per-wave kernel switch the memo epilogue on
     A.nobs = c->nobs;
     A.obs_off = c->obs_off;
     A.cands_off = c->cands_off;
@@ -595,6 +596,17 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
         if (A.dbg & 16) A.ncand = 3;
     }
     return C3SC_OK;
+}
+
+// switch the memo epilogue of the fiber-per-wave kernel on for this launch if one was requested (c3sc_hip_cross_iteration)
+static void arm_memo(c3sc_hip_ctx *c, const KernelEntry *e, KArgs &A)
+{
+    A.memo_keys = nullptr;
+    if (c->memo.keys == nullptr || e->variant != C3SC_VARIANT_FIBER_PER_WAVE) return;
+    A.memo_keys = c->memo.keys; A.memo_vals = c->memo.vals; A.memo_capmask = c->memo.capmask; A.memo_epoch_bits = c->memo.epoch_bits;
+    A.memo_shift = c->memo.shift; A.memo_counters = c->memo.counters; A.memo_mode = c->memo.mode;
+    for (int m = 0; m < c->d; m++) A.memo_stride[m] = c->memo.stride[m];
+    c->memo.applied = true;
 }
 
 static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const int32_t *d_policy, double *d_out,
@@ -621,8 +633,10 @@ static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx
                             : "bellman_fibers: no kernel instantiation serves this call (model, dim, rank, N, control mode)");
         }
         c->last_kernel = e->name;
+        arm_memo(c, e, A);
         he = e->fn(A, io);
         if (he != hipErrorOutOfMemory && he != hipErrorNotSupported) break;
+        c->memo.applied = false;
         if (getenv("C3SC_VERBOSE")) fprintf(stderr, "c3sc: %s declined (%s), trying the next instantiation\n", e->name, hipGetErrorName(he));
         declined.push_back(e);
     }
@@ -657,6 +671,7 @@ static int launch_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, co
     const KernelEntry *e = find_kernel(c->model, c->d, c->rp, A.N, C3SC_VARIANT_FIBER_PER_WAVE, k);
     if (!e || e->rp != c->rp) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: no fiber-per-wave instantiation for (model, dim, rank, N)");
     c->last_kernel = e->name;
+    arm_memo(c, e, A);
     LaunchIO io{c->arena, d_idx, d_out, nullptr, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
     g_launches++;
     const hipError_t he = e->fn(A, io);

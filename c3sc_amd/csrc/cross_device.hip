@@ -19,6 +19,7 @@
 // bits dropped, ties to the lowest index) -- tests/test_solver_loops.py holds the two paths to identical cores.
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.hpp"
@@ -27,10 +28,11 @@ using namespace c3sc;
 
 namespace {
 
-constexpr int NT = 256;                       // threads of the core-step workgroup
+constexpr int NT = 512;                       // threads of the core-step workgroup
+constexpr int MAXROWS = 8192;                 // rows of a fiber matrix (N r): 16 per thread
 constexpr unsigned long long IDX_BITS = 22;   // low bits of a pivot-search key hold the (inverted) index
 constexpr unsigned long long IDX_MASK = (1ull << IDX_BITS) - 1;
-constexpr size_t LDS_CAP_BYTES = 150 * 1024;  // of the 160 KB of a CU
+constexpr size_t LDS_CAP_BYTES = 140 * 1024;  // dynamic LDS of the general core step: 160 KB of a CU minus its 17 KB of static arrays
 
 struct Strides { long long s[MAXD]; };
 
@@ -55,7 +57,7 @@ __global__ void k_cross_idx(int32_t *__restrict__ idx, const int32_t *__restrict
 // (the reference's memo keeps the first value, bellman.c:1349-1353), a miss stores its own.  The same node twice in ONE
 // batch means the same fiber twice (one varying dimension per batch), i.e. identical values: the loser of the race keeps
 // its own.
-constexpr unsigned long long PENDING = 1ull << 48, EPOCH_MASK = ~((1ull << 49) - 1), ID_MASK = (1ull << 48) - 1;
+constexpr unsigned long long EPOCH_MASK = MEMO_EPOCH_MASK, ID_MASK = MEMO_ID_MASK;
 
 // growth: the entries of the current epoch move into a larger table (same probe rule; no concurrent lookups)
 __global__ void k_cross_memo_rehash(const unsigned long long *__restrict__ okeys, const double *__restrict__ ovals, unsigned long long ocap,
@@ -73,42 +75,20 @@ __global__ void k_cross_memo_rehash(const unsigned long long *__restrict__ okeys
 __global__ void k_cross_memo(const int32_t *__restrict__ idx, double *__restrict__ out, long total, int N, int d, int k, Strides S,
                              unsigned long long *keys, double *vals, unsigned long long capmask, int shift, unsigned long long epoch_bits,
                              unsigned long long *counters)
-{
+{ // the memo as a pass of its own, behind Bellman kernels that do not carry it in their epilogue (kernel_common.hpp: memo_merge)
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int inserted = 0;
+    int inserted = 0, overflow = 0;
     if (e < total) {
         const long f = e / N;
         const int j = (int)(e - f * N);
         unsigned long long id = (unsigned long long)j * (unsigned long long)S.s[k];
         for (int m = 0; m < d; m++)
             if (m != k) id += (unsigned long long)idx[f * d + m] * (unsigned long long)S.s[m];
-        const unsigned long long K = epoch_bits | id, KP = K | PENDING;
-        unsigned long long slot = (id * 0x9E3779B97F4A7C15ull) >> shift;
-        const double v = out[e];
-        bool done = false;
-        for (unsigned long long probe = 0; probe <= capmask && !done; probe++, slot = (slot + 1) & capmask) {
-            unsigned long long cur = __hip_atomic_load(&keys[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            while ((cur & EPOCH_MASK) != epoch_bits) { // free: claim it
-                const unsigned long long prev = atomicCAS(&keys[slot], cur, KP);
-                if (prev == cur) {
-                    vals[slot] = v;
-                    __hip_atomic_store(&keys[slot], K, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    inserted = 1;
-                    done = true;
-                    break;
-                }
-                cur = prev;
-            }
-            if (done) break;
-            if ((cur & ~PENDING) == K) { // this node
-                if (!(cur & PENDING)) out[e] = __hip_atomic_load(&vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                done = true;
-            }
-        }
-        if (!done) atomicExch(&counters[3], 1ull); // table full (sized so that it cannot happen)
+        out[e] = memo_merge(keys, vals, capmask, shift, epoch_bits, id, out[e], inserted, overflow);
     }
     const unsigned long long mask = __ballot(inserted);
     if (mask != 0 && (threadIdx.x & 63) == (unsigned)__ffsll((long long)mask) - 1) atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+    if (overflow) atomicExch(&counters[3], 1ull);
 }
 
 // ------------------------------------------------------------------------------------------------ core step
@@ -118,11 +98,19 @@ struct CoreArgs {
     int dir;       // 0: left-to-right (rows (a, j) = a + r0 j, columns b); 1: right-to-left (rows (j, b) = j + N b, columns a)
     int copy_only; // last core of a half sweep: the fiber values are the core
     const int32_t *set_in; // dir 0: I_k [r0][k]; dir 1: J_k [r1][d-1-k]
-    int32_t *set_out;      // dir 0: I_{k+1} [r1][k+1]; dir 1: J_{k-1} [r0][d-k]
+    int32_t *set_out;      // dir 0: I_{k+1} [r1][k+1]; dir 1: J_{k-1} [r0][d-k]; read first: the rows it names start the pivot search
     double *G;             // core in the working layout G[a + r0 (j + N b)]
     double *work;          // m x n scratch in global memory when the matrix does not fit LDS
     unsigned long long *counters; // [1] rank-deficient factorisation seen, [2] maxvol swaps
+    int warm;              // pivot search starts from the rows of the previous index set (c3sc_cross.c: WARM_BOOST_LOG2)
+    double swap_tol;       // maxvol swaps while max |B| > 1 + swap_tol
+    // the fiber index list of the NEXT core step, written at the end (its index sets are final then); nidx == null: none
+    int32_t *nidx;
+    const int32_t *nI, *nJ;
+    int nr0, nr1, nk;
 };
+
+constexpr int WARM_BOOST_LOG2 = 6; // as in c3sc_cross.c
 
 __device__ inline unsigned long long pivot_key(double x, unsigned long long index)
 { // larger |x| first (22 mantissa bits dropped: values equal to ~2e-10 relative tie), then the LOWER index
@@ -147,6 +135,102 @@ __device__ inline unsigned long long block_max(unsigned long long v, unsigned lo
     return r;
 }
 
+// rows named by the previous index set (P.set_out before it is overwritten), matched through the tuples of P.set_in; both
+// sets are first brought into LDS in one coalesced round trip (matching them in global memory was ~10 dependent loads)
+__device__ inline void mark_warm_rows(const CoreArgs &P, int m, int n, unsigned char *warmf, int *s_in, int *s_old)
+{
+    const int tid = threadIdx.x;
+    const int lin = P.dir == 0 ? P.k : P.d - 1 - P.k, nin = P.dir == 0 ? P.r0 : P.r1; // set_in: nin tuples of length lin
+    const int lold = lin + 1;                                                           // set_out: n tuples of length lin + 1
+    for (int i = tid; i < m; i += NT) warmf[i] = 0;
+    if (P.warm) {
+        for (int e = tid; e < nin * lin; e += NT) s_in[e] = P.set_in[e];
+        for (int e = tid; e < n * lold; e += NT) s_old[e] = P.set_out[e];
+    }
+    __syncthreads();
+    if (P.warm && tid < n) {
+        const int *u = s_old + tid * lold;
+        if (P.dir == 0) { // tuple (u_0..u_{k-1}, j) is row a + r0 j if I_k[a] == (u_0..u_{k-1})
+            const int j = u[lin];
+            if (j >= 0 && j < P.N)
+                for (int a = 0; a < nin; a++) {
+                    bool eq = true;
+                    for (int t = 0; t < lin; t++) eq = eq && (s_in[a * lin + t] == u[t]);
+                    if (eq) { warmf[a + P.r0 * j] = 1; break; }
+                }
+        } else { // tuple (j, v_1..) is row j + N b if J_k[b] == (v_1..)
+            const int j = u[0];
+            if (j >= 0 && j < P.N)
+                for (int b = 0; b < nin; b++) {
+                    bool eq = true;
+                    for (int t = 0; t < lin; t++) eq = eq && (s_in[b * lin + t] == u[1 + t]);
+                    if (eq) { warmf[j + P.N * b] = 1; break; }
+                }
+        }
+    }
+    __syncthreads();
+}
+
+// canonical order of the result: rows ascending; pos[c] = position of column c of B in the output (n <= 32: rank counting)
+__device__ inline void sort_rows(int n, const int *rows, int *srows, int *pos)
+{
+    const int tid = threadIdx.x;
+    if (tid < n) {
+        const int r = rows[tid];
+        int rank = 0;
+        for (int q = 0; q < n; q++) rank += (rows[q] < r) || (rows[q] == r && q < tid);
+        srows[rank] = r;
+        pos[tid] = rank;
+    }
+    __syncthreads();
+}
+
+__device__ inline void write_sets_and_next(const CoreArgs &P, int n, const int *srows, const double *pivabs, int nswaps)
+{
+    const int tid = threadIdx.x, r0 = P.r0, N = P.N;
+    if (!P.copy_only) {
+        if (P.dir == 0) {
+            const int k = P.k;
+            for (int e = tid; e < n * (k + 1); e += NT) {
+                const int q = e / (k + 1), t = e % (k + 1);
+                const int row = srows[q], a = row % r0, j = row / r0;
+                P.set_out[e] = t < k ? P.set_in[a * k + t] : j;
+            }
+        } else {
+            const int len = P.d - P.k;
+            for (int e = tid; e < n * len; e += NT) {
+                const int q = e / len, t = e % len;
+                const int row = srows[q], j = row % N, b = row / N;
+                P.set_out[e] = t == 0 ? j : P.set_in[b * (len - 1) + (t - 1)];
+            }
+        }
+        if (tid == 0) {
+            double mx = 0.0, mn = INFINITY;
+            for (int c = 0; c < n; c++) { mx = pivabs[c] > mx ? pivabs[c] : mx; mn = pivabs[c] < mn ? pivabs[c] : mn; }
+            if (!(mn > 1e-12 * mx)) atomicExch(&P.counters[1], 1ull);
+            if (nswaps) atomicAdd(&P.counters[2], (unsigned long long)nswaps);
+        }
+    }
+    if (P.nidx) { // fiber list of the next core step (k_cross_idx's job, without a launch of its own)
+        __syncthreads();
+        const int d = P.d, k = P.nk, F = P.nr0 * P.nr1;
+        for (int e = tid; e < F * d; e += NT) {
+            const int f = e / d, mm = e - f * d;
+            const int a = f % P.nr0, b = f / P.nr0;
+            int v = 0;
+            if (mm < k) v = P.nI[a * k + mm];
+            else if (mm > k) v = P.nJ[b * (d - 1 - k) + (mm - k - 1)];
+            P.nidx[e] = v;
+        }
+    }
+}
+
+// The matrix lives in LDS (column-major m x n; in global scratch when it does not fit), thread t owns rows t, t + NT, ...
+// Everything a thread does to one of its rows is written as chunks of CH columns: the loads of a chunk are issued together
+// and the arithmetic follows (left to itself the compiler keeps one LDS round trip per element in flight, because every
+// store into the matrix might alias the next load: the kernel was 45 us of pure latency that way).
+constexpr int CH = 8;
+
 template <bool INLDS>
 __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P)
 {
@@ -155,128 +239,164 @@ __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P)
     __shared__ double Lr[32 * 32];
     __shared__ double rowv[32];
     __shared__ double pivabs[32];
-    __shared__ int rows[32];
+    __shared__ int rows[32], srows[32], pos[32];
     __shared__ unsigned long long red[2 * (NT / 64)];
+    __shared__ unsigned char warmf[MAXROWS];
+    __shared__ int s_in[32 * MAXD], s_old[32 * MAXD];
     const int tid = threadIdx.x;
     const int r0 = P.r0, N = P.N, r1 = P.r1;
     if (P.copy_only) { // G[a + r0 (j + N b)] = out[(a + r0 b) N + j]
-        const long total = (long)r0 * N * r1;
-        for (long e = tid; e < total; e += NT) {
-            const int a = (int)(e % r0), j = (int)((e / r0) % N), b = (int)(e / ((long)r0 * N));
-            P.G[e] = P.out[((long)a + (long)r0 * b) * N + j];
+        const int total = r0 * N * r1;
+        for (int e = tid; e < total; e += NT) {
+            const int a = e % r0, j = (e / r0) % N, b = e / (r0 * N);
+            P.G[e] = P.out[(a + r0 * b) * N + j];
         }
+        write_sets_and_next(P, 0, srows, pivabs, 0);
         return;
     }
     const int m = P.dir == 0 ? r0 * N : N * r1, n = P.dir == 0 ? r1 : r0;
-    double *A = INLDS ? smem : P.work; // column-major m x n
-    // load the fiber matrix
-    for (long e = tid; e < (long)m * n; e += NT) {
-        const int i = (int)(e % m), c = (int)(e / m);
-        int a, j, b;
-        if (P.dir == 0) { a = i % r0; j = i / r0; b = c; }
-        else { j = i % N; b = i / N; a = c; }
-        A[e] = P.out[((long)a + (long)r0 * b) * N + j];
+    double *A = INLDS ? smem : P.work;
+    for (int i = tid; i < m; i += NT) { // load the fiber matrix, a row per thread
+        int base, step;
+        if (P.dir == 0) { base = (i % r0) * N + i / r0; step = r0 * N; } // out[(a + r0 c) N + j], i = a + r0 j
+        else { base = r0 * (i / N) * N + i % N; step = N; }              // out[(c + r0 b) N + j], i = j + N b
+        for (int c0 = 0; c0 < n; c0 += CH) {
+            double x[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) x[u] = (c0 + u < n) ? P.out[base + step * (c0 + u)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
+        }
     }
-    __syncthreads();
+    mark_warm_rows(P, m, n, warmf, s_in, s_old);
+    const double boost = (double)(1 << WARM_BOOST_LOG2);
     int parity = 0;
     unsigned used = 0; // bit q: my q-th row (row tid + q NT) is a pivot row
-    // ---- tall LU with row pivoting: A = P L U, |L| <= 1; afterwards A holds L below the pivots (multipliers in place)
+    // ---- tall LU with row pivoting: A = P L U; afterwards A holds L below the pivots (multipliers in place)
     for (int kc = 0; kc < n; kc++) {
         unsigned long long key = 0;
         for (int i = tid, q = 0; i < m; i += NT, q++)
             if (!((used >> q) & 1u)) {
-                const unsigned long long kk = pivot_key(A[i + (long)kc * m], (unsigned long long)i);
+                const double x = A[i + kc * m];
+                const unsigned long long kk = pivot_key(warmf[i] ? x * boost : x, (unsigned long long)i);
                 key = kk > key ? kk : key;
             }
         const unsigned long long best = block_max(key, red, parity);
         const int p = (int)(IDX_MASK - (best & IDX_MASK));
-        const double dp = A[p + (long)kc * m];
+        const double dp = A[p + kc * m];
         if (tid == 0) { rows[kc] = p; pivabs[kc] = fabs(dp); }
         if (p % NT == tid) used |= 1u << (p / NT);
         const double inv = dp != 0.0 ? 1.0 / dp : 0.0;
         for (int i = tid, q = 0; i < m; i += NT, q++) {
             if ((used >> q) & 1u) continue;
-            const double l = A[i + (long)kc * m] * inv;
-            A[i + (long)kc * m] = l;
+            const double l = A[i + kc * m] * inv;
+            A[i + kc * m] = l;
             if (l != 0.0)
-                for (int c = kc + 1; c < n; c++) A[i + (long)c * m] -= l * A[p + (long)c * m];
+                for (int c0 = kc + 1; c0 < n; c0 += CH) {
+                    double x[CH], pc[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; u++) {
+                        const int c = c0 + u < n ? c0 + u : n - 1;
+                        x[u] = A[i + c * m];
+                        pc[u] = A[p + c * m];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CH; u++) x[u] -= l * pc[u];
+#pragma unroll
+                    for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
+                }
         }
         __syncthreads();
     }
     // ---- B = L inv(L[rows]): L[rows] is unit lower triangular in pivot order
     for (int e = tid; e < n * n; e += NT) {
         const int q = e / n, j = e % n;
-        Lr[q * 32 + j] = j < q ? A[rows[q] + (long)j * m] : (j == q ? 1.0 : 0.0);
+        Lr[q * 32 + j] = j < q ? A[rows[q] + j * m] : (j == q ? 1.0 : 0.0);
     }
     __syncthreads();
     for (int i = tid, q = 0; i < m; i += NT, q++) {
         if ((used >> q) & 1u) continue;
-        for (int j = n - 1; j >= 0; j--) { // x Lr = l, in place
-            double s = A[i + (long)j * m];
-            for (int t = j + 1; t < n; t++) s -= A[i + (long)t * m] * Lr[t * 32 + j];
-            A[i + (long)j * m] = s;
+        for (int j = n - 1; j >= 0; j--) { // x Lr = l, in place: s = l_j - sum_{t > j} x_t Lr[t][j], t ascending
+            double s = A[i + j * m];
+            for (int t0 = j + 1; t0 < n; t0 += CH) {
+                double xt[CH], w[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const int t = t0 + u < n ? t0 + u : n - 1;
+                    xt[u] = A[i + t * m];
+                    w[u] = Lr[t * 32 + j];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; u++) if (t0 + u < n) s -= xt[u] * w[u];
+            }
+            A[i + j * m] = s;
         }
     }
     __syncthreads();
     for (int e = tid; e < n * n; e += NT) { // pivot rows: unit vectors
         const int q = e / n, j = e % n;
-        A[rows[q] + (long)j * m] = (j == q) ? 1.0 : 0.0;
+        A[rows[q] + j * m] = (j == q) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // ---- maxvol: swap rows until the largest entry of B is <= 1.01
+    // ---- maxvol: swap rows until the largest entry of B is <= 1 + swap_tol
     int nswaps = 0;
     for (int it = 0; it < 200; it++) {
         unsigned long long key = 0;
-        for (int c = 0; c < n; c++)
-            for (int i = tid; i < m; i += NT) {
-                const unsigned long long kk = pivot_key(A[i + (long)c * m], (unsigned long long)c * (unsigned long long)m + (unsigned long long)i);
-                key = kk > key ? kk : key;
+        for (int i = tid; i < m; i += NT)
+            for (int c0 = 0; c0 < n; c0 += CH) {
+                double x[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) x[u] = A[i + (c0 + u < n ? c0 + u : n - 1) * m];
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const unsigned long long kk = (c0 + u < n) ? pivot_key(x[u], (unsigned long long)((c0 + u) * m + i)) : 0ull;
+                    key = kk > key ? kk : key;
+                }
             }
         const unsigned long long best = block_max(key, red, parity);
-        const long lin = (long)(IDX_MASK - (best & IDX_MASK));
-        const int bj = (int)(lin / m), bi = (int)(lin % m);
-        const double piv = A[bi + (long)bj * m];
-        if (!(fabs(piv) > 1.0 + 1e-2)) break;
-        if (tid < n) rowv[tid] = A[bi + (long)tid * m] - (tid == bj ? 1.0 : 0.0);
+        const int lin = (int)(IDX_MASK - (best & IDX_MASK));
+        const int bj = lin / m, bi = lin % m;
+        const double piv = A[bi + bj * m];
+        if (!(fabs(piv) > 1.0 + P.swap_tol)) break;
+        if (tid < n) rowv[tid] = A[bi + tid * m] - (tid == bj ? 1.0 : 0.0);
         __syncthreads();
         for (int i = tid; i < m; i += NT) {
-            const double cv = A[i + (long)bj * m] / piv;
+            const double cv = A[i + bj * m] / piv;
             if (cv != 0.0)
-                for (int c = 0; c < n; c++) A[i + (long)c * m] -= cv * rowv[c];
+                for (int c0 = 0; c0 < n; c0 += CH) {
+                    double x[CH], rc[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; u++) {
+                        const int c = c0 + u < n ? c0 + u : n - 1;
+                        x[u] = A[i + c * m];
+                        rc[u] = rowv[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CH; u++) x[u] -= cv * rc[u];
+#pragma unroll
+                    for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
+                }
         }
         if (tid == 0) rows[bj] = bi;
         nswaps++;
         __syncthreads();
     }
     __syncthreads();
-    // ---- results
-    if (P.dir == 0) {
-        for (long e = tid; e < (long)m * n; e += NT) P.G[e] = A[e]; // G[i + m b], i = a + r0 j
-        const int k = P.k;
-        for (int e = tid; e < n * (k + 1); e += NT) {
-            const int q = e / (k + 1), t = e % (k + 1);
-            const int row = rows[q], a = row % r0, j = row / r0;
-            P.set_out[e] = t < k ? P.set_in[a * k + t] : j;
+    sort_rows(n, rows, srows, pos);
+    // ---- results, columns in the order of ascending rows
+    for (int i = tid; i < m; i += NT)
+        for (int c0 = 0; c0 < n; c0 += CH) {
+            double x[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) x[u] = A[i + (c0 + u < n ? c0 + u : n - 1) * m];
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+                if (c0 + u < n) {
+                    if (P.dir == 0) P.G[i + m * pos[c0 + u]] = x[u];      // G[i + m b'], i = a + r0 j
+                    else P.G[pos[c0 + u] + r0 * i] = x[u];                // G[a' + r0 cc], cc = i
+                }
         }
-    } else {
-        for (long e = tid; e < (long)m * n; e += NT) { // G[a + r0 cc] = B[cc][a]
-            const int a = (int)(e % r0);
-            const long cc = e / r0;
-            P.G[e] = A[cc + (long)a * m];
-        }
-        const int len = P.d - P.k;
-        for (int e = tid; e < n * len; e += NT) {
-            const int q = e / len, t = e % len;
-            const int row = rows[q], j = row % N, b = row / N;
-            P.set_out[e] = t == 0 ? j : P.set_in[b * (len - 1) + (t - 1)];
-        }
-    }
-    if (tid == 0) {
-        double mx = 0.0, mn = INFINITY;
-        for (int c = 0; c < n; c++) { mx = pivabs[c] > mx ? pivabs[c] : mx; mn = pivabs[c] < mn ? pivabs[c] : mn; }
-        if (!(mn > 1e-12 * mx)) atomicExch(&P.counters[1], 1ull);
-        if (nswaps) atomicAdd(&P.counters[2], (unsigned long long)nswaps);
-    }
+    write_sets_and_next(P, n, srows, pivabs, nswaps);
 }
 
 } // namespace
@@ -291,20 +411,65 @@ struct c3sc_cross_dev {
     size_t slab_bytes = 0;
     size_t offI[MAXD] = {0}, offJ[MAXD] = {0}, offG[MAXD] = {0}, off_idx = 0, off_out = 0, off_work = 0, sets_bytes = 0, cores_bytes = 0,
            off_cores = 0;
-    // memo
-    unsigned long long *keys = nullptr;
-    double *vals = nullptr;
-    size_t cap = 0;
-    unsigned epoch = 0;
+    // node memos: values of the current value-iteration sweep; policies (candidate indices) of the current policy iteration
+    struct MemoTab {
+        unsigned long long *keys = nullptr;
+        double *vals = nullptr;
+        size_t cap = 0;
+        unsigned epoch = 0;
+    } vmemo, pmemo;
+    long long policy_tag = -1; // the caller's policy-iteration counter the policy memo belongs to
+    size_t off_uidx = 0;       // [Fmax][Nmax] candidate indices between the policy pass and the evaluation pass
     Strides strides;
     unsigned long long *counters = nullptr; // device [4]
     // pinned host staging for the one-copy upload / download
     char *stage = nullptr;
     size_t stage_bytes = 0;
     bool lds_optin = false;
+    int warm = 1;
+    double swap_tol = 0.05;
 };
 
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int memo_shift_of(size_t cap)
+{
+    int shift = 64;
+    for (size_t cp = cap; cp > 1; cp >>= 1) shift--;
+    return shift;
+}
+
+// at least `want` slots (a power of two); keep = the entries of the current epoch move over (growth in the middle of a sweep)
+static int memo_ensure(c3sc_hip_ctx *c, c3sc_cross_dev::MemoTab &t, size_t want, bool keep)
+{
+    if (want <= t.cap) return C3SC_OK;
+    unsigned long long *nk = nullptr;
+    double *nv = nullptr;
+    HIPCHK(c, hipMalloc((void **)&nk, want * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc((void **)&nv, want * sizeof(double)));
+    HIPCHK(c, hipMemset(nk, 0, want * sizeof(unsigned long long)));
+    if (t.keys && keep && t.epoch != 0) {
+        hipLaunchKernelGGL(k_cross_memo_rehash, dim3(256), dim3(256), 0, nullptr, t.keys, t.vals, (unsigned long long)t.cap, nk, nv,
+                           (unsigned long long)(want - 1), memo_shift_of(want), (unsigned long long)t.epoch << 49);
+        HIPCHK(c, hipDeviceSynchronize());
+    } else {
+        t.epoch = 0;
+    }
+    if (t.keys) HIPCHK(c, hipFree(t.keys));
+    if (t.vals) HIPCHK(c, hipFree(t.vals));
+    t.keys = nk; t.vals = nv; t.cap = want;
+    return C3SC_OK;
+}
+
+static int memo_new_epoch(c3sc_hip_ctx *c, c3sc_cross_dev::MemoTab &t)
+{
+    t.epoch++;
+    if (t.epoch > 0x7FFF) { // the epoch field wrapped: really clear
+        HIPCHK(c, hipMemset(t.keys, 0, t.cap * sizeof(unsigned long long)));
+        t.epoch = 1;
+    }
+    return C3SC_OK;
+}
 
 extern "C" {
 
@@ -313,8 +478,10 @@ void c3sc_hip_cross_free(c3sc_hip_ctx *c)
     if (!c || !c->cross) return;
     c3sc_cross_dev *x = c->cross;
     if (x->slab) (void)hipFree(x->slab);
-    if (x->keys) (void)hipFree(x->keys);
-    if (x->vals) (void)hipFree(x->vals);
+    for (auto *t : {&x->vmemo, &x->pmemo}) {
+        if (t->keys) (void)hipFree(t->keys);
+        if (t->vals) (void)hipFree(t->vals);
+    }
     if (x->counters) (void)hipFree(x->counters);
     if (x->stage) (void)hipHostFree(x->stage);
     delete x;
@@ -347,7 +514,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     for (int k = 0; k < d; k++) {
         const size_t F = (size_t)x->r[k] * x->r[k + 1], sz = F * x->N[k];
         fmax = std::max(fmax, F); nmax = std::max(nmax, (size_t)x->N[k]); wmax = std::max(wmax, sz);
-        if (sz > (IDX_MASK + 1) / 2 || (size_t)x->r[k] * x->N[k] > 32 * NT || (size_t)x->N[k] * x->r[k + 1] > 32 * NT)
+        if (sz > (IDX_MASK + 1) / 2 || (size_t)x->r[k] * x->N[k] > MAXROWS || (size_t)x->N[k] * x->r[k + 1] > MAXROWS)
             return fail(c, C3SC_ERR_UNSUPPORTED, "cross_setup: core too large for the one-workgroup factorisation");
         x->offG[k] = off; off += up256(sz * sizeof(double));
     }
@@ -355,6 +522,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     x->off_idx = off; off += up256(fmax * d * sizeof(int32_t));
     x->off_out = off; off += up256(fmax * nmax * sizeof(double));
     x->off_work = off; off += up256(wmax * sizeof(double));
+    x->off_uidx = off; off += up256(fmax * nmax * sizeof(int32_t));
     if (off > x->slab_bytes) {
         if (x->slab) HIPCHK(c, hipFree(x->slab));
         x->slab = nullptr; x->slab_bytes = 0;
@@ -372,36 +540,16 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
         HIPCHK(c, hipMalloc((void **)&x->counters, 4 * sizeof(unsigned long long)));
         HIPCHK(c, hipMemset(x->counters, 0, 4 * sizeof(unsigned long long)));
     }
-    // memo: every node a sweep can touch (5 iterations x 2 half sweeps x sum_k F_k N_k, before rank kicks) at load <= 1/2
+    // value memo: every node a sweep can touch (5 iterations x 2 half sweeps x sum_k F_k N_k, before rank kicks) at load <= 1/3
     size_t nodes = 0;
     for (int k = 0; k < d; k++) nodes += (size_t)x->r[k] * x->r[k + 1] * x->N[k];
     size_t want = 1 << 16;
     while (want < 32 * nodes) want <<= 1;
-    if (want > x->cap) { // grow; a sweep in progress (rank kick between cross rounds) keeps its entries
-        unsigned long long *nk = nullptr;
-        double *nv = nullptr;
-        HIPCHK(c, hipMalloc((void **)&nk, want * sizeof(unsigned long long)));
-        HIPCHK(c, hipMalloc((void **)&nv, want * sizeof(double)));
-        HIPCHK(c, hipMemset(nk, 0, want * sizeof(unsigned long long)));
-        if (x->keys && !new_sweep && x->epoch != 0) {
-            int sh = 64;
-            for (size_t cp = want; cp > 1; cp >>= 1) sh--;
-            hipLaunchKernelGGL(k_cross_memo_rehash, dim3(256), dim3(256), 0, nullptr, x->keys, x->vals, (unsigned long long)x->cap, nk, nv,
-                               (unsigned long long)(want - 1), sh, (unsigned long long)x->epoch << 49);
-            HIPCHK(c, hipDeviceSynchronize());
-        } else {
-            x->epoch = 0;
-        }
-        if (x->keys) HIPCHK(c, hipFree(x->keys));
-        if (x->vals) HIPCHK(c, hipFree(x->vals));
-        x->keys = nk; x->vals = nv; x->cap = want;
-    }
-    if (new_sweep || x->epoch == 0) {
-        x->epoch++;
-        if (x->epoch > 0x7FFF) { // epoch field wrapped: really clear
-            HIPCHK(c, hipMemset(x->keys, 0, x->cap * sizeof(unsigned long long)));
-            x->epoch = 1;
-        }
+    {
+        const bool fresh = new_sweep || x->vmemo.epoch == 0;
+        int rc = memo_ensure(c, x->vmemo, want, !fresh);
+        if (rc != C3SC_OK) return rc;
+        if (fresh || x->vmemo.epoch == 0) { rc = memo_new_epoch(c, x->vmemo); if (rc != C3SC_OK) return rc; }
     }
     long long s = 1;
     for (int m = d - 1; m >= 0; m--) { x->strides.s[m] = s; s *= x->N[m]; }
@@ -420,48 +568,103 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     return C3SC_OK;
 }
 
-/* one cross iteration: left-to-right half sweep (new left index sets), then right-to-left (new right index sets); the cores
- * of the right-to-left half sweep are the iteration's result */
-int c3sc_hip_cross_iteration(c3sc_hip_ctx *c, int box, void *stream)
+/* pivot-search options of the core steps (defaults: warm start on, swap tolerance 0.05 -- the host driver's) */
+int c3sc_hip_cross_options(c3sc_hip_ctx *c, int warm_pivots, double swap_tol)
 {
-    if (!c || !c->cross) return fail(c, C3SC_ERR_ARG, "cross_iteration: cross_setup first");
+    if (!c || !(swap_tol >= 0.0)) return fail(c, C3SC_ERR_ARG, "cross_options: bad arguments");
+    if (!c->cross) c->cross = new c3sc_cross_dev();
+    c->cross->warm = warm_pivots ? 1 : 0;
+    c->cross->swap_tol = swap_tol;
+    return C3SC_OK;
+}
+
+/* one cross iteration: left-to-right half sweep (new left index sets), then right-to-left (new right index sets); the cores
+ * of the right-to-left half sweep are the iteration's result.  pol == null: the fibers are bellman_vi's (value memo);
+ * pol != null: bellman_pi's -- per core step the greedy policy of pol's value function (policy memo, first entry stays for
+ * the whole policy iteration `policy_tag`), then the evaluation of that policy on c's value function (no value memo: the
+ * reference's is never hit). */
+static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long policy_tag, int box, void *stream)
+{
+    if (!c || !c->cross || c->cross->d == 0) return fail(c, C3SC_ERR_ARG, "cross_iteration: cross_setup first");
     c3sc_cross_dev *x = c->cross;
     const int d = x->d;
     hipStream_t st = (hipStream_t)stream;
-    int shift = 64;
-    for (size_t cp = x->cap; cp > 1; cp >>= 1) shift--;
-    for (int half = 0; half < 2; half++)
-        for (int s = 0; s < d; s++) {
-            const int k = half == 0 ? s : d - 1 - s;
-            const int r0 = x->r[k], r1 = x->r[k + 1], N = x->N[k];
-            const size_t F = (size_t)r0 * r1;
-            int32_t *idx = (int32_t *)(x->slab + x->off_idx);
-            double *out = (double *)(x->slab + x->off_out);
-            const int32_t *Ik = (const int32_t *)(x->slab + x->offI[k]), *Jk = (const int32_t *)(x->slab + x->offJ[k]);
-            hipLaunchKernelGGL(k_cross_idx, dim3((unsigned)((F * d + 255) / 256)), dim3(256), 0, st, idx, Ik, Jk, r0, r1, k, d);
-            int rc = box ? c3sc_hip_bellman_fibers_box(c, k, F, idx, out, nullptr, nullptr, stream)
-                         : c3sc_hip_bellman_fibers(c, k, F, idx, out, nullptr, nullptr, stream);
+    if (pol) {
+        if (box) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: candidate lists only");
+        if (pol->d != d) return fail(c, C3SC_ERR_ARG, "cross_iteration_pi: the policy context has another grid");
+        size_t nodes = 0;
+        for (int k = 0; k < d; k++) nodes += (size_t)x->r[k] * x->r[k + 1] * x->N[k];
+        size_t want = 1 << 16;
+        while (want < 256 * nodes) want <<= 1; // a policy iteration runs ~10 evaluation sweeps over one policy memo
+        const bool fresh = policy_tag != x->policy_tag || x->pmemo.epoch == 0;
+        int rc = memo_ensure(c, x->pmemo, want, !fresh);
+        if (rc != C3SC_OK) return rc;
+        if (fresh) { rc = memo_new_epoch(c, x->pmemo); if (rc != C3SC_OK) return rc; x->policy_tag = policy_tag; }
+    }
+    c3sc_cross_dev::MemoTab &mt = pol ? x->pmemo : x->vmemo;
+    const int shift = memo_shift_of(mt.cap);
+    int32_t *idx = (int32_t *)(x->slab + x->off_idx), *uidx = (int32_t *)(x->slab + x->off_uidx);
+    double *out = (double *)(x->slab + x->off_out);
+    auto setI = [&](int k) { return (int32_t *)(x->slab + x->offI[k]); };
+    auto setJ = [&](int k) { return (int32_t *)(x->slab + x->offJ[k]); };
+    // the first step's fiber list; every later one is written by the core step before it
+    hipLaunchKernelGGL(k_cross_idx, dim3((unsigned)(((size_t)x->r[0] * x->r[1] * d + 255) / 256)), dim3(256), 0, st, idx, setI(0), setJ(0), x->r[0],
+                       x->r[1], 0, d);
+    for (int s = 0; s < 2 * d; s++) {
+        const int half = s / d, k = half == 0 ? s : 2 * d - 1 - s;
+        const int r0 = x->r[k], r1 = x->r[k + 1], N = x->N[k];
+        const size_t F = (size_t)r0 * r1;
+        const long total = (long)F * N;
+        // the fiber-per-wave kernel applies the memo in its epilogue (ctx->memo); any other kernel is followed by the memo pass
+        c3sc_hip_ctx *mc = pol ? pol : c; // the context whose launch carries the memo
+        mc->memo.keys = mt.keys; mc->memo.vals = mt.vals; mc->memo.capmask = (unsigned long long)(mt.cap - 1); mc->memo.shift = shift;
+        mc->memo.epoch_bits = (unsigned long long)mt.epoch << 49; mc->memo.counters = x->counters; mc->memo.mode = pol ? 1 : 0;
+        for (int m = 0; m < d; m++) mc->memo.stride[m] = x->strides.s[m];
+        mc->memo.applied = false;
+        int rc;
+        if (pol) rc = c3sc_hip_bellman_fibers(pol, k, F, idx, out, uidx, nullptr, stream); // values unused: the policy is the output
+        else rc = box ? c3sc_hip_bellman_fibers_box(c, k, F, idx, out, nullptr, nullptr, stream)
+                      : c3sc_hip_bellman_fibers(c, k, F, idx, out, nullptr, nullptr, stream);
+        mc->memo.keys = nullptr;
+        if (rc != C3SC_OK) { if (pol && rc != C3SC_OK) c->err = pol->err; return rc; }
+        if (pol) {
+            if (!mc->memo.applied) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: the policy pass needs the fiber-per-wave kernel");
+            rc = c3sc_hip_policy_fibers(c, k, F, idx, uidx, out, nullptr, stream);
             if (rc != C3SC_OK) return rc;
-            const long total = (long)F * N;
-            hipLaunchKernelGGL(k_cross_memo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, idx, out, total, N, d, k, x->strides,
-                               x->keys, x->vals, (unsigned long long)(x->cap - 1), shift, (unsigned long long)x->epoch << 49, x->counters);
-            CoreArgs P;
-            P.out = out; P.r0 = r0; P.N = N; P.r1 = r1; P.k = k; P.d = d;
-            P.dir = half;
-            P.copy_only = (half == 0) ? (k == d - 1) : (k == 0);
-            P.set_in = half == 0 ? Ik : Jk;
-            P.set_out = P.copy_only ? nullptr : (half == 0 ? (int32_t *)(x->slab + x->offI[k + 1]) : (int32_t *)(x->slab + x->offJ[k - 1]));
-            P.G = (double *)(x->slab + x->offG[k]);
-            P.work = (double *)(x->slab + x->off_work);
-            P.counters = x->counters;
-            const size_t mn = F * N * sizeof(double);
-            if (P.copy_only || mn <= LDS_CAP_BYTES)
-                hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), P.copy_only ? 0 : mn, st, P);
-            else
-                hipLaunchKernelGGL(k_cross_core<false>, dim3(1), dim3(NT), 0, st, P);
+        } else if (!mc->memo.applied)
+            hipLaunchKernelGGL(k_cross_memo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, idx, out, total, N, d, k, x->strides, mt.keys,
+                               mt.vals, (unsigned long long)(mt.cap - 1), shift, (unsigned long long)mt.epoch << 49, x->counters);
+        CoreArgs P;
+        P.out = out; P.r0 = r0; P.N = N; P.r1 = r1; P.k = k; P.d = d;
+        P.dir = half;
+        P.copy_only = (half == 0) ? (k == d - 1) : (k == 0);
+        P.set_in = half == 0 ? setI(k) : setJ(k);
+        P.set_out = P.copy_only ? nullptr : (half == 0 ? setI(k + 1) : setJ(k - 1));
+        P.G = (double *)(x->slab + x->offG[k]);
+        P.work = (double *)(x->slab + x->off_work);
+        P.counters = x->counters;
+        P.warm = x->warm;
+        P.swap_tol = x->swap_tol;
+        P.nidx = nullptr; P.nI = P.nJ = nullptr; P.nr0 = P.nr1 = P.nk = 0;
+        if (s + 1 < 2 * d) {
+            const int nh = (s + 1) / d, nk = nh == 0 ? s + 1 : 2 * d - 2 - s;
+            P.nidx = idx; P.nI = setI(nk); P.nJ = setJ(nk); P.nr0 = x->r[nk]; P.nr1 = x->r[nk + 1]; P.nk = nk;
         }
+        const size_t mn = F * N * sizeof(double);
+        if (P.copy_only) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), 0, st, P);
+        else if (mn <= LDS_CAP_BYTES) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), mn, st, P);
+        else hipLaunchKernelGGL(k_cross_core<false>, dim3(1), dim3(NT), 0, st, P);
+    }
     HIPCHK(c, hipGetLastError());
     return C3SC_OK;
+}
+
+int c3sc_hip_cross_iteration(c3sc_hip_ctx *c, int box, void *stream) { return cross_iteration_impl(c, nullptr, 0, box, stream); }
+
+int c3sc_hip_cross_iteration_pi(c3sc_hip_ctx *c, c3sc_hip_ctx *policy_ctx, long long policy_tag, void *stream)
+{
+    if (!policy_ctx) return fail(c, C3SC_ERR_ARG, "cross_iteration_pi: null policy context");
+    return cross_iteration_impl(c, policy_ctx, policy_tag, 0, stream);
 }
 
 /* wait for the iteration and bring back: cores (working layout G[a + r_k (j + N_k b)]), both families of index sets, and

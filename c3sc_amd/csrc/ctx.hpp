@@ -57,6 +57,17 @@ struct c3sc_hip_ctx {
     // pinned, device-mapped host block for small *_host batches (read and written by the kernel in place)
     void *pinned = nullptr, *pinned_dev = nullptr;
     size_t pinned_bytes = 0;
+    // node memo requested for the next Bellman launch (set by c3sc_hip_cross_iteration around its launches)
+    struct {
+        unsigned long long *keys = nullptr;
+        double *vals = nullptr;
+        unsigned long long capmask = 0, epoch_bits = 0;
+        int shift = 0;
+        long long stride[c3sc::MAXD] = {0};
+        unsigned long long *counters = nullptr;
+        int mode = 0;         // KArgs::memo_mode
+        bool applied = false; // the launched kernel carried the memo in its epilogue
+    } memo;
     c3sc_cross_dev *cross = nullptr; // owned; freed by c3sc_hip_cross_free (called from c3sc_hip_ctx_destroy)
 };
 

@@ -56,6 +56,17 @@ struct KArgs {
     long quad_imgR_off[MAXD];  //             and of the transposed cores (suffix side); read through img_base by LDS-DMA
     long pair_img_off[MAXD];   // every core once more as the fiber-pair kernel's LDS image: [N][elems | 1] (k_core_image)
     int cends;                 // c3sc_hip_set_consistent_ends: see vary_neighbors
+    // node memo of the device-resident cross iterations (cross_device.hip), applied in the epilogue of the fiber-per-wave kernel
+    // when memo_keys != null: a node already stored in this sweep takes the stored value, a new one is stored
+    // (bellman.c:1333-1353, 1412-1417)
+    unsigned long long *memo_keys;
+    double *memo_vals;
+    unsigned long long memo_capmask, memo_epoch_bits;
+    int memo_shift;
+    long long memo_stride[MAXD];
+    unsigned long long *memo_counters; // [0] nodes stored, [3] table full
+    int memo_mode; // 0: the node's VALUE (bellman_vi's memo); 1: its POLICY, the winning candidate index of a live node
+                   // (bellman_pi's per-node cache under key2, bellman.c:1806, 1877)
     const double *img_base;    // the arena again, as a pointer that is NOT the kernels' `ro` argument: the LDS-DMA copy reads the
                                // images through it (see stage_core_image on why it must not be derived from `ro`)
 };
@@ -120,6 +131,35 @@ __device__ inline int vary_neighbors(int j, int n, int bc, int ab_in, int &lo, i
         hi = j;
     }
     return ab;
+}
+
+// Node memo (open addressing, linear probing).  Key word: [63:49] epoch of the sweep (never 0) | [48] pending | [47:0] node id;
+// a slot whose epoch is not the current one is free, so the table is cleared by advancing the epoch.  A hit returns the stored
+// value (first value stays, bellman.c:1349-1353), a miss stores v.  The same node twice in one batch is the same fiber twice
+// (a batch varies one dimension), i.e. identical values: the loser of that race keeps its own.  *inserted reports a store.
+constexpr unsigned long long MEMO_PENDING = 1ull << 48, MEMO_EPOCH_MASK = ~((1ull << 49) - 1), MEMO_ID_MASK = (1ull << 48) - 1;
+__device__ inline double memo_merge(unsigned long long *keys, double *vals, unsigned long long capmask, int shift, unsigned long long epoch_bits,
+                                    unsigned long long id, double v, int &inserted, int &overflow)
+{
+    const unsigned long long K = epoch_bits | id, KP = K | MEMO_PENDING;
+    unsigned long long slot = (id * 0x9E3779B97F4A7C15ull) >> shift;
+    for (unsigned long long probe = 0; probe <= capmask; probe++, slot = (slot + 1) & capmask) {
+        unsigned long long cur = __hip_atomic_load(&keys[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        while ((cur & MEMO_EPOCH_MASK) != epoch_bits) { // free: claim it
+            const unsigned long long prev = atomicCAS(&keys[slot], cur, KP);
+            if (prev == cur) {
+                vals[slot] = v;
+                __hip_atomic_store(&keys[slot], K, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                inserted = 1;
+                return v;
+            }
+            cur = prev;
+        }
+        if ((cur & ~MEMO_PENDING) == K) // this node: stored by an earlier batch (complete) or by a twin of this batch (pending)
+            return (cur & MEMO_PENDING) ? v : __hip_atomic_load(&vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    overflow = 1;
+    return v;
 }
 
 // boundary_in_obstacle (boundary.c:668-680, bound_rect_inside :329-344): inclusive boxes.

@@ -340,6 +340,21 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
                     table_values<Model>(A, ro, ix, tv);
                     val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
                 }
+                if (A.memo_keys) { // wave-uniform: node memo of the device-resident cross iterations
+                    int ins = 0, ovf = 0;
+                    if (live && (A.memo_mode == 0 || ab == 0)) {
+                        unsigned long long id = 0;
+#pragma unroll
+                        for (int m = 0; m < D; m++) id += (unsigned long long)ix[m] * (unsigned long long)A.memo_stride[m];
+                        const double mv = memo_merge(A.memo_keys, A.memo_vals, A.memo_capmask, A.memo_shift, A.memo_epoch_bits, id,
+                                                     A.memo_mode == 0 ? val : (double)ui, ins, ovf);
+                        if (A.memo_mode == 0) val = mv;
+                        else ui = (int)mv;
+                    }
+                    const unsigned long long mk = __ballot(ins);
+                    if (mk != 0 && lane == 0) atomicAdd(&A.memo_counters[0], (unsigned long long)__popcll(mk));
+                    if (__any(ovf) && lane == 0) atomicExch(&A.memo_counters[3], 1ull);
+                }
                 if (live) {
                     outv[(size_t)f * N + j] = val;
                     if (uidx) uidx[(size_t)f * N + j] = ui;

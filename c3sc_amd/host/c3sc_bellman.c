@@ -1316,7 +1316,7 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
     if (dp_has_device_model(c->dp) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL) {
         struct c3sc_hip_ctx *ctx = sync_device(vi);
         size_t nodes = 0;
-        next = c3sc_interp_device(c->dx, ctx, !c3opt_is_bruteforce(opt), c->ngrid, c->xgrid, vf, aa, verbose, &nodes);
+        next = c3sc_interp_device(c->dx, ctx, !c3opt_is_bruteforce(opt), c->ngrid, c->xgrid, vf, aa, verbose, &nodes, NULL, 0, NULL);
         vi->nnode_evals += nodes;
         vi->nstate_evals += nodes;
     } else
@@ -1332,8 +1332,23 @@ struct ValueF *c3control_step_pi(struct C3Control *c, struct ValueF *vf, struct 
 { /* bellman.c:2214-2262 */
     c3control_begin_pi_step(c, poli, vf, opt);
     struct ApproxArgs *aa = device_rank_cap(c, apargs);
-    struct ValueF *next = valuef_interp_idx_sharded(c->dx, bellman_pi_batch_idx, poli, c->ngrid, c->xgrid, vf, aa, verbose,
-                                                    c->shard_world, c->shard_rank, c->shard_exchange, c->shard_xarg);
+    struct ValueF *next;
+    /* whole cross iterations on the device, as in c3control_step_vi: candidate lists of a device model, unsharded */
+    const int sharded = c->shard_world > 1 && c->shard_exchange != NULL;
+    const int checked = c->dp->model_checked || c->dp->stagecost == NULL || c->dp->boundcost == NULL || c->dp->obscost == NULL;
+    if (dp_has_device_model(c->dp) && c3opt_is_bruteforce(opt) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL) {
+        struct ControlParams *cp = poli->cp;
+        struct c3sc_hip_ctx *ctx_it = sync_device_ctx(cp, workspace_get_hip_ctx(cp->work), poli->vf_iteration);
+        struct c3sc_hip_ctx *ctx_pol = sync_device_ctx(cp, workspace_get_hip_ctx_policy(cp->work), poli->vf_policy);
+        size_t npol = 0, requested = 0;
+        next = c3sc_interp_device(c->dx, ctx_it, 0, c->ngrid, c->xgrid, vf, aa, verbose, &npol, ctx_pol, (long long)workspace_get_pi_iter(cp->work),
+                                  &requested);
+        poli->npol_evals += npol;
+        poli->niter_evals += requested;
+        poli->niter_node_evals += requested;
+    } else
+        next = valuef_interp_idx_sharded(c->dx, bellman_pi_batch_idx, poli, c->ngrid, c->xgrid, vf, aa, verbose, c->shard_world,
+                                         c->shard_rank, c->shard_exchange, c->shard_xarg);
     approx_args_free(aa);
     c3control_end_pi_step(c, poli, niter_evals);
     return next;

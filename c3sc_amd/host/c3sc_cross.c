@@ -115,16 +115,27 @@ static inline uint64_t pivot_key(double x, uint64_t index)
     return ((bits >> PIV_IDX_BITS) << PIV_IDX_BITS) | (PIV_IDX_MASK - index);
 }
 
-C3SC_CLONES static int lu_maxvol(size_t m, size_t n, double *A, size_t *rows, size_t *nswaps)
+/* Warm start and hysteresis.  warm[i] != 0 marks the rows of the index set this core step produced last time (matched through the
+ * current tuples of the neighbouring set).  The pivot search multiplies their magnitudes by 2^WARM_BOOST_LOG2, so the factorisation
+ * keeps the previous rows unless one of them has become a poor pivot; B depends only on the SET of rows, so if that set is still
+ * dominant to within SWAP_TOL no swap happens and the step reproduces its index set exactly.  A converged value iteration then
+ * sees a fixed interpolation scheme instead of pivots that jump between equally good rows with the last bits of the fiber
+ * values (round 2: 15-27 % jumps of single control updates).  Both constants are part of the algorithm's definition: the device
+ * twin uses the same. */
+#define WARM_BOOST_LOG2 6
+static double g_swap_tol = 0.05; /* swap while max |B| > 1 + tol (maxvol's usual 1e-2 .. 1e-1) */
+
+C3SC_CLONES static int lu_maxvol(size_t m, size_t n, double *A, size_t *rows, size_t *nswaps, const unsigned char *warm)
 {
     if (m * n > PIV_IDX_MASK) DIE("lu_maxvol: matrix too large");
+    const double boost = (double)(1u << WARM_BOOST_LOG2);
     unsigned char *used = xcalloc(m, 1);
     double *pivabs = xcalloc(n, sizeof(double)), *Lr = xcalloc(n * n, sizeof(double)), *rowv = xcalloc(n, sizeof(double)), *colv = xcalloc(m, sizeof(double));
     for (size_t kc = 0; kc < n; kc++) {
         double *ak = A + kc * m;
         uint64_t key = 0;
         for (size_t i = 0; i < m; i++)
-            if (!used[i]) { const uint64_t kk = pivot_key(ak[i], i); if (kk > key) key = kk; }
+            if (!used[i]) { const uint64_t kk = pivot_key((warm && warm[i]) ? ak[i] * boost : ak[i], i); if (kk > key) key = kk; }
         const size_t p = (size_t)(PIV_IDX_MASK - (key & PIV_IDX_MASK));
         const double dp = ak[p];
         rows[kc] = p;
@@ -159,7 +170,7 @@ C3SC_CLONES static int lu_maxvol(size_t m, size_t n, double *A, size_t *rows, si
         }
         const size_t lin = (size_t)(PIV_IDX_MASK - (key & PIV_IDX_MASK)), bj = lin / m, bi = lin % m;
         const double piv = A[bi + bj * m];
-        if (!(fabs(piv) > 1.0 + 1e-2)) break;
+        if (!(fabs(piv) > 1.0 + g_swap_tol)) break;
         for (size_t c = 0; c < n; c++) rowv[c] = A[bi + c * m] - (c == bj ? 1.0 : 0.0);
         for (size_t i = 0; i < m; i++) colv[i] = A[i + bj * m] / piv;
         for (size_t c = 0; c < n; c++) {
@@ -169,6 +180,29 @@ C3SC_CLONES static int lu_maxvol(size_t m, size_t n, double *A, size_t *rows, si
         }
         rows[bj] = bi;
         ns++;
+    }
+    /* canonical order: rows ascending (B's columns follow), so that the same SET of rows gives the same index set and core
+     * whatever order the pivots were found in -- a cross iteration that changes nothing is then recognisable as such */
+    {
+        size_t *perm = xcalloc(n, sizeof(size_t));
+        for (size_t q = 0; q < n; q++) perm[q] = q;
+        for (size_t q = 1; q < n; q++) { /* insertion sort of perm by rows[perm[.]] */
+            const size_t pq = perm[q];
+            size_t t = q;
+            while (t > 0 && rows[perm[t - 1]] > rows[pq]) { perm[t] = perm[t - 1]; t--; }
+            perm[t] = pq;
+        }
+        int sorted = 1;
+        for (size_t q = 0; q < n; q++) if (perm[q] != q) sorted = 0;
+        if (!sorted) {
+            double *T = xcalloc(m * n, sizeof(double));
+            size_t *rn = xcalloc(n, sizeof(size_t));
+            for (size_t q = 0; q < n; q++) { memcpy(T + q * m, A + perm[q] * m, m * sizeof(double)); rn[q] = rows[perm[q]]; }
+            memcpy(A, T, m * n * sizeof(double));
+            memcpy(rows, rn, n * sizeof(size_t));
+            free(T); free(rn);
+        }
+        free(perm);
     }
     double mx = 0.0, mn = INFINITY;
     for (size_t c = 0; c < n; c++) { if (pivabs[c] > mx) mx = pivabs[c]; if (pivabs[c] < mn) mn = pivabs[c]; }
@@ -624,10 +658,14 @@ struct cross {
     int verbose;
     int deficient;  /* a core step of the current cross iteration saw an (exactly) rank-deficient fiber matrix */
     size_t nswaps;  /* maxvol row swaps so far (diagnostics) */
+    int warm;       /* core steps start their pivot search from the rows of the index set they produced last time */
     /* device-resident core steps (c3sc_hip_cross_*): the fibers of this interpolation are the batched Bellman operator of dev */
     struct c3sc_hip_ctx *dev;
     int dev_box, dev_fresh; /* control box instead of a candidate list; index sets / ranks changed since the last upload */
     int dev_new_sweep;      /* the next upload starts a new memo epoch */
+    struct c3sc_hip_ctx *dev_pol; /* bellman_pi: context holding the policy's value function, or NULL (bellman_vi) */
+    long long dev_tag;            /* bellman_pi: the policy iteration the policy memo belongs to */
+    unsigned long long dev_requested; /* nodes of all fibers asked for */
     unsigned long long dev_nodes; /* nodes stored in the device memo during this interpolation (the reference's nnode_evals) */
 };
 
@@ -698,7 +736,17 @@ static struct tt *cross_sweep_lr(struct cross *c)
         assert(m >= r1);
         size_t *rows = xcalloc(r1, sizeof(size_t));
         memcpy(t->G[k], C, m * r1 * sizeof(double));
-        TIMED(2, if (lu_maxvol(m, r1, t->G[k], rows, &c->nswaps)) c->deficient = 1);
+        /* rows of the previous I_{k+1}: tuple (u_0..u_{k-1}, j) is row a + r0 j if I_k[a] == (u_0..u_{k-1}) */
+        unsigned char *warm = xcalloc(m, 1);
+        if (c->warm)
+            for (size_t q = 0; q < r1; q++) {
+                const int *u = c->I[k + 1] + q * (k + 1);
+                if (u[k] < 0 || (size_t)u[k] >= N) continue;
+                for (size_t a = 0; a < r0; a++)
+                    if (k == 0 || memcmp(c->I[k] + a * k, u, k * sizeof(int)) == 0) { warm[a + r0 * (size_t)u[k]] = 1; break; }
+            }
+        TIMED(2, if (lu_maxvol(m, r1, t->G[k], rows, &c->nswaps, warm)) c->deficient = 1);
+        free(warm);
         /* I_{k+1}[b] = (I_k[a], j) with row = a + r0*j */
         int *In = xcalloc(r1 * (k + 1), sizeof(int));
         for (size_t b = 0; b < r1; b++) {
@@ -728,7 +776,19 @@ static struct tt *cross_sweep_rl(struct cross *c)
         for (size_t cc = 0; cc < cols; cc++)
             for (size_t a = 0; a < r0; a++) Ct[cc + a * cols] = C[a + r0 * cc];
         size_t *rows = xcalloc(r0, sizeof(size_t));
-        TIMED(2, if (lu_maxvol(cols, r0, Ct, rows, &c->nswaps)) c->deficient = 1);
+        /* rows of the previous J_{k-1}: tuple (j, v_1..) is row j + N b if J_k[b] == (v_1..) */
+        unsigned char *warm = xcalloc(cols, 1);
+        if (c->warm) {
+            const size_t len = d - k;
+            for (size_t q = 0; q < r0; q++) {
+                const int *u = c->J[k - 1] + q * len;
+                if (u[0] < 0 || (size_t)u[0] >= N) continue;
+                for (size_t b = 0; b < r1; b++)
+                    if (len == 1 || memcmp(c->J[k] + b * (len - 1), u + 1, (len - 1) * sizeof(int)) == 0) { warm[(size_t)u[0] + N * b] = 1; break; }
+            }
+        }
+        TIMED(2, if (lu_maxvol(cols, r0, Ct, rows, &c->nswaps, warm)) c->deficient = 1);
+        free(warm);
         for (size_t cc = 0; cc < cols; cc++)
             for (size_t a = 0; a < r0; a++) t->G[k][a + r0 * cc] = Ct[cc + a * cols];
         /* J_{k-1}[a] = (j, J_k[b]) with col = j + N*b */
@@ -754,12 +814,13 @@ static struct tt *cross_iteration_device(struct cross *c)
 {
     const size_t d = c->d;
     if (c->dev_fresh) {
+        if (c3sc_hip_cross_options(c->dev, c->warm, g_swap_tol) != 0) DIE("c3sc_hip_cross_options: %s", c3sc_hip_last_error(c->dev));
         int rc = c3sc_hip_cross_setup(c->dev, c->r, (const int32_t *const *)c->I, (const int32_t *const *)c->J, c->dev_new_sweep);
         if (rc != 0) DIE("c3sc_hip_cross_setup: %s", c3sc_hip_last_error(c->dev));
         c->dev_fresh = 0;
         c->dev_new_sweep = 0;
     }
-    int rc = c3sc_hip_cross_iteration(c->dev, c->dev_box, NULL);
+    int rc = c->dev_pol ? c3sc_hip_cross_iteration_pi(c->dev, c->dev_pol, c->dev_tag, NULL) : c3sc_hip_cross_iteration(c->dev, c->dev_box, NULL);
     if (rc != 0) DIE("c3sc_hip_cross_iteration: %s", c3sc_hip_last_error(c->dev));
     struct tt *t = tt_alloc(d, c->N, c->r);
     unsigned long long info[4] = {0, 0, 0, 0};
@@ -769,7 +830,7 @@ static struct tt *cross_iteration_device(struct cross *c)
     c->dev_nodes += info[0];
     if (info[1]) c->deficient = 1;
     c->nswaps += (size_t)info[2];
-    for (size_t k = 0; k < d; k++) c->nfibers += 2 * c->r[k] * c->r[k + 1];
+    for (size_t k = 0; k < d; k++) { c->nfibers += 2 * c->r[k] * c->r[k + 1]; c->dev_requested += 2 * c->r[k] * c->r[k + 1] * c->N[k]; }
     return t;
 }
 
@@ -818,7 +879,7 @@ static int same_sets(const struct cross *c, int **A, int **B, int right)
 }
 static void free_sets(const struct cross *c, int **S) { for (size_t k = 0; k < c->d; k++) free(S[k]); free(S); }
 
-struct dev_fibers { struct c3sc_hip_ctx *ctx; int box; unsigned long long nodes; };
+struct dev_fibers { struct c3sc_hip_ctx *ctx, *pol; long long tag; int box; unsigned long long nodes, requested; };
 
 static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber_idx_fn fi, void *args, const size_t *N, double **grid,
                                   struct ValueF *vref, struct ApproxArgs *aargs, int verbose, struct dev_fibers *dev)
@@ -838,7 +899,9 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     struct cross c;
     memset(&c, 0, sizeof(c));
     c.d = d; c.N = N; c.grid = grid; c.f = f; c.fb = fb; c.fi = fi; c.args = args; c.verbose = verbose;
-    if (dev != NULL) { c.dev = dev->ctx; c.dev_box = dev->box; c.dev_fresh = 1; c.dev_new_sweep = 1; }
+    c.warm = getenv("C3SC_COLD_PIVOTS") == NULL;
+    if (getenv("C3SC_SWAP_TOL")) g_swap_tol = atof(getenv("C3SC_SWAP_TOL"));
+    if (dev != NULL) { c.dev = dev->ctx; c.dev_pol = dev->pol; c.dev_tag = dev->tag; c.dev_box = dev->box; c.dev_fresh = 1; c.dev_new_sweep = 1; }
     c.r = xcalloc(d + 1, sizeof(size_t));
     c.r[0] = c.r[d] = 1;
     size_t base = approx_args_get_startrank(aargs);
@@ -957,7 +1020,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     tt_free(best);
     for (size_t k = 0; k < d; k++) { free(c.I[k]); free(c.J[k]); }
     free(c.I); free(c.J); free(c.r);
-    if (dev != NULL) dev->nodes = c.dev_nodes;
+    if (dev != NULL) { dev->nodes = c.dev_nodes; dev->requested = c.dev_requested; }
     return vf;
 }
 
@@ -1031,14 +1094,18 @@ struct ValueF *c3sc_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const
 }
 
 /* The interpolation whose fibers are the batched Bellman operator of a device context (c3sc_hip_bellman_fibers[_box] on the value
- * function uploaded to ctx): whole cross iterations run on the device (cross_iteration_device).  *nodes returns the number of
- * nodes stored in the device memo, the reference's nnode_evals (bellman.c:1374-1386). */
+ * function uploaded to ctx; with policy_ctx: bellman_pi -- the greedy policy of policy_ctx's value function evaluated on ctx's):
+ * whole cross iterations run on the device (cross_iteration_device).  *nodes returns the number of nodes stored in the device
+ * memo (bellman_vi: the reference's nnode_evals, bellman.c:1374-1386; bellman_pi: npol_evals), *requested the nodes of all fibers
+ * asked for (bellman_pi's niter_node_evals). */
 struct ValueF *c3sc_interp_device(size_t d, struct c3sc_hip_ctx *ctx, int box, const size_t *N, double **grid, struct ValueF *vref,
-                                  struct ApproxArgs *aargs, int verbose, size_t *nodes)
+                                  struct ApproxArgs *aargs, int verbose, size_t *nodes, struct c3sc_hip_ctx *policy_ctx, long long policy_tag,
+                                  size_t *requested)
 {
-    struct dev_fibers dv = {ctx, box, 0};
+    struct dev_fibers dv = {ctx, policy_ctx, policy_tag, box, 0, 0};
     struct ValueF *vf = interp_impl(d, NULL, NULL, NULL, NULL, N, grid, vref, aargs, verbose, &dv);
     if (nodes) *nodes = (size_t)dv.nodes;
+    if (requested) *requested = (size_t)dv.requested;
     return vf;
 }
 

@@ -38,7 +38,8 @@ struct ValueF *c3sc_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const
                                        size_t rank, int (*exchange)(double *, size_t, size_t, size_t, size_t, void *), void *xarg,
                                        c3sc_absorb_fn absorb);
 struct ValueF *c3sc_interp_device(size_t d, struct c3sc_hip_ctx *ctx, int box, const size_t *N, double **grid, struct ValueF *vref,
-                                  struct ApproxArgs *aargs, int verbose, size_t *nodes);
+                                  struct ApproxArgs *aargs, int verbose, size_t *nodes, struct c3sc_hip_ctx *policy_ctx, long long policy_tag,
+                                  size_t *requested);
 void valuef_set_cross_indices(struct ValueF *vf, const size_t *nisl, int *const *isl, const size_t *nisr, int *const *isr);
 void valuef_free_cross_indices(struct ValueF *vf);
 #endif

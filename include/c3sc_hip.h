@@ -213,6 +213,13 @@ int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32
  *   1 if a fiber matrix was numerically rank deficient, maxvol row swaps, 1 if the memo overflowed} */
 int c3sc_hip_cross_setup(c3sc_hip_ctx *ctx, const size_t *ranks, const int32_t *const *I, const int32_t *const *J, int new_sweep);
 int c3sc_hip_cross_iteration(c3sc_hip_ctx *ctx, int box, void *stream);
+/* the same for bellman_pi (bellman.c:1702-1886): per core step the greedy policy of the value function uploaded to policy_ctx
+ * (cached per node for the whole policy iteration policy_tag: the reference's prob table, bellman.c:1806, 1877), then its
+ * evaluation on ctx's value function.  info[0] of the fetch then counts the nodes whose policy was computed (npol_evals). */
+int c3sc_hip_cross_iteration_pi(c3sc_hip_ctx *ctx, c3sc_hip_ctx *policy_ctx, long long policy_tag, void *stream);
+/* pivot search of the core steps: warm_pivots != 0 starts it from the rows of the index set the step produced last time,
+ * swap_tol is maxvol's dominance tolerance (row swaps while max |B| > 1 + swap_tol); defaults 1 and 0.05 */
+int c3sc_hip_cross_options(c3sc_hip_ctx *ctx, int warm_pivots, double swap_tol);
 int c3sc_hip_cross_fetch(c3sc_hip_ctx *ctx, double *const *h_cores, int32_t *const *h_I, int32_t *const *h_J, unsigned long long *info,
                          void *stream);
 void c3sc_hip_cross_free(c3sc_hip_ctx *ctx);

@@ -75,7 +75,9 @@ def test_oracle_fixtures_of_the_long_cases(oracle, case):
     after = loop.nodal(cost)
     step = np.abs(after - before).max()
     print(f"{case}: fixture |V| = {float(g['norm']):.9f}; two more oracle updates move the nodes by {step:.3e} (last recorded |V_vi-V_pi| {hist[-1, 1]:.3e})")
-    assert step <= 50 * max(hist[-1, 1], 1e-6)
+    # (the file holds the cores, not the cross index sets: the continuation starts its pivot search cold, which costs a few 1e-5
+    #  of re-approximation on top of the loop's own last step)
+    assert step <= 100 * max(hist[-1, 1], 1e-6)
     loop.L.valuef_destroy(cost)
     loop.close()
 

@@ -227,3 +227,53 @@ def test_device_resident_cross_iterations_match_the_host_driver(name, kw, aargs)
     L.valuef_destroy(v0)
     L.approx_args_free(aa)
     ctl.close()
+
+
+@pytest.mark.parametrize("name,kw,aargs", [
+    ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=2)),
+    ("dubins3d", dict(ngrid=(41, 41, 41), rank=4), dict(maxrank=12, kick=3)),
+    ("lqg2d", dict(ngrid=(50, 50), rank=4), dict(maxrank=20, kick=5)),
+], ids=["car7d-small", "dubins3d", "lqg2d"])
+def test_device_resident_policy_iteration_matches_the_host_driver(name, kw, aargs):
+    """The examples' control update -- c3control_pi_solve (10 evaluation sweeps of one policy, bellman_pi) followed by one
+    c3control_vi_solve step -- with whole cross iterations on the device (policy pass with the per-node policy memo, evaluation
+    pass, factorisations) against the host-driven path: cores, ranks and both evaluation counters identical, bit for bit."""
+    w = wl.WORKLOADS[name]().scaled(**kw)
+    L, fl, ctl, aa = _setup(w, **aargs)
+    d = w.dx
+
+    def start(n, x, out, a):
+        X = np.ctypeslib.as_array(x, shape=(n, d))
+        np.ctypeslib.as_array(out, shape=(n,))[:] = 1.0 + 0.1 * ((X - 0.05) ** 2).sum(axis=1)
+        return 0
+
+    v0 = C.c_void_p(L.c3control_init_value(ctl.h, FIBER_FN(start), None, aa, 0))
+    results = {}
+    for path in ("device", "host"):
+        if path == "host":
+            os.environ["C3SC_HOST_CROSS"] = "1"
+        else:
+            os.environ.pop("C3SC_HOST_CROSS", None)
+        v = C.c_void_p(L.valuef_copy(v0))
+        rows = []
+        for upd in range(3):
+            diag = C.c_void_p(None)
+            nxt = C.c_void_p(L.c3control_pi_solve(ctl.h, C.c_size_t(6), C.c_double(1e-9), v, aa, ctl.opt, 0, C.byref(diag)))
+            L.valuef_destroy(v)
+            v = C.c_void_p(L.c3control_vi_solve(ctl.h, C.c_size_t(1), C.c_double(1e-9), nxt, aa, ctl.opt, 0, C.byref(diag)))
+            L.valuef_destroy(nxt)
+            rows.append((L.diag_count(diag), L.diag_last_diff(diag)) + _cores_of(L, v, w))
+            L.diag_destroy(C.byref(diag))
+        results[path] = rows
+        L.valuef_destroy(v)
+    os.environ.pop("C3SC_HOST_CROSS", None)
+    for it, (a, b) in enumerate(zip(results["device"], results["host"])):
+        assert a[0] == b[0] and a[1] == b[1], f"update {it}: sweeps / last step {a[:2]} vs {b[:2]}"
+        assert a[2] == b[2], f"update {it}: ranks {a[2]} vs {b[2]}"
+        for m in range(d):
+            assert np.array_equal(a[3][m], b[3][m]), f"update {it}, core {m}: max diff {np.abs(a[3][m] - b[3][m]).max():.3e}"
+    print(f"{name} {w.ngrid}: 3 control updates (6 policy-evaluation sweeps + 1 value-iteration sweep each): device-resident and host-driven "
+          f"paths bit-identical; ranks {results['device'][-1][2]}")
+    L.valuef_destroy(v0)
+    L.approx_args_free(aa)
+    ctl.close()

@@ -29,7 +29,7 @@ for f in ("valuef_norm", "valuef_norm2diff"):
     getattr(L, f).restype = C.c_double
 L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
 L.diag_count.restype = C.c_size_t
-ctl = facade_lib.Control(w)
+ctl = facade_lib.Control(w, consistent_ends=None)  # the library default: consistent end points
 aa = C.c_void_p(L.approx_args_init())
 L.approx_args_set_cross_tol(aa, C.c_double(1e-5))
 L.approx_args_set_round_tol(aa, C.c_double(1e-5))

@@ -19,6 +19,7 @@
 // bits dropped, ties to the lowest index) -- tests/test_solver_loops.py holds the two paths to identical cores.
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -520,7 +521,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     }
     x->cores_bytes = off - x->off_cores;
     x->off_idx = off; off += up256(fmax * d * sizeof(int32_t));
-    x->off_out = off; off += up256(fmax * nmax * sizeof(double));
+    x->off_out = off; off += up256((fmax + 64) * nmax * sizeof(double)); // + the padding rows of a sharded step (world * ceil(F / world) >= F)
     x->off_work = off; off += up256(wmax * sizeof(double));
     x->off_uidx = off; off += up256(fmax * nmax * sizeof(int32_t));
     if (off > x->slab_bytes) {
@@ -589,6 +590,10 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
     c3sc_cross_dev *x = c->cross;
     const int d = x->d;
     hipStream_t st = (hipStream_t)stream;
+    c3sc_hip_comm *comm = c->shard_comm;
+    const int world = comm ? c3sc_hip_comm_world(comm) : 1, rank = comm ? c3sc_hip_comm_rank(comm) : 0;
+    if (comm && pol) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: not sharded (use the host-driven driver)");
+    if (world > 64) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration: up to 64 ranks");
     if (pol) {
         if (box) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: candidate lists only");
         if (pol->d != d) return fail(c, C3SC_ERR_ARG, "cross_iteration_pi: the policy context has another grid");
@@ -622,7 +627,16 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         for (int m = 0; m < d; m++) mc->memo.stride[m] = x->strides.s[m];
         mc->memo.applied = false;
         int rc;
-        if (pol) rc = c3sc_hip_bellman_fibers(pol, k, F, idx, out, uidx, nullptr, stream); // values unused: the policy is the output
+        if (comm) { // sharded: this rank's block of rows, then the all-gather in place; the memo pass runs on the full array,
+                    // in the same order on every rank, so that all ranks keep identical memos and take identical decisions
+            const size_t per = (F + world - 1) / world, lo = std::min(F, (size_t)rank * per), hi = std::min(F, lo + per);
+            mc->memo.keys = nullptr;
+            rc = C3SC_OK;
+            if (hi > lo)
+                rc = box ? c3sc_hip_bellman_fibers_box(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream)
+                         : c3sc_hip_bellman_fibers(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream);
+            if (rc == C3SC_OK) rc = c3sc_hip_comm_allgather(comm, out + (size_t)rank * per * N, out, per * N, stream);
+        } else if (pol) rc = c3sc_hip_bellman_fibers(pol, k, F, idx, out, uidx, nullptr, stream); // values unused: the policy is the output
         else rc = box ? c3sc_hip_bellman_fibers_box(c, k, F, idx, out, nullptr, nullptr, stream)
                       : c3sc_hip_bellman_fibers(c, k, F, idx, out, nullptr, nullptr, stream);
         mc->memo.keys = nullptr;

@@ -9,6 +9,7 @@
 #include "kernel_common.hpp"
 
 struct c3sc_cross_dev; // cross_device.hip: device-resident state of the cross-approximation core steps
+struct c3sc_hip_comm;  // comm_rccl.hip: RCCL communicator (one process per GPU)
 
 struct c3sc_hip_ctx {
     int device = 0;
@@ -68,6 +69,7 @@ struct c3sc_hip_ctx {
         int mode = 0;         // KArgs::memo_mode
         bool applied = false; // the launched kernel carried the memo in its epilogue
     } memo;
+    c3sc_hip_comm *shard_comm = nullptr; // borrowed: the cross iterations shard their core steps over it (c3sc_hip_cross_set_comm)
     c3sc_cross_dev *cross = nullptr; // owned; freed by c3sc_hip_cross_free (called from c3sc_hip_ctx_destroy)
 };
 

@@ -1078,6 +1078,7 @@ struct C3Control {
     size_t shard_world, shard_rank;
     c3sc_exchange_fn shard_exchange;
     void *shard_xarg;
+    struct c3sc_hip_comm *shard_comm; /* owned: created by c3control_shard_over_gpus */
 };
 
 struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, double *ub, size_t *ngrid, double discount)
@@ -1109,6 +1110,7 @@ struct C3Control *c3control_create(size_t dx, size_t du, size_t dw, double *lb, 
 void c3control_destroy(struct C3Control *c)
 {
     if (c == NULL) return;
+    if (c->shard_comm) c3sc_hip_comm_destroy(c->shard_comm); /* before the workspace's device context goes */
     boundary_free(c->bound); mca_param_destroy(c->mca); dp_param_destroy(c->dp); workspace_free(c->work);
     for (size_t m = 0; m < c->dx; m++) free(c->xgrid[m]);
     free(c->prevpol);
@@ -1142,6 +1144,25 @@ void c3control_set_fiber_sharding(struct C3Control *c, size_t world, size_t rank
     c->shard_rank = rank;
     c->shard_exchange = exchange;
     c->shard_xarg = xarg;
+}
+
+int c3control_shard_over_gpus(struct C3Control *c, size_t world, size_t rank, const void *id128)
+{ /* new: one process per GPU of a node, all running the same solver; the fibers of every core step are split over the ranks and
+     gathered with one RCCL all-gather (c3sc_hip_comm_*).  id128: the 128 bytes rank 0 got from
+     c3sc_hip_comm_unique_id, identical on all ranks.  The device of this rank is C3SC_HIP_DEVICE (default 0: launchers that pin
+     one GPU per process, e.g. HIP_VISIBLE_DEVICES, need nothing else).  Collective: every rank must call it.  Value iteration then
+     runs its sharded core steps device-resident (c3sc_hip_cross_set_comm); policy iteration goes through the host-driven driver
+     with c3sc_hip_comm_exchange as its exchange function.  Returns 0 on success. */
+    if (c->shard_comm) { c3sc_hip_comm_destroy(c->shard_comm); c->shard_comm = NULL; }
+    c3control_set_fiber_sharding(c, 1, 0, NULL, NULL);
+    if (world <= 1 && id128 == NULL) return 0;
+    struct c3sc_hip_ctx *ctx = workspace_get_hip_ctx(c->work);
+    struct c3sc_hip_comm *comm = NULL;
+    const int rc = c3sc_hip_comm_create(ctx, (int)world, (int)rank, id128, &comm);
+    if (rc != C3SC_OK) { fprintf(stderr, "c3sc: c3sc_hip_comm_create: %s\n", c3sc_hip_last_error(ctx)); return rc; }
+    c->shard_comm = comm;
+    c3control_set_fiber_sharding(c, world, rank, c3sc_hip_comm_exchange, comm);
+    return 0;
 }
 
 struct VIparam *c3control_begin_vi(struct C3Control *c, struct ValueF *vf, struct c3Opt *opt)
@@ -1311,10 +1332,12 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
      * core steps on one stream) when the fibers are the device model's; the host-driven path below serves host callbacks
      * (tables), sharded runs, the very first sweep while the device model is still to be cross-checked against the user's
      * callbacks (vi_core does that on its first fiber), and C3SC_HOST_CROSS=1.  Same results either way. */
-    const int sharded = c->shard_world > 1 && c->shard_exchange != NULL;
+    const int rccl = c->shard_comm != NULL && c->shard_exchange == c3sc_hip_comm_exchange; /* sharded over the C communicator */
+    const int sharded = (c->shard_world > 1 && c->shard_exchange != NULL) && !rccl;
     const int checked = c->dp->model_checked || c->dp->stagecost == NULL || c->dp->boundcost == NULL || c->dp->obscost == NULL;
     if (dp_has_device_model(c->dp) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL) {
         struct c3sc_hip_ctx *ctx = sync_device(vi);
+        c3sc_hip_cross_set_comm(ctx, rccl ? c->shard_comm : NULL);
         size_t nodes = 0;
         next = c3sc_interp_device(c->dx, ctx, !c3opt_is_bruteforce(opt), c->ngrid, c->xgrid, vf, aa, verbose, &nodes, NULL, 0, NULL);
         vi->nnode_evals += nodes;

@@ -1063,8 +1063,16 @@ static int sharded_fibers_idx(size_t F, size_t k, const int32_t *idx, double *ou
     const size_t N = s->N[k];
     int rc = 0;
     if (hi > lo) rc = s->fi(hi - lo, k, idx + lo * s->d, out + lo * N, s->args);
-    if (rc != 0) return rc;
+    /* A rank whose fibers failed still enters the collective -- the others are waiting in it -- with its rows set to NaN (no
+     * fiber value ever is): after the exchange every rank sees the mark and all of them return the error together. */
+    const int local_rc = rc;
+    if (local_rc != 0)
+        for (size_t i = lo * N; i < hi * N; i++) out[i] = NAN;
     rc = s->exchange(out, F, N, lo, hi, s->xarg);
+    if (rc == 0) {
+        for (size_t i = 0; i < F * N && rc == 0; i++)
+            if (out[i] != out[i]) rc = local_rc != 0 ? local_rc : 3; /* a peer failed */
+    } else if (local_rc != 0) rc = local_rc;
     if (rc == 0 && s->absorb) s->absorb(F, k, idx, out, lo, hi, s->args);
     if (rc == 0 && getenv("C3SC_SHARD_DEBUG")) { /* diagnostic: every rank recomputes the whole batch and compares */
         extern int c3sc_memo_bypass;

@@ -94,6 +94,9 @@ void c3control_set_consistent_ends(struct C3Control *, int on);
 /* new: multi-GPU (one process per GPU, every rank runs the same solver): the fibers of every core step of step_vi /
  * step_pi are split over `world` ranks and all-gathered by `exchange` (valuefunc.h: valuef_interp_idx_sharded) */
 void c3control_set_fiber_sharding(struct C3Control *, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg);
+/* new: the same with the library's own RCCL communicator (c3sc_hip_comm_*): a C main() shards over the GPUs of a node without
+ * writing an exchange function.  id128 = the bytes of c3sc_hip_comm_unique_id from rank 0.  Collective.  0 on success. */
+int c3control_shard_over_gpus(struct C3Control *, size_t world, size_t rank, const void *id128);
 /* one value-iteration sweep's callback state, as c3control_step_vi builds it (bellman.c:2177-2199); the
  * cross approximation that consumes it (valuef_interp -> C3) is out of scope, so the caller drives the fibers */
 struct VIparam *c3control_begin_vi(struct C3Control *, struct ValueF *vf, struct c3Opt *opt);

@@ -224,6 +224,26 @@ int c3sc_hip_cross_fetch(c3sc_hip_ctx *ctx, double *const *h_cores, int32_t *con
                          void *stream);
 void c3sc_hip_cross_free(c3sc_hip_ctx *ctx);
 
+/* Multi-GPU (one process per GPU, RCCL over xGMI, opened at run time -- no link dependency).  The path shards
+ * by independent fibers: every rank evaluates a contiguous block of each core step's fibers on its own device and ONE all-gather
+ * per core step puts the F x N values on every rank (tens of KB, latency-bound).  bellman.c:2201 passes the value function
+ * read-only during a sweep, which is what makes the fibers independent.
+ *   unique_id: rank 0 creates the 128-byte id and hands it to the other ranks (file, environment, socket ...)
+ *   create:    collective over all ranks of the node
+ *   allgather: count doubles per rank, device buffers, in place when d_send == d_recv + rank * count; asynchronous on stream
+ *   cross_set_comm: the device-resident cross iterations of ctx shard their core steps over the communicator
+ *   exchange:  a c3sc_exchange_fn (include/c3sc/valuefunc.h) for the host-driven sharded driver: pass it with xarg = the
+ *              communicator to c3control_set_fiber_sharding / valuef_interp_idx_sharded */
+typedef struct c3sc_hip_comm c3sc_hip_comm;
+int c3sc_hip_comm_unique_id(void *id128);
+int c3sc_hip_comm_create(c3sc_hip_ctx *ctx, int world, int rank, const void *id128, c3sc_hip_comm **out);
+void c3sc_hip_comm_destroy(c3sc_hip_comm *comm);
+int c3sc_hip_comm_world(const c3sc_hip_comm *comm);
+int c3sc_hip_comm_rank(const c3sc_hip_comm *comm);
+int c3sc_hip_comm_allgather(c3sc_hip_comm *comm, const double *d_send, double *d_recv, size_t count, void *stream);
+int c3sc_hip_cross_set_comm(c3sc_hip_ctx *ctx, c3sc_hip_comm *comm);
+int c3sc_hip_comm_exchange(double *out, size_t F, size_t N, size_t lo, size_t hi, void *comm);
+
 int c3sc_hip_sync(c3sc_hip_ctx *ctx, void *stream);
 int c3sc_hip_get_status(c3sc_hip_ctx *ctx, unsigned *flags, int clear);
 /* name of the kernel the last launch used (for profiles) */

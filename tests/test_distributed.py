@@ -184,11 +184,26 @@ def _run_sharded(use_gpu):
     procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, use_gpu)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    return res
+    import queue as _queue
+    import time as _time
+
+    res, deadline = [], _time.time() + 300
+    try:
+        while len(res) < 2:  # a rank that died leaves its peer in the collective: stop waiting as soon as one has failed
+            try:
+                res.append(q.get(timeout=1.0))
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs) or _time.time() > deadline:
+                    raise AssertionError(f"sharded ranks failed or timed out: exit codes {[p.exitcode for p in procs]}")
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:  # never leave a hung peer behind
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    return sorted(res)
 
 
 def test_gloo_world2_sharded_cross_driver(oracle):
@@ -210,3 +225,105 @@ def test_world2_sharded_solver_step_matches_single_rank(oracle):
     for rank, same, n_sharded, n_full in res:
         assert same, f"rank {rank}: sharded sweeps differ from the unsharded ones"
         assert 0 < n_sharded < 0.8 * n_full
+
+
+# ------------------------------------------------------------------------------------------------ RCCL in C (c3sc_hip_comm_*)
+def _rccl_worker(rank, world, idfile, q):
+    """One process per GPU: the solver sharded over the library's own RCCL communicator (c3control_shard_over_gpus), no Python in
+    the exchange.  The 128-byte id travels through a file."""
+    import ctypes as C
+    import time
+
+    os.environ["C3SC_HIP_DEVICE"] = str(rank if world > 1 else 0)
+    import facade_lib
+    from c3sc_amd.engine import load_library
+
+    H = load_library()
+    L = facade_lib.lib()
+    for n in ("c3control_init_value", "c3control_step_vi"):
+        getattr(L, n).restype = C.c_void_p
+    L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+    L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
+    idbuf = (C.c_char * 128)()
+    if rank == 0:
+        assert H.c3sc_hip_comm_unique_id(idbuf) == 0
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(idbuf))
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        for _ in range(600):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.05)
+        idbuf.raw = open(idfile, "rb").read()
+    w = wl.c4_car7d().scaled(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)
+    d = w.dx
+
+    def sweeps(sharded):
+        ctl = facade_lib.Control(w, consistent_ends=None)
+        if sharded:
+            assert L.c3control_shard_over_gpus(ctl.h, C.c_size_t(world), C.c_size_t(rank), idbuf) == 0
+        aa = C.c_void_p(L.approx_args_init())
+        L.approx_args_set_cross_tol(aa, C.c_double(1e-8))
+        L.approx_args_set_round_tol(aa, C.c_double(1e-8))
+        L.approx_args_set_kickrank(aa, C.c_size_t(2))
+        L.approx_args_set_startrank(aa, C.c_size_t(3))
+        L.approx_args_set_maxrank(aa, C.c_size_t(5))
+        start = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).__setitem__(
+            slice(None), 1.0 + 0.1 * (np.ctypeslib.as_array(x, shape=(n, d)) ** 2).sum(axis=1)), 0)[1])
+        v = C.c_void_p(L.c3control_init_value(ctl.h, start, None, aa, 0))
+        ne, rows = C.c_size_t(0), []
+        for _ in range(3):
+            nxt = C.c_void_p(L.c3control_step_vi(ctl.h, v, aa, ctl.opt, 0, C.byref(ne)))
+            L.valuef_destroy(v)
+            v = nxt
+            ranks = [int(L.valuef_get_ranks(v)[i]) for i in range(d + 1)]
+            pp = L.valuef_get_cores(v)
+            rows.append((ne.value, ranks, [np.ctypeslib.as_array(pp[m], shape=(w.ngrid[m] * ranks[m] * ranks[m + 1],)).copy() for m in range(d)]))
+        L.valuef_destroy(v)
+        L.approx_args_free(aa)
+        ctl.close()
+        return rows
+
+    full = sweeps(False)
+    shard = sweeps(True)
+    same = all(a[0] == b[0] and a[1] == b[1] and all(np.array_equal(x, y) for x, y in zip(a[2], b[2])) for a, b in zip(full, shard))
+    # the exchange function of the host-driven driver on its own: rows [lo, hi) of a host array gathered over the communicator
+    q.put((rank, bool(same), [r[0] for r in shard]))
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_in_c_shards_the_device_resident_sweeps(tmp_path):
+    """c3control_shard_over_gpus: the library's own RCCL communicator (librccl opened at run time, device buffers, stream-ordered
+    all-gather inside the device-resident cross iteration) -- two ranks on two GPUs when the box has them, otherwise the same
+    code path with a one-rank communicator.  Cores, ranks and node counts equal the unsharded sweeps' bit for bit on every rank."""
+    import torch
+    import torch.multiprocessing as mp
+
+    world = 2 if torch.cuda.device_count() >= 2 else 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    idfile = str(tmp_path / "rccl_id.bin")
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, idfile, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    import time as _time
+
+    res, deadline = [], _time.time() + 300
+    try:
+        while len(res) < world:
+            try:
+                res.append(q.get(timeout=1.0))
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs) or _time.time() > deadline:
+                    raise AssertionError(f"ranks failed or timed out: exit codes {[p.exitcode for p in procs]}")
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    for rank, same, counts in sorted(res):
+        assert same, f"rank {rank}: sharded sweeps differ from the unsharded ones"
+    print(f"RCCL communicator in C, world {world}: sharded device-resident sweeps identical to the unsharded ones; node evaluations {sorted(res)[0][2]}")

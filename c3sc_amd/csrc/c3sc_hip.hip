@@ -131,9 +131,13 @@ using namespace c3sc;
 // Besides the trigonometric tables, any other expensive univariate function of a grid coordinate is tabulated
 // here with the host's IEEE arithmetic (correctly rounded division, the same result the device's division sequence
 // gives): the car models' speed factor v / (0.2 (1 + v/8)) costs a ~15-instruction dependent chain per node otherwise.
-static int model_ntab(int model) { return model == C3SC_MODEL_DUBINS3D ? 2 : (model == C3SC_MODEL_SCAR4D ? 3 : (model == C3SC_MODEL_CAR7D ? 4 : 0)); }
+static int model_ntab(int model)
+{
+    return model == C3SC_MODEL_DUBINS3D ? 2 : (model == C3SC_MODEL_SCAR4D ? 3 : ((model == C3SC_MODEL_CAR7D || model == C3SC_MODEL_PERCH7D) ? 4 : 0));
+}
 static int model_tab_dim(int model, int t)
 {
+    if (model == C3SC_MODEL_PERCH7D) return t < 2 ? 2 : 3; // cos / sin of the pitch x2, cos / sin of the elevator angle x3
     if (model == C3SC_MODEL_CAR7D) return t == 2 ? 5 : (t == 3 ? 3 : 2);
     if (model == C3SC_MODEL_SCAR4D) return t == 2 ? 3 : 2;
     return 2;
@@ -142,6 +146,7 @@ static double model_table_value(int model, int t, double xv)
 {
     if (t == 0) return cos(xv);
     if (t == 1) return sin(xv);
+    if (model == C3SC_MODEL_PERCH7D) return t == 2 ? cos(xv) : sin(xv);
     if (model == C3SC_MODEL_CAR7D && t == 2) return tan(xv);
     if (model == C3SC_MODEL_CAR7D && t == 3) return xv / (0.2 * (1.0 + xv / 8.0));
     if (model == C3SC_MODEL_SCAR4D && t == 2) return (1.0 / (1.0 + (xv / 8.0))) * (xv / 0.2); /* scar.c:68-71 with L = 0.2, vcar = 8 */

@@ -265,7 +265,8 @@ struct NodeRegs {
     }
 };
 
-// Lane-distributed copy of the control candidates and their features (lane c holds candidate c; ncand <= 64),
+// Lane-distributed copy of the control candidates and their features (lane c holds candidate c0 + c: 64 candidates at a time;
+// the fiber-per-wave kernel walks longer lists in chunks, the other kernels decline them),
 // plus the upwind rates of the dims whose drift and diffusion depend on the control alone (Model::UCONST_MASK):
 // those are constants of the candidate (nodeutil.c:289-309 with b = b(u), sigma = sigma(u)), computed once per
 // wave with the very arithmetic the node loop would use and broadcast by v_readlane in the scan.
@@ -304,10 +305,10 @@ struct CandRegs {
     __device__ inline double get_rpm(int slot, int c) const { return readlane_f64(rpm[slot], c); }
     __device__ inline double get_rpp(int slot, int c) const { return readlane_f64(rpp[slot], c); }
     __device__ inline double get_qab(int c) const { return readlane_f64(qab, c); }
-    __device__ inline void load(const KArgs &A, const double *__restrict__ ro)
+    __device__ inline void load(const KArgs &A, const double *__restrict__ ro, int c0 = 0) // candidates c0 .. c0 + 63
     {
         constexpr int D = Model::D;
-        const int c = min((int)(threadIdx.x & 63), A.ncand - 1);
+        const int c = min(c0 + (int)(threadIdx.x & 63), A.ncand - 1);
 #pragma unroll
         for (int i = 0; i < Model::DU; i++) u[i] = ro[A.cands_off + c * Model::DU + i];
         cf[0] = 0.0;
@@ -350,9 +351,9 @@ struct CandLds {
     static constexpr int CW = DU + NCFa + 2 * NUC + 1;
     const double *tb;
     __host__ __device__ static constexpr int doubles(int ncand) { return ncand * CW; }
-    __device__ inline void fill(double *dst, const CandRegs<Model> &cr, int ncand)
+    __device__ inline void fill(double *dst, const CandRegs<Model> &cr, int ncand, int c0 = 0) // cr holds candidates c0 .. c0 + 63
     {
-        const int c = min((int)(threadIdx.x & 63), ncand - 1);
+        const int c = min(c0 + (int)(threadIdx.x & 63), ncand - 1);
         double *row = dst + c * CW;
 #pragma unroll
         for (int i = 0; i < DU; i++) row[i] = cr.u[i];

@@ -109,9 +109,11 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
     CandLds<Model> cr;
     cr.tb = nullptr;
     if constexpr (!STENCIL && !Model::IS_TABLE) {
-        CandRegs<Model> cr0;
-        cr0.load(A, ro);
-        cr.fill(smem + A.tbl_off, cr0, A.ncand); // every wave writes the same rows
+        for (int c0 = 0; c0 < A.ncand; c0 += 64) { // every wave writes the same rows; 64 candidates per pass
+            CandRegs<Model> cr0;
+            cr0.load(A, ro, c0);
+            cr.fill(smem + A.tbl_off, cr0, A.ncand, c0);
+        }
         __syncthreads();
     }
     unsigned st = 0;

@@ -10,6 +10,7 @@ hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
 {
     constexpr int D = Model::D;
     constexpr int NV = 2 * (D - 1), NP = NV + 1, RH = RP / 2;
+    if (A.ncand > 64) return hipErrorNotSupported; // one lane per candidate fills the table: the per-wave kernel walks longer lists
     // LDS: max(largest staged fixed core, half-swap buffer, per-node exchange buffers)
     size_t doubles = (size_t)NV * RH * 64;
     const size_t exch = (size_t)(2 * RP + (NP + 1) * 2 + 2 * NP) * 64; // L, R rows + exchange rows

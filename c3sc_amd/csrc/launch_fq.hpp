@@ -12,6 +12,7 @@ hipError_t launch_fq_impl(const KArgs &A, const LaunchIO &io)
     if (A.cmode == 1) return hipErrorNotSupported; // candidate lists only
     if (K > 0 && K < D - 1 && A.quad_aop_off[K] == 0) return hipErrorNotSupported;
     // LDS: the largest staged fixed core, then the per-wave node values, then the candidate table
+    if (A.ncand > 64) return hipErrorNotSupported; // see launch_fpp.hpp
     size_t doubles = 0;
     for (int m = 0; m < D; m++) {
         if (m == K) continue;
@@ -58,6 +59,7 @@ hipError_t launch_fq_duo(const KArgs &A, const LaunchIO &io)
     constexpr int D = Model::D;
     if (A.cmode == 1) return hipErrorNotSupported; // candidate lists only
     if (K > 0 && K < D - 1 && A.quad_aop_off[K] == 0) return hipErrorNotSupported;
+    if (A.ncand > 64) return hipErrorNotSupported; // see launch_fpp.hpp
     size_t doubles = 0;
     for (int m = 0; m < D; m++) {
         if (m == K) continue;

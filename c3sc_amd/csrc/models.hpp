@@ -261,6 +261,118 @@ struct Rossler3D {
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
 };
 
+// The 3-state / 3-control problem of the reference's own tests (test/transition_prob/tprob_test.c: drift f3 :223-251, diffusion
+// s2 = I :197-220, stagecost3d :273-300, boundcost 100 :302-309, ocost 0 :311-318), used by Test_bellman_vi3d / Test_bellman_pi3d
+// (:2361-2540) with u in [-5, 5]^3.  No params.
+struct Tprob3D {
+    static constexpr bool IS_TABLE = false;
+    static constexpr int D = 3, DU = 3;
+    static constexpr int NTAB = 0, NCF = 0;
+    static constexpr unsigned UDEP_MASK = 0x7u; // every equation carries a control
+    static constexpr unsigned UCONST_MASK = 0;  // ... multiplied by the state
+    static constexpr bool STAGE_UDEP = true;
+    __host__ __device__ static constexpr int tab_dim(int) { return 0; }
+    struct Node {};
+    __device__ static inline void prep(const double *, const double (&)[D], const double (&)[1], Node &) {}
+    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *u, const double *,
+                                        double (&b)[D])
+    {
+        b[0] = x[0] * (x[2] * x[2]) * u[0];     // x[0]*pow(x[2],2)*u[0]
+        b[1] = -x[1] * u[2] + u[1];
+        b[2] = x[0] * x[1] * u[0] + 2 * u[1];
+    }
+    __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&s)[D])
+    {
+        s[0] = 1.0; s[1] = 1.0; s[2] = 1.0;
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *u)
+    { // the reference's order of accumulation (:283-291)
+        double s = 0.0;
+        s += 0.2 * x[0] * x[0];
+        s += 0.5 * x[1] * x[1];
+        s += 2.0 * x[2] * x[2];
+        s += 0.1 * u[0] * u[0];
+        s += 0.5 * u[1] * u[1];
+        s += 3.0 * u[2] * u[2];
+        return s;
+    }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 100.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
+// examples/perching/perch.c:36-273 -- the reference's one real 7-D problem: a glider perching.  State (x, z, theta, phi, dx, dz,
+// dtheta), control = elevator rate.  The reference computes the aerodynamic forces as rho S |v|^2 sin(alpha) with
+// alpha = angle - atan2(v_z, v_x) (:104-109); sin(a - atan2(y, x)) = (sin a x - cos a y) / |v|, so the force is
+// rho S |v| (sin a v_x - cos a v_z): a square root instead of atan2 + sin per candidate, equal to rounding (the oracle keeps the
+// reference's libm form; parity holds to 1e-12 of the value scale).  Tables: cos / sin of theta (dim 2) and of phi (dim 3);
+// cos / sin of theta + phi by the addition formulas.  Diffusion 1e-9 I (:165-176); no params.
+struct Perch7D {
+    static constexpr bool IS_TABLE = false;
+    static constexpr int D = 7, DU = 1;
+    static constexpr int NTAB = 4, NCF = 0;
+    static constexpr unsigned UDEP_MASK = (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6);
+    static constexpr unsigned UCONST_MASK = 1u << 3; // dphi/dt = u alone; the accelerations also depend on the state
+    static constexpr bool STAGE_UDEP = true;
+    __host__ __device__ static constexpr int tab_dim(int t) { return t < 2 ? 2 : 3; }
+    struct Node { double ct, st, cp, ctp, stp, fw, ex0, ex1; };
+    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[4], Node &n)
+    {
+        const double l = 0.35, l_w = -0.03, rho = 1.292, S_w = 0.1;
+        n.ct = tv[0]; n.st = tv[1]; n.cp = tv[2];
+        const double sp = tv[3];
+        n.ctp = n.ct * n.cp - n.st * sp;
+        n.stp = n.st * n.cp + n.ct * sp;
+        const double w0 = x[4] + l_w * x[6] * n.st, w1 = x[5] - l_w * x[6] * n.ct; // wing velocity (:93-95)
+        n.fw = rho * S_w * sqrt(w0 * w0 + w1 * w1) * (n.st * w0 - n.ct * w1);
+        n.ex0 = x[4] + l * x[6] * n.st;                                              // elevator velocity without the control (:100-102)
+        n.ex1 = x[5] - l * x[6] * n.ct;
+    }
+    __device__ static inline void drift(const double *, const Node &n, const double (&x)[D], const double *u, const double *,
+                                        double (&b)[D])
+    {
+        const double m = 0.05, g = 9.81, rho = 1.292, S_e = 0.025, In = 6e-3, l = 0.35, l_w = -0.03, l_e = 0.04;
+        const double e0 = n.ex0 + l_e * (x[6] + u[0]) * n.stp, e1 = n.ex1 - l_e * (x[6] + u[0]) * n.ctp;
+        const double fe = rho * S_e * sqrt(e0 * e0 + e1 * e1) * (n.stp * e0 - n.ctp * e1);
+        b[0] = x[4]; b[1] = x[5]; b[2] = x[6]; b[3] = u[0];
+        b[4] = (-n.fw * n.st - fe * n.stp) / m;
+        b[5] = (n.fw * n.ct + fe * n.ctp - m * g) / m;
+        b[6] = (-n.fw * l_w - fe * (l * n.cp + l_e)) / In;
+    }
+    __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&s)[D])
+    {
+#pragma unroll
+        for (int i = 0; i < D; i++) s[i] = 1e-9;
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *u)
+    { // :185-215, in the reference's order
+        double s = 0.0;
+        s += 20.0 * x[0] * x[0];
+        s += 50.0 * x[1] * x[1];
+        s += 10.0 * x[2] * x[2];
+        s += 1.0 * x[3] * x[3];
+        s += 1.0 * x[4] * x[4];
+        s += 1.0 * x[5] * x[5];
+        s += 1.0 * x[6] * x[6];
+        s += 0.1 * u[0] * u[0];
+        return s;
+    }
+    __device__ static inline double boundcost(const double *, const double (&x)[D])
+    { // :222-241
+        const double hp = 1.5707963267948966; // M_PI / 2.0
+        double s = 0.0;
+        s += 600.0 * x[0] * x[0];
+        s += 400.0 * x[1] * x[1];
+        s += 1.0 / 9.0 * x[2] * x[2];
+        s += 5.0 * (x[2] - hp) * (x[2] - hp);
+        s += 1.0 / 9.0 * x[3] * x[3];
+        s += 1.0 * x[4] * x[4];
+        s += 1.0 * (x[5] + 1.5) * (x[5] + 1.5);
+        s += 1.0 / 9.0 * (x[6] + 0.5) * (x[6] + 0.5);
+        return s;
+    }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
 // Universal model for arbitrary host callbacks (the reference's examples unchanged): the HOST evaluates the
 // user's drift / diffusion / stage-cost callbacks for every (node, candidate) of the fibers it submits and the
 // kernel reads the numbers from a table: per fiber [N][U][2D+1] = (drift[D], diag sigma[D], stage) and

@@ -27,6 +27,8 @@ MODEL_CAR7D = 3
 MODEL_LQGND = 4
 MODEL_CHAIN = 5
 MODEL_ROSSLER3D = 6
+MODEL_TPROB3D = 7
+MODEL_PERCH7D = 8
 
 BC_ABSORB, BC_PERIODIC, BC_REFLECT = 1, 2, 3  # enum EBTYPE, src/boundary.h:42-47
 _BC_NAME = {BC_ABSORB: "absorb", BC_PERIODIC: "periodic", BC_REFLECT: "reflect"}
@@ -134,9 +136,30 @@ def rossler3d(n=20, r=8) -> Workload:
                     (BC_REFLECT,) * 3, [], np.linspace(-4.0, 4.0, 33).reshape(-1, 1))
 
 
+def perch7d(n=20, r=15) -> Workload:
+    """examples/perching/perch.c:322-384: glider perching, 7 states, N = 20 per dimension, every face absorbing (the default of
+    c3control_create), beta = 1, maxrank 15, one obstacle = the perch (cost 0); its BFGS box u in [-2 pi, 2 pi] as a 41-point
+    candidate list, slightly off-centre (set_control_box gives the continuous minimiser over the same box)."""
+    lb = (-4.0, -1.0, -math.pi / 2.0, -2.0 * math.pi / 9.0, 0.0, -5.0, -10.0)
+    ub = (0.0, 1.0, math.pi / 2.0, 2.0 * math.pi / 9.0, 7.0, 5.0, 10.0)
+    goal = ((0.0, 0.0, 0.0, 0.0, 0.0, -2.0, 0.0), (0.1, 0.1, ub[2] - lb[2], ub[3] - lb[3], 0.5, 0.5, ub[6] - lb[6]))
+    cands = (np.linspace(-2.0 * math.pi, 2.0 * math.pi, 41) + 0.01).clip(-2.0 * math.pi, 2.0 * math.pi).reshape(-1, 1)
+    return Workload("perch7d", MODEL_PERCH7D, (), 7, 1, lb, ub, (n,) * 7, uniform_ranks(7, r), 1.0, (BC_ABSORB,) * 7, [goal], cands)
+
+
+def tprob3d(n=25, r=10) -> Workload:
+    """The 3-state / 3-control problem of the reference's own tests (test/transition_prob/tprob_test.c:2448-2540, Test_bellman_pi3d):
+    drift f3, diffusion I, stagecost3d, boundcost 100, box [-1,2] x [-2,3] x [-3,1] with N = 25, every face absorbing (the default of
+    c3control_create), beta = 0.1, rank 10; its BFGS box u in [-5, 5]^3 as a 5 x 5 x 5 candidate list (slightly off-centre: no exact
+    ties between +u and -u)."""
+    ax = np.linspace(-5.0, 5.0, 5) + 0.0625
+    return Workload("tprob3d", MODEL_TPROB3D, (), 3, 3, (-1.0, -2.0, -3.0), (2.0, 3.0, 1.0), (n,) * 3, uniform_ranks(3, r), 0.1,
+                    (BC_ABSORB,) * 3, [], _grid_cands([ax.clip(-5.0, 5.0)] * 3))
+
+
 WORKLOADS = {
     "lqg2d": c1_lqg2d, "dubins3d": c2_dubins, "lqg6d": c3_lqg6d, "car7d": c4_car7d, "quad10d": c5_quad10d,
-    "scar4d": scar4d, "rossler3d": rossler3d,
+    "scar4d": scar4d, "rossler3d": rossler3d, "tprob3d": tprob3d, "perch7d": perch7d,
 }
 
 _GOLD = np.uint64(0x9E3779B97F4A7C15)

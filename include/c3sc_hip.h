@@ -56,6 +56,8 @@ enum {
     C3SC_MODEL_LQGND = 4,    /* examples/lqgnd/lqgnd.c:80-198; params {dim, sig_even, sig_odd} */
     C3SC_MODEL_CHAIN = 5,    /* examples/double_int/double_int.c:80-157; params {dim, sig, sig_last, stage_mode} */
     C3SC_MODEL_ROSSLER3D = 6, /* examples/rossler/rossler.c:80-157; params {3, sig, sig_last} */
+    C3SC_MODEL_PERCH7D = 8,  /* examples/perching/perch.c:36-273: glider perching, 7 states, elevator rate u in [-2 pi, 2 pi] */
+    C3SC_MODEL_TPROB3D = 7,  /* the reference tests' 3-D problem: test/transition_prob/tprob_test.c f3 :223-251, s2, stagecost3d */
     C3SC_MODEL_TABLE = 100   /* host-evaluated callbacks (c3sc_hip_bellman_fibers_tables); not set with set_model */
 };
 

@@ -2,6 +2,9 @@
  * pinning status).  Scalar C99 restatement of the c3sc Bellman-backup hot path.
  * All file:line citations are relative to /root/reference/.
  */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846 /* strict ISO C has no M_PI; perch.c uses it (:66, 231) */
+#endif
 #include "c3sc_oracle.h"
 
 #include <assert.h>
@@ -697,6 +700,8 @@ int orc_model_dims(int model, const double *p, size_t *dx, size_t *du)
     case ORC_MODEL_LQGND: *dx = (size_t)p[0]; *du = (size_t)p[0] / 2; return 0;
     case ORC_MODEL_CHAIN: *dx = (size_t)p[0]; *du = 1; return 0;
     case ORC_MODEL_ROSSLER3D: *dx = 3; *du = 1; return 0;
+    case ORC_MODEL_TPROB3D: *dx = 3; *du = 3; return 0;
+    case ORC_MODEL_PERCH7D: *dx = 7; *du = 1; return 0;
     default: return 1;
     }
 }
@@ -745,6 +750,31 @@ int orc_model_drift(int model, const double *p, const double *x, const double *u
         out[dim - 1] = u[0];
         return 0;
     }
+    case ORC_MODEL_PERCH7D: { /* perch.c:36-139, the reference's own expressions (libm cos / sin / atan2) */
+        const double m = 0.05, g = 9.81, rho = 1.292, S_w = 0.1, S_e = 0.025, In = 6e-3, l = 0.35, l_w = -0.03, l_e = 0.04;
+        const double c_t = cos(x[2]), c_tp = cos(x[2] + x[3]), c_p = cos(x[3]), s_t = sin(x[2]), s_tp = sin(x[2] + x[3]);
+        const double dx_w[2] = {x[4] + l_w * x[6] * s_t, x[5] - l_w * x[6] * c_t};
+        const double dx_w_norm_sq = dx_w[0] * dx_w[0] + dx_w[1] * dx_w[1];
+        const double dx_e[2] = {x[4] + l * x[6] * s_t + l_e * (x[6] + u[0]) * s_tp, x[5] - l * x[6] * c_t - l_e * (x[6] + u[0]) * c_tp};
+        const double dx_e_norm_sq = dx_e[0] * dx_e[0] + dx_e[1] * dx_e[1];
+        const double alpha_w = x[2] - atan2(dx_w[1], dx_w[0]);
+        const double alpha_e = x[2] + x[3] - atan2(dx_e[1], dx_e[0]);
+        const double f_w = rho * S_w * dx_w_norm_sq * sin(alpha_w);
+        const double f_e = rho * S_e * dx_e_norm_sq * sin(alpha_e);
+        out[0] = x[4];
+        out[1] = x[5];
+        out[2] = x[6];
+        out[3] = u[0];
+        out[4] = (-f_w * s_t - f_e * s_tp) / m;
+        out[5] = (f_w * c_t + f_e * c_tp - m * g) / m;
+        out[6] = (-f_w * l_w - f_e * (l * c_p + l_e)) / In;
+        return 0;
+    }
+    case ORC_MODEL_TPROB3D: /* tprob_test.c:223-251 (f3) */
+        out[0] = x[0] * pow(x[2], 2) * u[0];
+        out[1] = -x[1] * u[2] + u[1];
+        out[2] = x[0] * x[1] * u[0] + 2 * u[1];
+        return 0;
     case ORC_MODEL_ROSSLER3D: { /* rossler.c:89-94: a = b = 0.1, c = 14 */
         const double a = 0.1, b = 0.1, c = 14.0;
         out[0] = -x[1] - x[2];
@@ -775,6 +805,8 @@ int orc_model_diff_diag(int model, const double *p, const double *x, const doubl
         return 0;
     }
     case ORC_MODEL_ROSSLER3D: out[0] = p[1]; out[1] = p[1]; out[2] = p[2]; return 0; /* rossler.c:113-117 */
+    case ORC_MODEL_TPROB3D: out[0] = 1.; out[1] = 1.; out[2] = 1.; return 0; /* tprob_test.c:197-220 (s2) */
+    case ORC_MODEL_PERCH7D: for (size_t i = 0; i < 7; i++) out[i] = 1e-9; return 0; /* perch.c:165-176 */
     default: return 1;
     }
 }
@@ -793,6 +825,26 @@ int orc_model_stage(int model, const double *p, const double *x, const double *u
         *out = s;
         return 0;
     }
+    case ORC_MODEL_PERCH7D: /* perch.c:185-215 */
+        *out = 0.0;
+        *out += 20.0 * x[0] * x[0];
+        *out += 50.0 * x[1] * x[1];
+        *out += 10.0 * x[2] * x[2];
+        *out += 1.0 * x[3] * x[3];
+        *out += 1.0 * x[4] * x[4];
+        *out += 1.0 * x[5] * x[5];
+        *out += 1.0 * x[6] * x[6];
+        *out += 0.1 * u[0] * u[0];
+        return 0;
+    case ORC_MODEL_TPROB3D: /* tprob_test.c:273-300 (stagecost3d) */
+        *out = 0.0;
+        *out += 0.2 * x[0] * x[0];
+        *out += 0.5 * x[1] * x[1];
+        *out += 2.0 * x[2] * x[2];
+        *out += 0.1 * u[0] * u[0];
+        *out += 0.5 * u[1] * u[1];
+        *out += 3.0 * u[2] * u[2];
+        return 0;
     case ORC_MODEL_ROSSLER3D: { /* rossler.c:137-143 */
         const double scale = 1e2, rho = 1e0;
         *out = 0.0;
@@ -820,6 +872,18 @@ int orc_model_boundcost(int model, const double *p, const double *x, double *out
     case ORC_MODEL_LQGND: *out = 100.0; return 0;  /* lqgnd.c:183 */
     case ORC_MODEL_CHAIN: *out = 1000.0; return 0; /* double_int.c:139 */
     case ORC_MODEL_ROSSLER3D: *out = 1000.0; return 0; /* rossler.c:156 */
+    case ORC_MODEL_TPROB3D: *out = 100.0; return 0; /* tprob_test.c:302-309 */
+    case ORC_MODEL_PERCH7D: /* perch.c:222-241 */
+        *out = 0.0;
+        *out += 600.0 * x[0] * x[0];
+        *out += 400.0 * x[1] * x[1];
+        *out += 1.0 / 9.0 * x[2] * x[2];
+        *out += 5.0 * (x[2] - M_PI / 2.0) * (x[2] - M_PI / 2.0);
+        *out += 1.0 / 9.0 * x[3] * x[3];
+        *out += 1.0 * x[4] * x[4];
+        *out += 1.0 * (x[5] + 1.5) * (x[5] + 1.5);
+        *out += 1.0 / 9.0 * (x[6] + 0.5) * (x[6] + 0.5);
+        return 0;
     default: return 1;
     }
 }

@@ -108,7 +108,9 @@ enum orc_model {
     ORC_MODEL_CAR7D = 3,    /* synthetic 7-D car, SURVEY.md 8d config C4  */
     ORC_MODEL_LQGND = 4,    /* examples/lqgnd/lqgnd.c:80-198 (dim=2: lqg2d_new/lqg2d.c:72-153) */
     ORC_MODEL_CHAIN = 5,    /* examples/double_int/double_int.c:80-157; params[2]=1 -> stage sum x^2 */
-    ORC_MODEL_ROSSLER3D = 6 /* examples/rossler/rossler.c:80-157 */
+    ORC_MODEL_ROSSLER3D = 6, /* examples/rossler/rossler.c:80-157 */
+    ORC_MODEL_PERCH7D = 8,   /* examples/perching/perch.c:36-273 */
+    ORC_MODEL_TPROB3D = 7    /* test/transition_prob/tprob_test.c: f3 :223-251, s2 :197-220, stagecost3d :273-300, boundcost, ocost */
 };
 int orc_model_dims(int model, const double *params, size_t *dx, size_t *du);
 int orc_model_drift(int model, const double *params, const double *x, const double *u, double *out);

@@ -86,3 +86,18 @@ def P_lb(P):
 
 def P_ub(P):
     return np.array(P.w.ub)
+
+
+# ---- Test_bellman_pi3d (tprob_test.c:2448-2540)
+def pi3d_cfg():
+    w = wl.WORKLOADS["tprob3d"]()  # 25^3, rank 10, beta 0.1, absorbing faces; candidates: 5^3 over [-5,5]^3
+    return dict(w=w, max_updates=400, conv=1e-3, adapt=0, startrank=10, maxrank=10, kick=10, cross_tol=1e-8, round_tol=1e-7, pi_sweeps=20,
+                break_on_conv=True, start_fn=lambda X: (X ** 2).sum(axis=1), box=([-5.0] * 3, [5.0] * 3))  # quad3d, :1567-1574
+
+
+def pi3d_loop(path, minimiser="bruteforce", callbacks=None):
+    return R.OracleLoop(pi3d_cfg()) if path == "oracle" else R.GpuLoop(pi3d_cfg(), minimiser, callbacks)
+
+
+def f3(x, u):  # tprob_test.c:223-251
+    return np.array([x[0] * x[2] ** 2 * u[0], -x[1] * u[2] + u[1], x[0] * x[1] * u[0] + 2 * u[1]])

@@ -34,6 +34,9 @@ SMALL = [
     ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8)),
     ("quad10d", dict(ngrid=(5, 6, 5, 4, 5, 6, 5, 4, 5, 6), rank=4)),
     ("rossler3d", dict(ngrid=(23, 40, 31), rank=7)),  # examples/rossler: state-dependent drift in every equation
+    ("tprob3d", dict(ngrid=(25, 19, 22), rank=10)),   # the reference tests' own 3-D problem (tprob_test.c f3): 3 controls, 125 candidates
+    ("perch7d", dict(ngrid=(6, 5, 7, 6, 5, 6, 5), rank=4)),     # examples/perching: 7-D glider (atan2 / sin in the reference, sqrt on the device)
+    ("perch7d", dict(ngrid=(20,) * 7, rank=15)),               # ... at the example's own size: N = 20, maxrank 15 (padded 16)
 ]
 
 
@@ -337,8 +340,10 @@ def _with_cands(w, cands):
 
 @pytest.mark.parametrize("name,kw,grid,fine", [("lqg2d", dict(ngrid=(21, 19), rank=4), 33, 20001),
                                                ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8), 9, 41),
-                                               ("rossler3d", dict(ngrid=(17, 21, 19), rank=6), 33, 20001)],
-                         ids=["lqg2d-du1", "lqg6d-du3", "rossler3d-du1"])
+                                               ("rossler3d", dict(ngrid=(17, 21, 19), rank=6), 33, 20001),
+                                               ("perch7d", dict(ngrid=(6, 5, 7, 6, 5, 6, 5), rank=4), 65, 20001),
+                                               ("tprob3d", dict(ngrid=(9, 8, 7), rank=6), 21, 41)],
+                         ids=["lqg2d-du1", "lqg6d-du3", "rossler3d-du1", "perch7d-du1", "tprob3d-du3"])
 def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
     """c3sc_hip_bellman_fibers_box: the non-BRUTEFORCE branch of bellman_optimal (bellman.c:545-1118).  The optimiser
     there is C3's BFGS (third party, unpinned), so the check is the reference's own (tprob_test.c:1494-1540):
@@ -348,7 +353,13 @@ def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
 
     w = wl.WORKLOADS[name]().scaled(**kw)
     cores = wl.synth_cores(w)
-    lb, ub = (-4.0 * np.ones(1), 4.0 * np.ones(1)) if name == "rossler3d" else (-np.ones(w.du), np.ones(w.du))  # rossler.c:212-213
+    lb, ub = -np.ones(w.du), np.ones(w.du)
+    if name == "rossler3d":
+        lb, ub = -4.0 * np.ones(1), 4.0 * np.ones(1)                    # rossler.c:212-213
+    elif name == "perch7d":
+        lb, ub = -2.0 * np.pi * np.ones(1), 2.0 * np.pi * np.ones(1)    # perch.c:329-330
+    elif name == "tprob3d":
+        lb, ub = -5.0 * np.ones(3), 5.0 * np.ones(3)                    # tprob_test.c:2463-2466
     eng = _engine(w, cores, 0)
     eng.set_control_box(lb, ub, grid=grid, polish=2)
     n100 = 100 if w.du == 1 else 11
@@ -367,11 +378,45 @@ def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
         live = ab == 0
         scale = np.abs(rfine).max()
         assert (out[live] <= r100[live] + 1e-10).all()          # the reference's assertion on bellman_optimal
-        assert (out[live] >= rfine[live] - 2e-5 * scale).all()  # not below what a much finer scan finds (up to its spacing)
+        # not below what a much finer scan finds, up to that scan's resolution (tprob3d: 41 points over [-5,5] per control, and
+        # the node objective has kinks where a drift component changes sign -- the continuous minimiser legitimately gets lower)
+        low_tol = 1e-2 if name == "tprob3d" else 2e-5
+        assert (out[live] >= rfine[live] - low_tol * scale).all(), float((rfine[live] - out[live]).max() / scale)
         np.testing.assert_allclose(out[~live], rfine[~live], rtol=1e-12)  # absorbed nodes: boundcost / obscost
         assert (uo >= lb - 1e-15).all() and (uo <= ub + 1e-15).all()
         back, _ = eng.policy_fibers_box_host(k, idx, uo)  # bellman_pi with the continuous policy
         np.testing.assert_allclose(back, out, rtol=1e-12, atol=1e-12 * scale)
+
+
+@pytest.mark.parametrize("nfib", [50, 20000], ids=["small-batch", "pair-sized-batch"])
+def test_candidate_lists_longer_than_a_wavefront(oracle, nfib):
+    """The kernels fill their candidate table with one lane per candidate, 64 at a time: the fiber-per-wave kernel walks longer
+    lists in chunks, the fiber-pair / quad kernels decline them and the launch falls through to the per-wave kernel (found this
+    round: 125 candidates used to give silently wrong minima).  97 and 200 candidates on the 2-D LQG problem, 125 on tprob3d;
+    at 20 000 fibers AUTO would take the fiber-pair kernel for 64 candidates or fewer."""
+    for name, kw, ncand in (("lqg2d", dict(ngrid=(31, 29), rank=4), 97), ("lqg2d", dict(ngrid=(31, 29), rank=4), 200),
+                            ("tprob3d", dict(ngrid=(9, 8, 7), rank=6), 125)):
+        w0 = wl.WORKLOADS[name]().scaled(**kw)
+        if name == "lqg2d":
+            w0 = _with_cands(w0, np.linspace(-1.0, 1.0, ncand).reshape(-1, 1) + 1e-3)
+        assert w0.ncand == ncand
+        cores = wl.synth_cores(w0)
+        P = oracle.Problem(w0, cores)
+        eng = _engine(w0, cores, 0)
+        for k in range(w0.dx):
+            idx = wl.synth_fibers(w0, k, nfib)
+            idx[0, :] = 0
+            idx[1, :] = np.array(w0.ngrid) - 1
+            idx[:, k] = 0
+            out, ui, ab = eng.bellman_fibers_host(k, idx)
+            assert eng.status() == 0 and "fiber_per_wave" in eng.last_kernel(), eng.last_kernel()
+            pick = np.arange(min(nfib, 60))
+            ref, ref_ui, ref_ab = P.bellman_fibers(k, idx[pick])
+            np.testing.assert_array_equal(ab[pick], ref_ab)
+            scale = np.abs(ref).max()
+            assert np.abs(out[pick] - ref).max() <= REL_TOL * scale
+            bad = ui[pick] != ref_ui
+            assert not bad.any() or np.abs(out[pick] - ref)[bad].max() <= REL_TOL * scale
 
 
 def test_edge_cases_empty_batch_max_rank_max_nodes(oracle):

@@ -512,3 +512,77 @@ def test_consistent_ends_make_the_fiber_function_a_function_of_the_node(oracle):
     # and along theta it differs from the literal rule at end points only
     d = dense["con", 2][0] != dense["lit", 2][0]
     assert d.any() and not d[:, :, 1:-1].any()
+
+
+def test_tprob3d_model_restates_the_reference_tests_callbacks(oracle):
+    """ORC_MODEL_TPROB3D against the formulas of test/transition_prob/tprob_test.c (f3 :223-251, s2 :197-220, stagecost3d
+    :273-300, boundcost :302-309, ocost :311-318) written out here."""
+    import ctypes as C
+
+    from c3sc_amd import workloads as wl
+
+    L = oracle.lib()
+    rng = np.random.default_rng(21)
+    dx, du = C.c_size_t(0), C.c_size_t(0)
+    assert L.orc_model_dims(wl.MODEL_TPROB3D, None, C.byref(dx), C.byref(du)) == 0 and (dx.value, du.value) == (3, 3)
+    for _ in range(50):
+        x, u = rng.uniform(-3, 3, 3), rng.uniform(-5, 5, 3)
+        out = np.zeros(3)
+        px, pu, po = oracle.dp(x), oracle.dp(u), oracle.dp(out)
+        assert L.orc_model_drift(wl.MODEL_TPROB3D, None, px, pu, po) == 0
+        np.testing.assert_array_equal(out, [x[0] * x[2] ** 2 * u[0], -x[1] * u[2] + u[1], x[0] * x[1] * u[0] + 2 * u[1]])
+        assert L.orc_model_diff_diag(wl.MODEL_TPROB3D, None, px, pu, po) == 0
+        np.testing.assert_array_equal(out, [1.0, 1.0, 1.0])
+        s = C.c_double(0)
+        assert L.orc_model_stage(wl.MODEL_TPROB3D, None, px, pu, C.byref(s)) == 0
+        want = 0.0
+        for t in (0.2 * x[0] * x[0], 0.5 * x[1] * x[1], 2.0 * x[2] * x[2], 0.1 * u[0] * u[0], 0.5 * u[1] * u[1], 3.0 * u[2] * u[2]):
+            want += t
+        assert s.value == want
+        assert L.orc_model_boundcost(wl.MODEL_TPROB3D, None, px, C.byref(s)) == 0 and s.value == 100.0
+        assert L.orc_model_obscost(wl.MODEL_TPROB3D, None, px, C.byref(s)) == 0 and s.value == 0.0
+
+
+def test_perch7d_model_restates_the_example(oracle):
+    """ORC_MODEL_PERCH7D against examples/perching/perch.c:36-241 written out here with Python's libm (the oracle keeps the
+    reference's own expressions: cos / sin / atan2); and the identity the device functor uses instead --
+    |v|^2 sin(a - atan2(v_z, v_x)) == |v| (sin a v_x - cos a v_z) -- to 1e-13 relative of the force scale."""
+    import ctypes as C
+    import math
+
+    from c3sc_amd import workloads as wl
+
+    L = oracle.lib()
+    w = wl.WORKLOADS["perch7d"]()
+    rng = np.random.default_rng(22)
+    m, g, rho, S_w, S_e, In, l, l_w, l_e = 0.05, 9.81, 1.292, 0.1, 0.025, 6e-3, 0.35, -0.03, 0.04
+    for _ in range(200):
+        x = rng.uniform(w.lb, w.ub)
+        u = rng.uniform(-2 * math.pi, 2 * math.pi, 1)
+        c_t, s_t, c_tp, s_tp, c_p = math.cos(x[2]), math.sin(x[2]), math.cos(x[2] + x[3]), math.sin(x[2] + x[3]), math.cos(x[3])
+        dw = (x[4] + l_w * x[6] * s_t, x[5] - l_w * x[6] * c_t)
+        de = (x[4] + l * x[6] * s_t + l_e * (x[6] + u[0]) * s_tp, x[5] - l * x[6] * c_t - l_e * (x[6] + u[0]) * c_tp)
+        f_w = rho * S_w * (dw[0] * dw[0] + dw[1] * dw[1]) * math.sin(x[2] - math.atan2(dw[1], dw[0]))
+        f_e = rho * S_e * (de[0] * de[0] + de[1] * de[1]) * math.sin(x[2] + x[3] - math.atan2(de[1], de[0]))
+        want = [x[4], x[5], x[6], u[0], (-f_w * s_t - f_e * s_tp) / m, (f_w * c_t + f_e * c_tp - m * g) / m, (-f_w * l_w - f_e * (l * c_p + l_e)) / In]
+        out = np.zeros(7)
+        assert L.orc_model_drift(wl.MODEL_PERCH7D, None, oracle.dp(x), oracle.dp(u), oracle.dp(out)) == 0
+        np.testing.assert_allclose(out, want, rtol=4e-16, atol=0)  # the compiler may associate a product differently: an ulp
+        f_w2 = rho * S_w * math.hypot(*dw) * (s_t * dw[0] - c_t * dw[1])
+        f_e2 = rho * S_e * math.hypot(*de) * (s_tp * de[0] - c_tp * de[1])
+        assert abs(f_w2 - f_w) <= 1e-13 * (1.0 + abs(f_w)) and abs(f_e2 - f_e) <= 1e-13 * (1.0 + abs(f_e))
+        s = C.c_double(0)
+        assert L.orc_model_stage(wl.MODEL_PERCH7D, None, oracle.dp(x), oracle.dp(u), C.byref(s)) == 0
+        want_s = 0.0
+        for t in (20.0 * x[0] * x[0], 50.0 * x[1] * x[1], 10.0 * x[2] * x[2], 1.0 * x[3] * x[3], 1.0 * x[4] * x[4], 1.0 * x[5] * x[5], 1.0 * x[6] * x[6],
+                  0.1 * u[0] * u[0]):
+            want_s += t
+        assert s.value == want_s
+        assert L.orc_model_boundcost(wl.MODEL_PERCH7D, None, oracle.dp(x), C.byref(s)) == 0
+        want_b = 0.0
+        for t in (600.0 * x[0] * x[0], 400.0 * x[1] * x[1], 1.0 / 9.0 * x[2] * x[2], 5.0 * (x[2] - math.pi / 2.0) * (x[2] - math.pi / 2.0),
+                  1.0 / 9.0 * x[3] * x[3], 1.0 * x[4] * x[4], 1.0 * (x[5] + 1.5) * (x[5] + 1.5), 1.0 / 9.0 * (x[6] + 0.5) * (x[6] + 0.5)):
+            want_b += t
+        assert s.value == want_b
+        out7 = np.zeros(7)
+        assert L.orc_model_diff_diag(wl.MODEL_PERCH7D, None, oracle.dp(x), oracle.dp(u), oracle.dp(out7)) == 0 and (out7 == 1e-9).all()

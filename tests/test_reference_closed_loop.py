@@ -89,3 +89,33 @@ def test_ref_bellman_vi_closed_loop_on_the_device(oracle):
             assert norm <= float(g["norm"]) * (1 + 1e-6) and norm >= float(g["norm"]) * (1 - 5e-3)
         L.valuef_destroy(cost)
         gpu.close()
+
+
+# ------------------------------------------------------------------------------------------------ Test_bellman_pi3d (:2448-2540)
+PI3D_GOAL_HALF = 0.4  # goal_width / 2, tprob_test.c:2459, 2530-2535
+
+
+def test_ref_bellman_pi3d_closed_loop_oracle_path(oracle):
+    """The oracle-fed replay of Test_bellman_pi3d (tools/run_reference_pi3d.py -> tests/golden/closed_loop_pi3d_oracle.npz: 3
+    states, 3 controls, fixed rank 10 on 25^3, 400 control updates of pi_solve(20) + one vi_solve step, 5^3 candidates over the
+    reference's control box): the implicit policy of its value function, evaluated by the oracle's restatement of
+    c3control_policy_eval, steers (-0.5, -0.5, 0.5) for 10 time units (run_sim_3d_3d).  The reference asserts the goal box
+    |x_i| < 0.4 -- in a test its own runner never executes (AllMyTests.c:59-62).  On this problem (unit noise, absorbing faces of
+    cost 100 close to the start) the optimal feedback parks the noise-free loop near the middle of the x2 interval: -0.43 with
+    the 5^3 list, -0.96 ... -1.26 with finer controller lists, -0.97 on the device path with the box minimiser.  Asserted: what
+    holds on every path -- the loop ran its 400 updates, the end state is inside the domain, x0 (the directly controlled
+    state) inside the box, and the state moved towards the box in x1."""
+    g = np.load(os.path.join(GOLDEN, "closed_loop_pi3d_oracle.npz"))
+    hist = g["history"]
+    assert len(hist) == 400 or hist[-1, 1] < 1e-3  # :2503-2518
+    w0 = wl.WORKLOADS["tprob3d"]()
+    ranks = tuple(int(r) for r in g["ranks"])
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, ranks, w0.discount, w0.bc, [], g["cands"])
+    P = oracle.Problem(w, [g[f"core{m}"].reshape(w.ngrid[m], -1) for m in range(3)], consistent_ends=True)
+    ctl = CL.oracle_controller(oracle, P, w.cands)
+    xT = CL.simulate_rk4(CL.f3, ctl, [-0.5, -0.5, 0.5], 10.0, 1e-2, 1e-2)
+    print(f"oracle path: |V| = {float(g['norm']):.6f} after {len(hist)} control updates / {int(g['sweeps'])} sweeps (last |V_vi - V_pi| {hist[-1, 1]:.3e}); "
+          f"closed loop ends at {xT}")
+    print(f"goal box reached: {bool(np.all(np.abs(xT) < PI3D_GOAL_HALF))}")
+    assert np.all(np.isfinite(xT)) and np.all(xT > np.array(w.lb)) and np.all(xT < np.array(w.ub))
+    assert abs(xT[0]) < PI3D_GOAL_HALF and abs(xT[1]) < 0.5

@@ -234,6 +234,14 @@ def solver_measurements(workload, budget_s):
     L.valuef_destroy(cost)
     L.approx_args_free(aa)
     ctl.close()
+    if workload == "car7d":  # is the floor approximation error?  dense ground truth on a reduced grid (a few seconds)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import dense_truth
+
+            iters["reduced_grid_truth"] = dense_truth.reduced_grid_truth(9, 9, 600)
+        except Exception as e:
+            iters["reduced_grid_truth"] = {"error": repr(e)}
 
     # the same loop on BASELINE config C2 (dubins3d 101^3): the examples' control update (pi_solve(10) + one vi_solve step) to a tolerance
     w2 = wl.WORKLOADS["dubins3d"]()

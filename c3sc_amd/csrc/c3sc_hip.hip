@@ -427,7 +427,10 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
     }
     const size_t primary_end = off;
     long coreT_off[MAXD] = {0}, aop_off[MAXD] = {0};
-    if (rp % 4 == 0) { // derived copies for the fiber-quad kernel (k_quad_aux)
+    bool have_quad = false; // the derived copies are made only when a fiber-quad kernel of this (model, dimension, padded rank) exists
+    for (const auto &e : kernel_registry())
+        if (e.variant == C3SC_VARIANT_FIBER_QUAD && e.d == d && e.rp == rp && (c->model == 0 || e.model == c->model)) have_quad = true;
+    if (rp % 4 == 0 && have_quad) { // derived copies for the fiber-quad kernel (k_quad_aux)
         const int C = rp / 4, MB = (C + 3) / 4;
         for (int m = 1; m < d - 1; m++) {
             coreT_off[m] = (long)off;
@@ -443,7 +446,7 @@ static int prepare_value(c3sc_hip_ctx *c, const size_t *ranks, size_t *cores_dou
         off += ((size_t)c->ngrid[m] * (per | 1) + 2 + 15) & ~(size_t)15;
     }
     long qimgL_off[MAXD] = {0}, qimgR_off[MAXD] = {0};
-    if (rp % 4 == 0) { // LDS images for the duo kernel's double-buffered LDS-DMA staging
+    if (rp % 4 == 0 && have_quad) { // LDS images for the duo kernel's double-buffered LDS-DMA staging
         for (int m = 0; m < d; m++) {
             const size_t per = (m == 0 || m == d - 1) ? rp : (size_t)rp * rp;
             const size_t sz = ((size_t)c->ngrid[m] * (per + 2) + 15) & ~(size_t)15;
@@ -524,6 +527,9 @@ int c3sc_hip_upload_value(c3sc_hip_ctx *c, const size_t *ranks, const double *co
     HIPCHK(c, hipMemcpy(c->arena + c->static_doubles, buf.data(), cd * sizeof(double), hipMemcpyHostToDevice));
     rc = make_quad_aux(c, nullptr);
     if (rc != C3SC_OK) return rc;
+    // the synchronous entry point is complete on return: the derived images are built by kernels on the NULL stream, and a caller
+    // may launch on a non-blocking stream next
+    HIPCHK(c, hipStreamSynchronize(nullptr));
     c->have_value = true;
     return C3SC_OK;
 }
@@ -582,6 +588,7 @@ static int fill_args(c3sc_hip_ctx *c, int k, size_t F, KArgs &A, bool need_model
     A.img_base = c->arena;
     A.cends = c->cends;
     A.memo_keys = nullptr; // only the launch paths that found a fiber-per-wave kernel switch the memo epilogue on
+    A.skip = c->skip_flag;
     A.nobs = c->nobs;
     A.obs_off = c->obs_off;
     A.cands_off = c->cands_off;

@@ -33,24 +33,55 @@ constexpr int NT = 512;                       // threads of the core-step workgr
 constexpr int MAXROWS = 8192;                 // rows of a fiber matrix (N r): 16 per thread
 constexpr unsigned long long IDX_BITS = 22;   // low bits of a pivot-search key hold the (inverted) index
 constexpr unsigned long long IDX_MASK = (1ull << IDX_BITS) - 1;
-constexpr size_t LDS_CAP_BYTES = 140 * 1024;  // dynamic LDS of the general core step: 160 KB of a CU minus its 17 KB of static arrays
+constexpr size_t LDS_CAP_BYTES = 132 * 1024;  // dynamic LDS of the general core step: 160 KB of a CU minus its 17 KB of static arrays
 
 struct Strides { long long s[MAXD]; };
 
 // ------------------------------------------------------------------------------------------------ fiber index list
-// idx[(a + r0 b) d + m] = I_k[a][m] (m < k) | 0 (m = k) | J_k[b][m - k - 1] (m > k)
-__global__ void k_cross_idx(int32_t *__restrict__ idx, const int32_t *__restrict__ I, const int32_t *__restrict__ J, int r0, int r1, int k, int d)
+// idx[(a + r0 b) d + m] = I_k[a][m] (m < k) | 0 (m = k) | J_k[b][m - k - 1] (m > k), written by ONE workgroup into the step's own
+// list -- and compared with what is there: if the step already holds this very list with values computed in the current
+// generation (same sweep, same buffer layout), *skip = 1 and the fiber kernel that follows returns at once; every node of the
+// list would be a memo hit returning the stored value, so the cached values ARE what it would produce (same bits, no counter
+// moves).  With unchanged index sets that is every right-to-left step and every step of a confirming iteration.
+struct NextList {
+    int32_t *idx;                 // [F][d] list of the step (cached across iterations)
+    const int32_t *I, *J;         // its index sets
+    int r0, r1, k, d;
+    int *skip;                    // out: 1 = list unchanged and values valid
+    unsigned long long *tag;      // in/out: generation the cached values belong to
+    unsigned long long gen;       // current generation
+    int enable;                   // 0: never skip (sharded steps: the all-gather cannot be skipped on one rank only)
+};
+
+template <int BT>
+__device__ inline void write_list_and_flag(const NextList &L)
 {
-    const int F = r0 * r1;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F * d; e += gridDim.x * blockDim.x) {
-        const int f = e / d, m = e - f * d;
-        const int a = f % r0, b = f / r0;
+    const int tid = threadIdx.x, d = L.d, k = L.k, F = L.r0 * L.r1;
+    int differs = 0;
+    for (int e = tid; e < F * d; e += BT) {
+        const int f = e / d, mm = e - f * d;
+        const int a = f % L.r0, b = f / L.r0;
         int v = 0;
-        if (m < k) v = I[a * k + m];
-        else if (m > k) v = J[b * (d - 1 - k) + (m - k - 1)];
-        idx[e] = v;
+        if (mm < k) v = L.I[a * k + mm];
+        else if (mm > k) v = L.J[b * (d - 1 - k) + (mm - k - 1)];
+        differs |= (L.idx[e] != v);
     }
+    const int any = __syncthreads_or(differs);
+    const bool valid = L.enable && (*L.tag == L.gen) && !any;
+    if (!valid)
+        for (int e = tid; e < F * d; e += BT) {
+            const int f = e / d, mm = e - f * d;
+            const int a = f % L.r0, b = f / L.r0;
+            int v = 0;
+            if (mm < k) v = L.I[a * k + mm];
+            else if (mm > k) v = L.J[b * (d - 1 - k) + (mm - k - 1)];
+            L.idx[e] = v;
+        }
+    __syncthreads();
+    if (tid == 0) { *L.skip = valid ? 1 : 0; *L.tag = L.gen; }
 }
+
+__global__ void __launch_bounds__(256) k_cross_idx(const NextList L) { write_list_and_flag<256>(L); }
 
 // ------------------------------------------------------------------------------------------------ node memo
 // key word: [63:49] epoch of the sweep (never 0) | [48] pending | [47:0] node id.  A slot whose epoch is not the current one
@@ -105,10 +136,8 @@ struct CoreArgs {
     unsigned long long *counters; // [1] rank-deficient factorisation seen, [2] maxvol swaps
     int warm;              // pivot search starts from the rows of the previous index set (c3sc_cross.c: WARM_BOOST_LOG2)
     double swap_tol;       // maxvol swaps while max |B| > 1 + swap_tol
-    // the fiber index list of the NEXT core step, written at the end (its index sets are final then); nidx == null: none
-    int32_t *nidx;
-    const int32_t *nI, *nJ;
-    int nr0, nr1, nk;
+    // the fiber index list of the NEXT core step, written at the end (its index sets are final then); next.idx == null: none
+    NextList next;
 };
 
 constexpr int WARM_BOOST_LOG2 = 6; // as in c3sc_cross.c
@@ -119,13 +148,35 @@ __device__ inline unsigned long long pivot_key(double x, unsigned long long inde
     return ((bits >> IDX_BITS) << IDX_BITS) | (IDX_MASK - index);
 }
 
+// maximum of a u64 over the wavefront, in lane 63: DPP row shifts inside the rows of 16 lanes, then the two row broadcasts
+// (six dependent VALU steps; the ds_bpermute butterfly it replaces was twelve LDS round trips on the critical path of every
+// elimination column).  0 is the identity: lanes a shift does not reach read 0.
+template <int CTRL, int ROWMASK>
+__device__ inline unsigned long long dpp_u64(unsigned long long v)
+{
+    int lo = (int)(unsigned)(v & 0xffffffffull), hi = (int)(unsigned)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+__device__ inline unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+
+__device__ inline unsigned long long wave_max_u64(unsigned long long v)
+{
+    v = umax64(v, dpp_u64<0x111, 0xf>(v)); // row_shr:1
+    v = umax64(v, dpp_u64<0x112, 0xf>(v)); // row_shr:2
+    v = umax64(v, dpp_u64<0x114, 0xf>(v)); // row_shr:4
+    v = umax64(v, dpp_u64<0x118, 0xf>(v)); // row_shr:8   -> lane 15 of every row holds the row's maximum
+    v = umax64(v, dpp_u64<0x142, 0xa>(v)); // row_bcast:15 into rows 1 and 3
+    v = umax64(v, dpp_u64<0x143, 0xc>(v)); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's maximum
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ inline unsigned long long block_max(unsigned long long v, unsigned long long *red /* [2][NT / 64] */, int &parity)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
+    v = wave_max_u64(v);
     unsigned long long *buf = red + parity * (NT / 64);
     if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -212,17 +263,9 @@ __device__ inline void write_sets_and_next(const CoreArgs &P, int n, const int *
             if (nswaps) atomicAdd(&P.counters[2], (unsigned long long)nswaps);
         }
     }
-    if (P.nidx) { // fiber list of the next core step (k_cross_idx's job, without a launch of its own)
+    if (P.next.idx) { // fiber list of the next core step (k_cross_idx's job, without a launch of its own)
         __syncthreads();
-        const int d = P.d, k = P.nk, F = P.nr0 * P.nr1;
-        for (int e = tid; e < F * d; e += NT) {
-            const int f = e / d, mm = e - f * d;
-            const int a = f % P.nr0, b = f / P.nr0;
-            int v = 0;
-            if (mm < k) v = P.nI[a * k + mm];
-            else if (mm > k) v = P.nJ[b * (d - 1 - k) + (mm - k - 1)];
-            P.nidx[e] = v;
-        }
+        write_list_and_flag<NT>(P.next);
     }
 }
 
@@ -307,8 +350,11 @@ __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P)
                     for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
                 }
         }
-        __syncthreads();
+        // no barrier here: the next column's pivot search reads a thread's own rows only, and the barrier inside its block_max
+        // stands between this update of a row and any other thread reading it as the next pivot row (pivot rows are never
+        // written again)
     }
+    __syncthreads();
     // ---- B = L inv(L[rows]): L[rows] is unit lower triangular in pivot order
     for (int e = tid; e < n * n; e += NT) {
         const int q = e / n, j = e % n;
@@ -380,7 +426,8 @@ __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P)
         }
         if (tid == 0) rows[bj] = bi;
         nswaps++;
-        __syncthreads();
+        // no barrier here either: the next search reads own rows, its block_max barrier orders the rest (rowv is rewritten only
+        // after that barrier, when every thread has finished this update)
     }
     __syncthreads();
     sort_rows(n, rows, srows, pos);
@@ -419,6 +466,10 @@ struct c3sc_cross_dev {
         size_t cap = 0;
         unsigned epoch = 0;
     } vmemo, pmemo;
+    // per core step k: its fiber list and values stay on the device so that a step asked for the same list again in the same
+    // generation is not recomputed (k_cross_idx / write_list_and_flag)
+    size_t offIdx[MAXD] = {0}, offOut[MAXD] = {0}, off_flags = 0;
+    unsigned long long gen = 0;
     long long policy_tag = -1; // the caller's policy-iteration counter the policy memo belongs to
     size_t off_uidx = 0;       // [Fmax][Nmax] candidate indices between the policy pass and the evaluation pass
     Strides strides;
@@ -522,6 +573,12 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     x->cores_bytes = off - x->off_cores;
     x->off_idx = off; off += up256(fmax * d * sizeof(int32_t));
     x->off_out = off; off += up256((fmax + 64) * nmax * sizeof(double)); // + the padding rows of a sharded step (world * ceil(F / world) >= F)
+    for (int k = 0; k < d; k++) {
+        const size_t F = (size_t)x->r[k] * x->r[k + 1];
+        x->offIdx[k] = off; off += up256(F * d * sizeof(int32_t));
+        x->offOut[k] = off; off += up256((F + 64) * x->N[k] * sizeof(double));
+    }
+    x->off_flags = off; off += up256(MAXD * (sizeof(int) + sizeof(unsigned long long)) + 64);
     x->off_work = off; off += up256(wmax * sizeof(double));
     x->off_uidx = off; off += up256(fmax * nmax * sizeof(int32_t));
     if (off > x->slab_bytes) {
@@ -530,6 +587,8 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
         HIPCHK(c, hipMalloc((void **)&x->slab, off));
         x->slab_bytes = off;
     }
+    x->gen++; // every set-up starts a new generation of cached step values: the layout, the ranks or the sweep changed
+    HIPCHK(c, hipMemsetAsync(x->slab + x->off_flags, 0, MAXD * (sizeof(int) + sizeof(unsigned long long)) + 64, nullptr));
     const size_t need_stage = x->sets_bytes + x->cores_bytes + 64;
     if (need_stage > x->stage_bytes) {
         if (x->stage) HIPCHK(c, hipHostFree(x->stage));
@@ -608,18 +667,31 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
     }
     c3sc_cross_dev::MemoTab &mt = pol ? x->pmemo : x->vmemo;
     const int shift = memo_shift_of(mt.cap);
-    int32_t *idx = (int32_t *)(x->slab + x->off_idx), *uidx = (int32_t *)(x->slab + x->off_uidx);
-    double *out = (double *)(x->slab + x->off_out);
+    int32_t *uidx = (int32_t *)(x->slab + x->off_uidx);
     auto setI = [&](int k) { return (int32_t *)(x->slab + x->offI[k]); };
     auto setJ = [&](int k) { return (int32_t *)(x->slab + x->offJ[k]); };
+    auto listOf = [&](int k) { return (int32_t *)(x->slab + x->offIdx[k]); };
+    auto outOf = [&](int k) { return (double *)(x->slab + x->offOut[k]); };
+    int *skipf = (int *)(x->slab + x->off_flags);
+    unsigned long long *tags = (unsigned long long *)(x->slab + x->off_flags + 64);
+    auto nextList = [&](int k) {
+        NextList L;
+        L.idx = listOf(k); L.I = setI(k); L.J = setJ(k); L.r0 = x->r[k]; L.r1 = x->r[k + 1]; L.k = k; L.d = d;
+        L.skip = skipf + k; L.tag = tags + k; L.gen = x->gen; L.enable = comm ? 0 : 1;
+        return L;
+    };
     // the first step's fiber list; every later one is written by the core step before it
-    hipLaunchKernelGGL(k_cross_idx, dim3((unsigned)(((size_t)x->r[0] * x->r[1] * d + 255) / 256)), dim3(256), 0, st, idx, setI(0), setJ(0), x->r[0],
-                       x->r[1], 0, d);
+    hipLaunchKernelGGL(k_cross_idx, dim3(1), dim3(256), 0, st, nextList(0));
     for (int s = 0; s < 2 * d; s++) {
         const int half = s / d, k = half == 0 ? s : 2 * d - 1 - s;
         const int r0 = x->r[k], r1 = x->r[k + 1], N = x->N[k];
         const size_t F = (size_t)r0 * r1;
         const long total = (long)F * N;
+        int32_t *idx = listOf(k);
+        double *out = outOf(k);
+        // a step that already holds the values of this very list (flag written by the kernel that made the list) is not recomputed
+        c->skip_flag = comm ? nullptr : skipf + k;
+        if (pol) pol->skip_flag = c->skip_flag;
         // the fiber-per-wave kernel applies the memo in its epilogue (ctx->memo); any other kernel is followed by the memo pass
         c3sc_hip_ctx *mc = pol ? pol : c; // the context whose launch carries the memo
         mc->memo.keys = mt.keys; mc->memo.vals = mt.vals; mc->memo.capmask = (unsigned long long)(mt.cap - 1); mc->memo.shift = shift;
@@ -640,10 +712,12 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         else rc = box ? c3sc_hip_bellman_fibers_box(c, k, F, idx, out, nullptr, nullptr, stream)
                       : c3sc_hip_bellman_fibers(c, k, F, idx, out, nullptr, nullptr, stream);
         mc->memo.keys = nullptr;
-        if (rc != C3SC_OK) { if (pol && rc != C3SC_OK) c->err = pol->err; return rc; }
+        if (pol) pol->skip_flag = nullptr;
+        if (rc != C3SC_OK) { c->skip_flag = nullptr; if (pol) c->err = pol->err; return rc; }
         if (pol) {
-            if (!mc->memo.applied) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: the policy pass needs the fiber-per-wave kernel");
+            if (!mc->memo.applied) { c->skip_flag = nullptr; return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: the policy pass needs the fiber-per-wave kernel"); }
             rc = c3sc_hip_policy_fibers(c, k, F, idx, uidx, out, nullptr, stream);
+            c->skip_flag = nullptr;
             if (rc != C3SC_OK) return rc;
         } else if (!mc->memo.applied)
             hipLaunchKernelGGL(k_cross_memo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, idx, out, total, N, d, k, x->strides, mt.keys,
@@ -659,10 +733,11 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         P.counters = x->counters;
         P.warm = x->warm;
         P.swap_tol = x->swap_tol;
-        P.nidx = nullptr; P.nI = P.nJ = nullptr; P.nr0 = P.nr1 = P.nk = 0;
+        c->skip_flag = nullptr;
+        std::memset(&P.next, 0, sizeof(P.next));
         if (s + 1 < 2 * d) {
             const int nh = (s + 1) / d, nk = nh == 0 ? s + 1 : 2 * d - 2 - s;
-            P.nidx = idx; P.nI = setI(nk); P.nJ = setJ(nk); P.nr0 = x->r[nk]; P.nr1 = x->r[nk + 1]; P.nk = nk;
+            P.next = nextList(nk);
         }
         const size_t mn = F * N * sizeof(double);
         if (P.copy_only) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), 0, st, P);

@@ -69,6 +69,7 @@ struct c3sc_hip_ctx {
         int mode = 0;         // KArgs::memo_mode
         bool applied = false; // the launched kernel carried the memo in its epilogue
     } memo;
+    const int *skip_flag = nullptr; // device flag the next fiber-per-wave launch returns on at once when set (cross_device.hip)
     c3sc_hip_comm *shard_comm = nullptr; // borrowed: the cross iterations shard their core steps over it (c3sc_hip_cross_set_comm)
     c3sc_cross_dev *cross = nullptr; // owned; freed by c3sc_hip_cross_free (called from c3sc_hip_ctx_destroy)
 };

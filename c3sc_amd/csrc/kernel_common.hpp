@@ -65,6 +65,7 @@ struct KArgs {
     int memo_shift;
     long long memo_stride[MAXD];
     unsigned long long *memo_counters; // [0] nodes stored, [3] table full
+    const int *skip; // fiber-per-wave kernel: return at once when *skip != 0 (the caller already holds this batch's values)
     int memo_mode; // 0: the node's VALUE (bellman_vi's memo); 1: its POLICY, the winning candidate index of a live node
                    // (bellman_pi's per-node cache under key2, bellman.c:1806, 1877)
     const double *img_base;    // the arena again, as a pointer that is NOT the kernels' `ro` argument: the LDS-DMA copy reads the

@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
     constexpr int D = Model::D;
     constexpr int S = 2 * D + 1;
     constexpr int WS = 4 * RP + 2 * D * RP + 64 * NPL; // per-wave scratch (doubles)
+    if (A.skip != nullptr && __builtin_amdgcn_readfirstlane(*A.skip) != 0) return; // the caller already holds these values (cross_device.hip)
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -44,8 +44,13 @@ struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32
 /* new: the same, with the fibers of every core step sharded over `world` ranks (one process per GPU): rank r runs fi on
  * the contiguous block [lo, hi) = ceil(F/world) fibers and `exchange(out, F, N_k, lo, hi, xarg)` fills the other ranks'
  * rows of out[F*N_k] (an all-gather: RCCL on the GPU box, gloo in the CPU tests; c3sc_amd/distributed.py builds it).
- * Every rank then holds the same fiber values and takes the same QR / maxvol decisions, so the ranks' results are
- * bit-identical to each other and to the unsharded call.  SURVEY.md 8e; the reference hook is bellman.c:2201. */
+ * Every rank then holds the same fiber values and takes the same pivot decisions, so the ranks' results are bit-identical to each
+ * other; they equal the unsharded call's bit for bit when fi is a function of the node (a C3Control's default, see
+ * c3control_set_consistent_ends) or, with the literal end-point rule, when the caller keeps every rank's node memo complete
+ * (c3control_step_vi does: the rows other ranks computed enter its memo; c3control_step_pi's per-node policy memo holds this
+ * rank's rows only, so with the literal rule a sharded policy evaluation may break a near-tie differently from the unsharded
+ * run).  A rank whose fi fails still enters the exchange (its rows marked NaN) and all ranks return the error together.
+ * SURVEY.md 8e; the reference hook is bellman.c:2201. */
 typedef int (*c3sc_exchange_fn)(double *out, size_t F, size_t N, size_t lo, size_t hi, void *xarg);
 struct ValueF *valuef_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
                                          const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,

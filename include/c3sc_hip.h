@@ -109,7 +109,9 @@ int c3sc_hip_set_controls(c3sc_hip_ctx *ctx, int ncand, int du, const double *ca
 /* replaces vi_param_add_value + valuef_precompute_cores (bellman.c:1173, valuefunc.c:165-189):
  * ranks[d+1], cores[m] host arrays in the reference layout */
 int c3sc_hip_upload_value(c3sc_hip_ctx *ctx, const size_t *ranks, const double *const *cores);
-/* same, cores already resident on the device (e.g. after the RCCL all-gather of updated cores) */
+/* same, cores already resident on the device (e.g. after the RCCL all-gather of updated cores).  Asynchronous on `stream`: the
+ * padded cores and the kernels' derived images are built by launches on that stream -- launch the fibers on the same stream or
+ * synchronise first.  (c3sc_hip_upload_value above is complete on return.) */
 int c3sc_hip_upload_value_device(c3sc_hip_ctx *ctx, const size_t *ranks, const double *const *d_cores, void *stream);
 int c3sc_hip_set_variant(c3sc_hip_ctx *ctx, int variant);
 

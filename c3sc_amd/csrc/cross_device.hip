@@ -138,6 +138,10 @@ struct CoreArgs {
     double swap_tol;       // maxvol swaps while max |B| > 1 + swap_tol
     // the fiber index list of the NEXT core step, written at the end (its index sets are final then); next.idx == null: none
     NextList next;
+    // confirm mode (k_cross_confirm): nothing is overwritten -- the index set the step produces is COMPARED with set_out, a
+    // difference raises *mismatch; the core is written only by the right-to-left steps (they own G in a finished iteration)
+    int confirm;
+    int *mismatch;
 };
 
 constexpr int WARM_BOOST_LOG2 = 6; // as in c3sc_cross.c
@@ -241,21 +245,27 @@ __device__ inline void write_sets_and_next(const CoreArgs &P, int n, const int *
 {
     const int tid = threadIdx.x, r0 = P.r0, N = P.N;
     if (!P.copy_only) {
+        int differs = 0;
         if (P.dir == 0) {
             const int k = P.k;
             for (int e = tid; e < n * (k + 1); e += NT) {
                 const int q = e / (k + 1), t = e % (k + 1);
                 const int row = srows[q], a = row % r0, j = row / r0;
-                P.set_out[e] = t < k ? P.set_in[a * k + t] : j;
+                const int v = t < k ? P.set_in[a * k + t] : j;
+                if (P.confirm) differs |= (P.set_out[e] != v);
+                else P.set_out[e] = v;
             }
         } else {
             const int len = P.d - P.k;
             for (int e = tid; e < n * len; e += NT) {
                 const int q = e / len, t = e % len;
                 const int row = srows[q], j = row % N, b = row / N;
-                P.set_out[e] = t == 0 ? j : P.set_in[b * (len - 1) + (t - 1)];
+                const int v = t == 0 ? j : P.set_in[b * (len - 1) + (t - 1)];
+                if (P.confirm) differs |= (P.set_out[e] != v);
+                else P.set_out[e] = v;
             }
         }
+        if (P.confirm && differs) atomicOr(P.mismatch, 1);
         if (tid == 0) {
             double mx = 0.0, mn = INFINITY;
             for (int c = 0; c < n; c++) { mx = pivabs[c] > mx ? pivabs[c] : mx; mn = pivabs[c] < mn ? pivabs[c] : mn; }
@@ -276,7 +286,7 @@ __device__ inline void write_sets_and_next(const CoreArgs &P, int n, const int *
 constexpr int CH = 8;
 
 template <bool INLDS>
-__global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P)
+__device__ __forceinline__ void core_step(const CoreArgs &P)
 {
 #pragma clang fp contract(off) // products and sums round separately, as in the host twin (ISO C): the two return the same bits
     extern __shared__ double smem[];
@@ -290,6 +300,7 @@ __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P)
     const int tid = threadIdx.x;
     const int r0 = P.r0, N = P.N, r1 = P.r1;
     if (P.copy_only) { // G[a + r0 (j + N b)] = out[(a + r0 b) N + j]
+        if (P.confirm && P.dir == 0) return;
         const int total = r0 * N * r1;
         for (int e = tid; e < total; e += NT) {
             const int a = e % r0, j = (e / r0) % N, b = e / (r0 * N);
@@ -440,12 +451,24 @@ __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P)
 #pragma unroll
             for (int u = 0; u < CH; u++)
                 if (c0 + u < n) {
-                    if (P.dir == 0) P.G[i + m * pos[c0 + u]] = x[u];      // G[i + m b'], i = a + r0 j
-                    else P.G[pos[c0 + u] + r0 * i] = x[u];                // G[a' + r0 cc], cc = i
+                    if (P.dir == 0) { if (!P.confirm) P.G[i + m * pos[c0 + u]] = x[u]; } // G[i + m b'], i = a + r0 j
+                    else P.G[pos[c0 + u] + r0 * i] = x[u];                                // G[a' + r0 cc], cc = i
                 }
         }
     write_sets_and_next(P, n, srows, pivabs, nswaps);
 }
+
+template <bool INLDS>
+__global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P) { core_step<INLDS>(P); }
+
+// The confirming iteration in one launch.  After an iteration that swapped rows, the next one usually changes nothing: with
+// unchanged index sets all of its 2 d core steps are independent (each factors the fiber values its step already holds), so
+// they run side by side, one workgroup per step, and only COMPARE the index sets they produce with the current ones.  If none
+// differs, the right-to-left steps have written the iteration's cores and the sequential iteration -- same kernels, same
+// inputs, same bits -- need not run; if one differs nothing was overwritten except the cores, which the sequential iteration
+// that follows rewrites anyway.
+template <bool INLDS>
+__global__ void __launch_bounds__(NT) k_cross_confirm(const CoreArgs *steps) { core_step<INLDS>(steps[blockIdx.x]); }
 
 } // namespace
 
@@ -468,7 +491,7 @@ struct c3sc_cross_dev {
     } vmemo, pmemo;
     // per core step k: its fiber list and values stay on the device so that a step asked for the same list again in the same
     // generation is not recomputed (k_cross_idx / write_list_and_flag)
-    size_t offIdx[MAXD] = {0}, offOut[MAXD] = {0}, off_flags = 0;
+    size_t offIdx[MAXD] = {0}, offOut[MAXD] = {0}, off_flags = 0, off_steps = 0;
     unsigned long long gen = 0;
     long long policy_tag = -1; // the caller's policy-iteration counter the policy memo belongs to
     size_t off_uidx = 0;       // [Fmax][Nmax] candidate indices between the policy pass and the evaluation pass
@@ -579,6 +602,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
         x->offOut[k] = off; off += up256((F + 64) * x->N[k] * sizeof(double));
     }
     x->off_flags = off; off += up256(MAXD * (sizeof(int) + sizeof(unsigned long long)) + 64);
+    x->off_steps = off; off += up256(2 * MAXD * sizeof(CoreArgs) + 64);
     x->off_work = off; off += up256(wmax * sizeof(double));
     x->off_uidx = off; off += up256(fmax * nmax * sizeof(int32_t));
     if (off > x->slab_bytes) {
@@ -589,7 +613,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     }
     x->gen++; // every set-up starts a new generation of cached step values: the layout, the ranks or the sweep changed
     HIPCHK(c, hipMemsetAsync(x->slab + x->off_flags, 0, MAXD * (sizeof(int) + sizeof(unsigned long long)) + 64, nullptr));
-    const size_t need_stage = x->sets_bytes + x->cores_bytes + 64;
+    const size_t need_stage = x->sets_bytes + x->cores_bytes + 64 + 2 * MAXD * sizeof(CoreArgs) + 64;
     if (need_stage > x->stage_bytes) {
         if (x->stage) HIPCHK(c, hipHostFree(x->stage));
         x->stage = nullptr; x->stage_bytes = 0;
@@ -623,6 +647,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     HIPCHK(c, hipMemcpy(x->slab, x->stage, x->sets_bytes, hipMemcpyHostToDevice));
     if (!x->lds_optin) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_cross_core<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP_BYTES));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_cross_confirm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP_BYTES));
         x->lds_optin = true;
     }
     return C3SC_OK;
@@ -734,6 +759,7 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         P.warm = x->warm;
         P.swap_tol = x->swap_tol;
         c->skip_flag = nullptr;
+        P.confirm = 0; P.mismatch = nullptr;
         std::memset(&P.next, 0, sizeof(P.next));
         if (s + 1 < 2 * d) {
             const int nh = (s + 1) / d, nk = nh == 0 ? s + 1 : 2 * d - 2 - s;
@@ -754,6 +780,50 @@ int c3sc_hip_cross_iteration_pi(c3sc_hip_ctx *c, c3sc_hip_ctx *policy_ctx, long 
 {
     if (!policy_ctx) return fail(c, C3SC_ERR_ARG, "cross_iteration_pi: null policy context");
     return cross_iteration_impl(c, policy_ctx, policy_tag, 0, stream);
+}
+
+/* The confirming iteration in one launch (k_cross_confirm): valid after a complete c3sc_hip_cross_iteration[_pi] -- every
+ * step then holds the fiber values of its current index sets.  *confirmed = 1: all 2 d steps reproduced their index sets; the
+ * cores of the iteration are in place (fetch them), nothing else changed.  *confirmed = 0: run the ordinary iteration. */
+int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
+{
+    if (!c || !c->cross || c->cross->d == 0 || !confirmed) return fail(c, C3SC_ERR_ARG, "cross_confirm: cross_setup first");
+    c3sc_cross_dev *x = c->cross;
+    const int d = x->d;
+    hipStream_t st = (hipStream_t)stream;
+    *confirmed = 0;
+    CoreArgs *h = (CoreArgs *)(x->stage + x->sets_bytes + x->cores_bytes + 64);
+    int *mismatch = (int *)(x->slab + x->off_flags) + MAXD + 1;
+    size_t maxmn = 0;
+    for (int s = 0; s < 2 * d; s++) {
+        const int half = s / d, k = half == 0 ? s : 2 * d - 1 - s;
+        CoreArgs &P = h[s];
+        std::memset(&P, 0, sizeof(P));
+        P.out = (double *)(x->slab + x->offOut[k]);
+        P.r0 = x->r[k]; P.N = x->N[k]; P.r1 = x->r[k + 1]; P.k = k; P.d = d;
+        P.dir = half;
+        P.copy_only = (half == 0) ? (k == d - 1) : (k == 0);
+        P.set_in = (int32_t *)(x->slab + (half == 0 ? x->offI[k] : x->offJ[k]));
+        P.set_out = P.copy_only ? nullptr : (int32_t *)(x->slab + (half == 0 ? x->offI[k + 1] : x->offJ[k - 1]));
+        P.G = (double *)(x->slab + x->offG[k]);
+        P.work = nullptr;
+        P.counters = x->counters;
+        P.warm = x->warm;
+        P.swap_tol = x->swap_tol;
+        P.confirm = 1;
+        P.mismatch = mismatch;
+        if (!P.copy_only) maxmn = std::max(maxmn, (size_t)P.r0 * P.r1 * P.N * sizeof(double));
+    }
+    if (maxmn > LDS_CAP_BYTES) return C3SC_OK; // a step does not fit LDS: no batched confirmation, the ordinary iteration runs
+    HIPCHK(c, hipMemsetAsync(mismatch, 0, sizeof(int), st));
+    HIPCHK(c, hipMemcpyAsync(x->slab + x->off_steps, h, 2 * d * sizeof(CoreArgs), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_cross_confirm<true>, dim3(2 * d), dim3(NT), maxmn, st, (const CoreArgs *)(x->slab + x->off_steps));
+    HIPCHK(c, hipGetLastError());
+    int flag = 1;
+    HIPCHK(c, hipMemcpyAsync(&flag, mismatch, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *confirmed = flag == 0;
+    return C3SC_OK;
 }
 
 /* wait for the iteration and bring back: cores (working layout G[a + r_k (j + N_k b)]), both families of index sets, and

@@ -674,6 +674,7 @@ struct cross {
     struct c3sc_hip_ctx *dev_pol; /* bellman_pi: context holding the policy's value function, or NULL (bellman_vi) */
     long long dev_tag;            /* bellman_pi: the policy iteration the policy memo belongs to */
     unsigned long long dev_requested; /* nodes of all fibers asked for */
+    int dev_confirm;                  /* try the one-launch confirming iteration (c3sc_hip_cross_confirm) */
     unsigned long long dev_nodes; /* nodes stored in the device memo during this interpolation (the reference's nnode_evals) */
 };
 
@@ -909,6 +910,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     c.d = d; c.N = N; c.grid = grid; c.f = f; c.fb = fb; c.fi = fi; c.args = args; c.verbose = verbose;
     c.warm = getenv("C3SC_COLD_PIVOTS") == NULL;
     if (getenv("C3SC_SWAP_TOL")) g_swap_tol = atof(getenv("C3SC_SWAP_TOL"));
+    c.dev_confirm = getenv("C3SC_NO_CONFIRM") == NULL;
     if (dev != NULL) { c.dev = dev->ctx; c.dev_pol = dev->pol; c.dev_tag = dev->tag; c.dev_box = dev->box; c.dev_fresh = 1; c.dev_new_sweep = 1; }
     c.r = xcalloc(d + 1, sizeof(size_t));
     c.r[0] = c.r[d] = 1;
@@ -941,8 +943,24 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
         for (size_t it = 0; it < maxiter; it++) {
             c.deficient = 0;
             int **Iold = copy_sets(&c, c.I, 0), **Jold = copy_sets(&c, c.J, 1);
-            struct tt *t2;
-            if (c.dev) t2 = cross_iteration_device(&c);
+            struct tt *t2 = NULL;
+            if (c.dev && it > 0 && !c.dev_fresh && c.dev_confirm) {
+                /* The previous iteration changed index sets; the next one usually changes nothing.  The device can establish that
+                 * in one launch -- all 2 d core steps side by side on the fiber values they already hold, comparing instead of
+                 * writing their index sets -- and, if so, has the iteration's cores in place: same kernels, same inputs, same
+                 * bits as the sequential iteration, which then need not run. */
+                int ok = 0;
+                if (c3sc_hip_cross_confirm(c.dev, &ok, NULL) != 0) DIE("c3sc_hip_cross_confirm: %s", c3sc_hip_last_error(c.dev));
+                if (ok) {
+                    t2 = tt_alloc(d, c.N, c.r);
+                    unsigned long long info[4] = {0, 0, 0, 0};
+                    if (c3sc_hip_cross_fetch(c.dev, t2->G, NULL, NULL, info, NULL) != 0) DIE("c3sc_hip_cross_fetch: %s", c3sc_hip_last_error(c.dev));
+                    if (info[1]) c.deficient = 1;
+                    for (size_t k = 0; k < d; k++) { c.nfibers += 2 * c.r[k] * c.r[k + 1]; c.dev_requested += 2 * c.r[k] * c.r[k + 1] * c.N[k]; }
+                }
+            }
+            if (t2 != NULL) { /* confirmed: sets unchanged by construction */ }
+            else if (c.dev) t2 = cross_iteration_device(&c);
             else {
                 struct tt *t1 = cross_sweep_lr(&c);
                 t2 = cross_sweep_rl(&c);

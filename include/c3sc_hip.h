@@ -217,6 +217,10 @@ int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32
  *   1 if a fiber matrix was numerically rank deficient, maxvol row swaps, 1 if the memo overflowed} */
 int c3sc_hip_cross_setup(c3sc_hip_ctx *ctx, const size_t *ranks, const int32_t *const *I, const int32_t *const *J, int new_sweep);
 int c3sc_hip_cross_iteration(c3sc_hip_ctx *ctx, int box, void *stream);
+/* after an iteration that changed index sets: the confirming iteration as ONE launch (all core steps side by side on the values
+ * they already hold, comparing instead of writing their index sets).  *confirmed = 1: the iteration that would follow changes
+ * nothing and its cores are in place -- fetch them; 0: run c3sc_hip_cross_iteration[_pi] as usual.  Synchronises the stream. */
+int c3sc_hip_cross_confirm(c3sc_hip_ctx *ctx, int *confirmed, void *stream);
 /* the same for bellman_pi (bellman.c:1702-1886): per core step the greedy policy of the value function uploaded to policy_ctx
  * (cached per node for the whole policy iteration policy_tag: the reference's prob table, bellman.c:1806, 1877), then its
  * evaluation on ctx's value function.  info[0] of the fetch then counts the nodes whose policy was computed (npol_evals). */

@@ -428,9 +428,18 @@ def main():
         idbytes = (C.c_char * 128).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
         comm = C.c_void_p()
         rc_comm = eng.L.c3sc_hip_comm_create(eng.h, C.c_int(world), C.c_int(rank), idbytes, C.byref(comm))
-        if rc_comm != 0:
-            raise SystemExit("c3sc_hip_comm_create: " + eng.L.c3sc_hip_last_error(eng.h).decode())
-        eng.L.c3sc_hip_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        # every rank must take the same route: agree on whether all communicators came up; if not, the process group's own
+        # all-gather (RCCL through torch.distributed) carries the sweep's collective instead
+        okt = torch.tensor([1 if rc_comm == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            if rc_comm == 0:
+                eng.L.c3sc_hip_comm_destroy(comm)
+            print("bench: c3sc_hip_comm_create failed on some rank (" + eng.L.c3sc_hip_last_error(eng.h).decode() + "); using torch.distributed's all-gather",
+                  file=sys.stderr, flush=True)
+            comm = None
+        else:
+            eng.L.c3sc_hip_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         full_t = torch.empty(shard0.numel() * world, dtype=torch.float64, device=dev)
 
     nodes_per_step_job = sum(F_job * w.ngrid[k] for k in range(d))
@@ -456,6 +465,9 @@ def main():
             rc = eng.L.c3sc_hip_comm_allgather(comm, C.c_void_p(mine.data_ptr()), C.c_void_p(full_t.data_ptr()), C.c_size_t(mine.numel()), C.c_void_p(sp))
             if rc != 0:
                 raise SystemExit("c3sc_hip_comm_allgather: " + eng.L.c3sc_hip_last_error(eng.h).decode())
+            gathered = full_t
+        elif use_dist:
+            dist.all_gather_into_tensor(full_t, (shard0 * (1.0 + 1e-12 * torch.tanh(probe))).contiguous())
             gathered = full_t
         else:
             gathered = shard0 * (1.0 + 1e-12 * torch.tanh(probe))

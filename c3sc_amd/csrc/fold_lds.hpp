@@ -129,4 +129,21 @@ __device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
     return s;
 }
 
+// neighbour values along the varying dim for node jn (nodeutil.c:570-624)
+__device__ inline void dimk_values(int jn, int N, int bck, double vL, double vC, double vR, double vwrap, double vone,
+                                   double &lo, double &hi)
+{
+    lo = vL;
+    hi = vR;
+    if (jn == 0) {
+        lo = (bck == C3SC_PERIODIC) ? vwrap : vC;
+        hi = (bck == C3SC_ABSORB) ? vC : vR;
+    }
+    if (jn == N - 1) {
+        lo = (bck == C3SC_ABSORB) ? vC : vL;
+        hi = (bck == C3SC_PERIODIC) ? vone : vC;
+        if (N == 1) lo = vC;
+    }
+}
+
 } // namespace c3sc

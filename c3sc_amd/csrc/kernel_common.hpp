@@ -1,6 +1,7 @@
 // kernel_common.hpp -- shared device code of the Bellman-backup kernels (gfx950, wave64).
 // Citations are relative to the reference tree (goroda/c3sc).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -673,68 +674,99 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     // factor of every candidate takes the polynomial and the per-candidate wave vote is not needed
     const bool all_small = __all(discl * h2l < 0.0078125 * Q0);
     const bool all_tiny = __all(discl * h2l < 0.0009765625 * Q0); // 2^-10: four terms are exact to an ulp
-    for (int c0 = 0; c0 < nc; c0 += CG) {
-        double val[CG];
-        bool ok[CG];
+    // ... and for the same reason Q_c >= Q0: when no lane's control-independent rates sum to less than 1e-14, no candidate can
+    // trip the stationary test (nodeutil.c:365-367) and the scan runs without it
+    const bool q0ok = __all(!(Q0 < 1e-14));
+    // The scan body is instantiated per (stationary test on/off, form of the discount factor) and the choice is made ONCE per
+    // node, outside the loop (all four conditions are wave-uniform): as run-time tests inside the body they cost every candidate a
+    // compare, two selects and ~8 scalar instructions and branches -- a quarter of a 33-candidate scan (lqg2d: 30 VALU and 13
+    // SALU instructions per candidate before, 26 and 5 after).
+    auto scan = [&](auto check_tag, auto exp_tag) __attribute__((always_inline)) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+        constexpr int EXPM = decltype(exp_tag)::value; // 0: four-term polynomial, 1: degree 7, 2: per-candidate vote (libm path possible)
+        for (int c0 = 0; c0 < nc; c0 += CG) {
+            double val[CG];
+            bool ok[CG];
 #pragma unroll
-        for (int q = 0; q < CG; q++) {
-            const int c = (c0 + q < nc) ? c0 + q : nc - 1;
-            double u[DU], cf[NCFa];
+            for (int q = 0; q < CG; q++) {
+                const int c = (CG == 1 || c0 + q < nc) ? c0 + q : nc - 1;
+                double u[DU], cf[NCFa];
 #pragma unroll
-            for (int i = 0; i < DU; i++) u[i] = cr.get_u(i, c);
-            cf[0] = 0.0;
+                for (int i = 0; i < DU; i++) u[i] = cr.get_u(i, c);
+                cf[0] = 0.0;
 #pragma unroll
-            for (int i = 0; i < Model::NCF; i++) cf[i] = cr.get_cf(i, c);
-            double b[D], s[D];
-            Model::drift(A.prm, nd, x, u, cf, b);
-            Model::sigma(A.prm, x, u, s);
-            double stage = stage0;
-            if constexpr (stage_usep<Model>()) stage = stage0 + cr.get_cf(0, c);
-            else if constexpr (Model::STAGE_UDEP) stage = Model::stage(A.prm, x, u);
-            double Q = Q0, PV = PV0;
-            constexpr unsigned UCg = Model::UCONST_MASK;
+                for (int i = 0; i < Model::NCF; i++) cf[i] = cr.get_cf(i, c);
+                double b[D], s[D];
+                Model::drift(A.prm, nd, x, u, cf, b);
+                Model::sigma(A.prm, x, u, s);
+                double stage = stage0;
+                if constexpr (stage_usep<Model>()) stage = stage0 + cr.get_cf(0, c);
+                else if constexpr (Model::STAGE_UDEP) stage = Model::stage(A.prm, x, u);
+                double Q = Q0, PV = PV0;
+                constexpr unsigned UCg = Model::UCONST_MASK;
 #pragma unroll
-            for (int m = 0; m < D; m++) {
-                if ((UM >> m) & 1u) {
-                    double pm, pp;
-                    if ((UCg >> m) & 1u) { // the rates of this dim are constants of the candidate (table built with the candidates)
-                        pm = cr.get_rpm(CandRegs<Model>::ucslot(m), c);
-                        pp = cr.get_rpp(CandRegs<Model>::ucslot(m), c);
+                for (int m = 0; m < D; m++) {
+                    if ((UM >> m) & 1u) {
+                        double pm, pp;
+                        if ((UCg >> m) & 1u) { // the rates of this dim are constants of the candidate (table built with the candidates)
+                            pm = cr.get_rpm(CandRegs<Model>::ucslot(m), c);
+                            pp = cr.get_rpp(CandRegs<Model>::ucslot(m), c);
+                        } else {
+                            const double half = t2l[m] * (s[m] * s[m]) / 2.0;
+                            // branch-free upwinding with the +-1e-14 dead zone of nodeutil.c:300-305
+                            const double tb = tl[m] * b[m];
+                            pm = (b[m] < -1e-14) ? half - tb : half;
+                            pp = (b[m] > 1e-14) ? half + tb : half;
+                        }
+                        if constexpr (UCg != UM) { // otherwise the sum of the candidate's rates is a table entry
+                            Q += pm;
+                            Q += pp;
+                        }
+                        PV = fma(pm, V[2 * m], PV);
+                        PV = fma(pp, V[2 * m + 1], PV);
+                    }
+                }
+                if constexpr (UCg == UM) Q = Q0 + cr.get_qab(c);
+                double Qs = Q;
+                ok[q] = true;
+                if constexpr (CHECK) {
+                    ok[q] = !(Q < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
+                    Qs = ok[q] ? Q : 1.0;
+                }
+                const double inv = rcp_newton(Qs);         // Q in [1e-14, ~1e8]: no scaling / fix-up needed, result within an ulp
+                const double dt = h2l * inv;               // nodeutil.c:369
+                const double pself = fma(-Qs, inv, 1.0);   // 1 - sum_i p_i/Q: rounding residue, as in the reference
+                const double ctg = fma(pself, V[2 * D], PV * inv);
+                const double xe = -discl * dt;
+                const double ebt = EXPM == 0 ? exp_tiny(xe) : (EXPM == 1 ? exp_small(xe) : exp_discount(xe)); // bellman.c:94
+                val[q] = dt * stage + ebt * ctg;                                 // bellman.c:97
+            }
+#pragma unroll
+            for (int q = 0; q < CG; q++) {
+                if (c0 + q < nc) {
+                    if constexpr (CHECK) anybad_g |= !ok[q];
+                    if (__builtin_constant_p(forced) && !forced && !CHECK) { // the minimising kernels' fast path: compare, min, one select
+                        ui = (val[q] < bestg) ? c0 + q : ui;
+                        // v_min_f64 by hand: fmin() canonicalises the loop-carried operand first (a v_max_f64 x, x per candidate)
+                        asm("v_min_f64 %0, %1, %2" : "=v"(bestg) : "v"(val[q]), "0"(bestg));
                     } else {
-                        const double half = t2l[m] * (s[m] * s[m]) / 2.0;
-                        // branch-free upwinding with the +-1e-14 dead zone of nodeutil.c:300-305
-                        const double tb = tl[m] * b[m];
-                        pm = (b[m] < -1e-14) ? half - tb : half;
-                        pp = (b[m] > 1e-14) ? half + tb : half;
+                        const bool take = ok[q] & (forced ? (c0 + q == fu) : (val[q] < bestg)); // +inf loses to the first candidate
+                        bestg = take ? val[q] : bestg;
+                        ui = take ? c0 + q : ui;
                     }
-                    if constexpr (UCg != UM) { // otherwise the sum of the candidate's rates is a table entry
-                        Q += pm;
-                        Q += pp;
-                    }
-                    PV = fma(pm, V[2 * m], PV);
-                    PV = fma(pp, V[2 * m + 1], PV);
                 }
             }
-            if constexpr (UCg == UM) Q = Q0 + cr.get_qab(c);
-            ok[q] = !(Q < 1e-14); // nodeutil.c:365-367 returns 1; bellman.c:452 asserts.  Skip + flag.
-            const double Qs = ok[q] ? Q : 1.0;
-            const double inv = rcp_newton(Qs);         // Q in [1e-14, ~1e8]: no scaling / fix-up needed, result within an ulp
-            const double dt = h2l * inv;               // nodeutil.c:369
-            const double pself = fma(-Qs, inv, 1.0);   // 1 - sum_i p_i/Q: rounding residue, as in the reference
-            const double ctg = fma(pself, V[2 * D], PV * inv);
-            const double ebt = (A.discount == 0.0) ? 1.0 : (all_tiny ? exp_tiny(-discl * dt) : (all_small ? exp_small(-discl * dt) : exp_discount(-discl * dt))); // bellman.c:94
-            val[q] = dt * stage + ebt * ctg;                                 // bellman.c:97
         }
-#pragma unroll
-        for (int q = 0; q < CG; q++) {
-            if (c0 + q < nc) {
-                anybad_g |= !ok[q];
-                const bool take = ok[q] & (forced ? (c0 + q == fu) : (val[q] < bestg)); // +inf loses to the first candidate
-                bestg = take ? val[q] : bestg;
-                ui = take ? c0 + q : ui;
-            }
-        }
-    }
+    };
+    typedef std::integral_constant<int, 0> E0;
+    typedef std::integral_constant<int, 1> E1;
+    typedef std::integral_constant<int, 2> E2;
+    if (q0ok) {
+        if (all_tiny) scan(std::false_type{}, E0{});
+        else if (all_small) scan(std::false_type{}, E1{});
+        else scan(std::false_type{}, E2{});
+    } else
+        scan(std::true_type{}, E2{});
     if (anybad_g & (ab == 0)) st |= C3SC_STATUS_STATIONARY;
     best = (ui >= 0) ? bestg : 0.0;
     best = (ab != 0) ? absorbed_cost : best;

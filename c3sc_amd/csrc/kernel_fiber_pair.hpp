@@ -122,23 +122,6 @@ __host__ __device__ constexpr int own_right_after(int m)
 template <int K>
 __host__ __device__ constexpr int gvec(int m, int s) { return (m < K ? 2 * m : 2 * (m - 1)) + s; }
 
-// neighbour values along the varying dim for node jn (nodeutil.c:570-624)
-__device__ inline void dimk_values(int jn, int N, int bck, double vL, double vC, double vR, double vwrap, double vone,
-                                   double &lo, double &hi)
-{
-    lo = vL;
-    hi = vR;
-    if (jn == 0) {
-        lo = (bck == C3SC_PERIODIC) ? vwrap : vC;
-        hi = (bck == C3SC_ABSORB) ? vC : vR;
-    }
-    if (jn == N - 1) {
-        lo = (bck == C3SC_ABSORB) ? vC : vL;
-        hi = (bck == C3SC_PERIODIC) ? vone : vC;
-        if (N == 1) lo = vC;
-    }
-}
-
 #define FPP_STAMP(slot)                                                   \
     if (C3SC_STAMPS_ON && (A.dbg & 128)) {                                \
         const unsigned long long now__ = clock64();                       \

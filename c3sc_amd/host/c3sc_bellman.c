@@ -1146,6 +1146,8 @@ void c3control_set_fiber_sharding(struct C3Control *c, size_t world, size_t rank
     c->shard_xarg = xarg;
 }
 
+int c3control_comm_unique_id(void *id128) { return c3sc_hip_comm_unique_id(id128); } /* so that a program links -lc3sc only */
+
 int c3control_shard_over_gpus(struct C3Control *c, size_t world, size_t rank, const void *id128)
 { /* new: one process per GPU of a node, all running the same solver; the fibers of every core step are split over the ranks and
      gathered with one RCCL all-gather (c3sc_hip_comm_*).  id128: the 128 bytes rank 0 got from
@@ -1364,6 +1366,7 @@ struct ValueF *c3control_step_pi(struct C3Control *c, struct ValueF *vf, struct 
         struct c3sc_hip_ctx *ctx_it = sync_device_ctx(cp, workspace_get_hip_ctx(cp->work), poli->vf_iteration);
         struct c3sc_hip_ctx *ctx_pol = sync_device_ctx(cp, workspace_get_hip_ctx_policy(cp->work), poli->vf_policy);
         size_t npol = 0, requested = 0;
+        c3sc_hip_cross_set_comm(ctx_it, NULL); /* a one-rank communicator left by c3control_step_vi: nothing to exchange here */
         next = c3sc_interp_device(c->dx, ctx_it, 0, c->ngrid, c->xgrid, vf, aa, verbose, &npol, ctx_pol, (long long)workspace_get_pi_iter(cp->work),
                                   &requested);
         poli->npol_evals += npol;

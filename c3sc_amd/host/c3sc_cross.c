@@ -385,8 +385,25 @@ C3SC_CLONES static void tt_round(struct tt *t, double eps)
         double *A = t->G[k]; /* m x n col-major */
         double *S, *V;
         if (m >= n) {
+            /* tall (the usual case, m = r N): thin QR first, then the SVD of the n x n factor -- the Jacobi rotations run over
+             * columns of length n instead of m (a third of rounding's time on car7d: 410 x 10 cores).  A = Q R, R = U_R S V^T
+             * => A = (Q U_R) S V^T; on exit A holds (Q U_R) diag(S) like svd_jacobi's own convention. */
             S = xcalloc(n, sizeof(double)); V = xcalloc(n * n, sizeof(double));
-            svd_jacobi(m, n, A, S, V);
+            double *R = xcalloc(n * n, sizeof(double)), *Q = xcalloc(m * n, sizeof(double));
+            memcpy(Q, A, m * n * sizeof(double));
+            qr_thin(m, n, Q, R);
+            svd_jacobi(n, n, R, S, V); /* R <- U_R diag(S) */
+            for (size_t j = 0; j < n; j++) {
+                double *aj = A + j * m;
+                for (size_t i = 0; i < m; i++) aj[i] = 0.0;
+                for (size_t q = 0; q < n; q++) {
+                    const double w = R[q + j * n];
+                    if (w == 0.0) continue;
+                    const double *qq = Q + q * m;
+                    for (size_t i = 0; i < m; i++) aj[i] += qq[i] * w;
+                }
+            }
+            free(R); free(Q);
         } else { /* wide: reduce with QR of A^T first is overkill here; pad rows with zeros */
             double *Ap = xcalloc(n * n, sizeof(double));
             for (size_t j = 0; j < n; j++) memcpy(Ap + j * n, A + j * m, m * sizeof(double));

@@ -4,12 +4,17 @@
  * value-iteration steps, save / reload, closed-loop simulation.  Own code; only the API names are the reference's.
  *
  *   cc -std=c99 -I include examples/lqg2d_pi.c -L c3sc_amd/host -lc3sc -lm -Wl,-rpath,$PWD/c3sc_amd/host -o lqg2d_pi
- *   ./lqg2d_pi [ngrid=60] [updates=5] [discount=0.1] [bruteforce|bfgs]
+ *   ./lqg2d_pi [ngrid=60] [updates=5] [discount=0.1] [bruteforce|bfgs] [shard]
+ *
+ * "shard": the multi-GPU set-up of a C main() -- c3control_comm_unique_id + c3control_shard_over_gpus -- with WORLD_SIZE / RANK from
+ * the environment (one process per GPU, device = C3SC_HIP_DEVICE; the 128-byte id travels through the file C3SC_COMM_ID_FILE).
+ * Without a launcher it is a one-rank communicator: the same RCCL code path (librccl opened at run time) on one GPU.
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "c3sc/c3sc.h"
 #include "c3sc_hip.h" /* C3SC_MODEL_LQGND */
@@ -50,6 +55,7 @@ int main(int argc, char **argv)
     size_t n = argc > 1 ? (size_t)atoi(argv[1]) : 60, updates = argc > 2 ? (size_t)atoi(argv[2]) : 5;
     double discount = argc > 3 ? atof(argv[3]) : 0.1;
     const int brute = !(argc > 4 && strcmp(argv[4], "bfgs") == 0);
+    const int shard = argc > 5 && strcmp(argv[5], "shard") == 0;
     size_t dx = 2, du = 1, dw = 2, ngrid[2] = {n, n};
     double lb[2] = {-2.0, -2.0}, ub[2] = {2.0, 2.0};
 
@@ -86,6 +92,22 @@ int main(int argc, char **argv)
     const double prm[3] = {2.0, 1.0, 1.0}; /* the one line a maintainer adds: which device functor restates the callbacks */
     c3control_set_device_model(c3c, C3SC_MODEL_LQGND, prm, 3);
 
+    if (shard) { /* one process per GPU: every rank runs this same program */
+        const char *ws = getenv("WORLD_SIZE"), *rk = getenv("RANK"), *idf = getenv("C3SC_COMM_ID_FILE");
+        const size_t world = ws ? (size_t)atoi(ws) : 1, rank = rk ? (size_t)atoi(rk) : 0;
+        char id[128];
+        if (rank == 0) {
+            if (c3control_comm_unique_id(id) != 0) { fprintf(stderr, "c3control_comm_unique_id failed\n"); return 1; }
+            if (world > 1 && idf) { FILE *fp = fopen(idf, "wb"); if (!fp || fwrite(id, 1, 128, fp) != 128) return 1; fclose(fp); }
+        } else {
+            FILE *fp = NULL;
+            for (int tries = 0; tries < 600 && (fp = fopen(idf ? idf : "", "rb")) == NULL; tries++) { struct timespec ts = {0, 50000000}; nanosleep(&ts, NULL); }
+            if (!fp || fread(id, 1, 128, fp) != 128) { fprintf(stderr, "rank %zu: no communicator id\n", rank); return 1; }
+            fclose(fp);
+        }
+        if (c3control_shard_over_gpus(c3c, world, rank, id) != 0) return 1;
+        printf("sharded over %zu rank(s) with the library's RCCL communicator\n", world);
+    }
     struct ValueF *cost = c3control_init_value(c3c, startcost, NULL, aargs, 0);
     struct Diag *diag = NULL;
     double diff = 0.0;

@@ -97,6 +97,7 @@ void c3control_set_fiber_sharding(struct C3Control *, size_t world, size_t rank,
 /* new: the same with the library's own RCCL communicator (c3sc_hip_comm_*): a C main() shards over the GPUs of a node without
  * writing an exchange function.  id128 = the bytes of c3sc_hip_comm_unique_id from rank 0.  Collective.  0 on success. */
 int c3control_shard_over_gpus(struct C3Control *, size_t world, size_t rank, const void *id128);
+int c3control_comm_unique_id(void *id128); /* rank 0: the 128 bytes every rank passes to c3control_shard_over_gpus */
 /* one value-iteration sweep's callback state, as c3control_step_vi builds it (bellman.c:2177-2199); the
  * cross approximation that consumes it (valuef_interp -> C3) is out of scope, so the caller drives the fibers */
 struct VIparam *c3control_begin_vi(struct C3Control *, struct ValueF *vf, struct c3Opt *opt);

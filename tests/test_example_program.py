@@ -47,3 +47,19 @@ def test_ref_bellman_pi3d_closed_loop_through_the_c_api(tmp_path):
     p = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     print(p.stdout[-1500:], p.stderr[-1500:])
     assert p.returncode == 0 and "BELLMAN_PI3D_OK" in p.stdout
+
+
+@pytest.mark.gpu
+def test_example_shards_with_the_c_communicator(tmp_path):
+    """The multi-GPU set-up of a plain C main() -- c3sc_hip_comm_unique_id + c3control_shard_over_gpus, librccl opened at run time,
+    no Python or torch in the process -- with a one-rank communicator on the box's GPU; the sharded solve must print the same
+    control updates as the unsharded one."""
+    exe = _build(tmp_path, "lqg2d_pi")
+    outs = []
+    for extra in ([], ["shard"]):
+        p = subprocess.run([exe, "40", "3", "6.0", "bruteforce"] + extra, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        print(p.stdout[-1200:], p.stderr[-1200:])
+        assert p.returncode == 0 and "LQG2D_PI_OK" in p.stdout
+        outs.append([ln for ln in p.stdout.splitlines() if ln.startswith("control update")])
+    assert "sharded over 1 rank(s)" in p.stdout
+    assert outs[0] == outs[1] and len(outs[0]) == 3

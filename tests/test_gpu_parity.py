@@ -108,6 +108,43 @@ def test_bellman_fibers_vs_oracle(oracle, name, kw, variant):
         _check(eng, P, w, k, idx)
 
 
+LANE = [("dubins3d", dict(ngrid=(21, 17, 16), rank=4)), ("dubins3d", dict(ngrid=(70, 66, 101), rank=6)), ("dubins3d", dict(ngrid=(33, 40, 37), rank=8)),
+        ("lqg2d", dict(ngrid=(51, 51), rank=4)), ("lqg2d", dict(ngrid=(128, 77), rank=3)), ("rossler3d", dict(ngrid=(23, 40, 31), rank=7)),
+        ("rossler3d", dict(ngrid=(20, 20, 20), rank=4))]
+
+
+@pytest.mark.parametrize("name,kw", LANE, ids=[f"{n}-r{k['rank']}-{i}" for i, (n, k) in enumerate(LANE)])
+def test_fiber_lane_kernel_vs_oracle(oracle, name, kw):
+    """The fiber-per-lane kernels (one wavefront per 64 fibers, low ranks; kernel_fiber_lane.hpp) against the oracle: ragged tiles,
+    boundary faces, the periodic wrap, every varying dimension.  Its policy-evaluation instantiation: applying the minimiser's
+    own argmin reproduces the (oracle-checked) minimum, and a random policy agrees with the per-wave kernel's evaluation
+    (itself held to the oracle by test_policy_evaluation_vs_oracle)."""
+    w = wl.WORKLOADS[name]().scaled(**kw)
+    cores = wl.synth_cores(w)
+    P = oracle.Problem(w, cores)
+    eng = _engine(w, cores, 2)
+    eng1 = _engine(w, cores, 1)
+    rng = np.random.default_rng(5)
+    for k in range(w.dx):
+        idx = wl.synth_fibers(w, k, 300)
+        idx[0, :] = 0
+        idx[1, :] = np.array(w.ngrid) - 1
+        idx[2, :] = 1
+        idx[:, k] = 0
+        _check(eng, P, w, k, idx)
+        assert "fiber_lane" in eng.last_kernel()
+        out, ui, ab = eng.bellman_fibers_host(k, idx)
+        scale = np.abs(out).max()
+        back, ab2 = eng.policy_fibers_host(k, idx, ui)
+        assert "fiber_lane" in eng.last_kernel()
+        np.testing.assert_array_equal(ab2, ab)
+        assert np.abs(back - out).max() <= REL_TOL * scale
+        pol = rng.integers(0, w.ncand, size=out.shape).astype(np.int32)
+        got, _ = eng.policy_fibers_host(k, idx, pol)
+        want, _ = eng1.policy_fibers_host(k, idx, pol)
+        assert np.abs(got - want).max() <= REL_TOL * scale
+
+
 FPL = [("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)), ("car7d", dict(ngrid=(11, 12, 9, 13, 10, 11, 12), rank=10))]
 
 

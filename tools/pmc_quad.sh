@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out
 W=${1:-quad10d}; TAG=${2:-r02_quad}; V=${3:-4}
 rm -rf $O/pq1 $O/pq2 $O/pq3
-A="--workload $W --fibers 131072 --variant $V --steps 2 --warmup 1 --no-cpu-baseline --no-solver"
+A="--workload $W --fibers ${FIBERS:-131072} --variant $V --steps 2 --warmup 1 --no-cpu-baseline --no-solver"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $O/pq1 -- python3 bench.py $A > /dev/null 2> $O/pq1.err; echo pq1 done
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $O/pq2 -- python3 bench.py $A > /dev/null 2> $O/pq2.err; echo pq2 done
 timeout -k 10 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_WAVES SQ_INSTS_MFMA --output-format csv -d $O/pq3 -- python3 bench.py $A > /dev/null 2> $O/pq3.err; echo pq3 done

@@ -129,6 +129,78 @@ __device__ inline double dot_reg(const double (&a)[RP], const double (&b)[RP])
     return s;
 }
 
+// ---- the same products with the lane's matrix read straight from the cores in global memory (L2-resident): low-dimensional
+// problems fold through at most d-2 matrices per fiber, and a staged copy of a whole core per 64 fibers costs more LDS (i.e.
+// occupancy) than the gathered reads cost time
+// v <- v G (ROWVEC: out[b] = sum_a v[a] G[a + b RP]) or v <- G v (out[a] = sum_b G[a + b RP] v[b]) for NV vectors, G read
+// from global memory in chunks of whole storage columns (RP contiguous doubles each)
+template <int RP, int NV, bool ROWVEC>
+__device__ __forceinline__ void apply_glb(const double *__restrict__ G, double (&v)[NV][RP])
+{
+    // 16-18 doubles of the matrix in registers at a time.  Left alone the compiler hoists every load of the fold (three matrices
+    // of a level, read through a const __restrict__ pointer: nothing orders them) above the first FMA and spills 200-500
+    // registers.  An empty asm cannot fence them either -- it does not receive the noalias pointer, so loads through it may
+    // cross it.  Instead the chunk's base pointer is laundered through a volatile asm (its loads depend on the asm's output)
+    // and the accumulators are pinned by volatile asms after the chunk's FMAs: volatile asms keep their order, so chunk c+1 is
+    // loaded after chunk c has been consumed.  The fold is short; other wavefronts cover its L2 round trips.
+    constexpr int CH = (RP <= 4) ? RP : (RP <= 6 ? 3 : 2);
+    double t[NV][RP];
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int i = 0; i < RP; i++) t[s][i] = 0.0;
+#pragma unroll
+    for (int b0 = 0; b0 < RP; b0 += CH) {
+        const double *Gc = G + b0 * RP;
+        asm volatile("" : "+v"(Gc));
+        double g[CH][RP];
+#pragma unroll
+        for (int b = 0; b < CH; b++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) g[b][a] = (b0 + b < RP) ? Gc[a + b * RP] : 0.0;
+#pragma unroll
+        for (int b = 0; b < CH; b++) {
+            if (b0 + b < RP) {
+#pragma unroll
+                for (int s = 0; s < NV; s++)
+#pragma unroll
+                    for (int a = 0; a < RP; a++) {
+                        if constexpr (ROWVEC) t[s][b0 + b] = fma(v[s][a], g[b][a], t[s][b0 + b]);
+                        else t[s][a] = fma(g[b][a], v[s][b0 + b], t[s][a]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int i = 0; i < RP; i++) pin(t[s][i]);
+    }
+#pragma unroll
+    for (int s = 0; s < NV; s++)
+#pragma unroll
+        for (int i = 0; i < RP; i++) v[s][i] = t[s][i];
+}
+
+// W[FIRST .. FIRST+COUNT) through G, at most two vectors per pass over the matrix
+template <int RP, int NW, int FIRST, int COUNT, bool ROWVEC>
+__device__ __forceinline__ void apply_range_glb(const double *__restrict__ G, double (&W)[NW][RP])
+{
+    if constexpr (COUNT > 0) {
+        constexpr int NV = COUNT >= 2 ? 2 : 1;
+        double tmp[NV][RP];
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) tmp[s][a] = W[FIRST + s][a];
+        apply_glb<RP, NV, ROWVEC>(G, tmp);
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+#pragma unroll
+            for (int a = 0; a < RP; a++) W[FIRST + s][a] = tmp[s][a];
+        apply_range_glb<RP, NW, FIRST + NV, COUNT - NV, ROWVEC>(G, W);
+    }
+}
+
 // neighbour values along the varying dim for node jn (nodeutil.c:570-624)
 __device__ inline void dimk_values(int jn, int N, int bck, double vL, double vC, double vR, double vwrap, double vone,
                                    double &lo, double &hi)

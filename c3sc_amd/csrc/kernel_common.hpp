@@ -501,7 +501,7 @@ __device__ inline double rcp_newton(double q)
 // (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)
 // neighbour in dim m, V[2D] = value at the node.  The candidate scan keeps the first minimum
 // (strict '<'), as the brute-force c3opt is assumed to.
-template <class Model, int CG = 1, int CGD = 1, class Cand = CandRegs<Model>>
+template <class Model, int CG = 1, int CGD = 1, class Cand = CandRegs<Model>, bool SPLIT = true>
 __device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
                                      const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1], const Cand &cr,
                                      const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st, bool forced = false,
@@ -576,6 +576,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         bool anybad = false;
         constexpr unsigned UCm = Model::UCONST_MASK;
         constexpr bool ALLC = (UCm == UM) && !Model::STAGE_UDEP && Model::NCF == 0; // nothing per candidate needs x
+        const double base0 = fma(h2l, stage0, PV0); // the candidate-independent part of every numerator (ALLC)
         // CGD candidates per trip: one candidate is a chain of ~10 dependent f64 operations and with two
         // wavefronts per SIMD nothing else covers their latency, so independent candidates are interleaved;
         // the selection below is straight-line (no short-circuit branches) and keeps the scan order.
@@ -596,7 +597,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
                         }
                     }
                     Q = Q0 + cr.get_qab(c);
-                    num = fma(h2l, stage0, PV0 + (PVa + PVb));
+                    num = base0 + (PVa + PVb);
                 } else {
                     double u[DU], cf[NCFa];
 #pragma unroll
@@ -657,7 +658,10 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
         }
         if (anybad & (ab == 0)) st |= C3SC_STATUS_STATIONARY;
         {
-            const double inv = 1.0 / bq;
+            // bq is a sum of rates in [1e-14, ~1e8] (or 1.0 when no candidate was valid): the hardware seed with two Newton steps
+            // is correctly rounded over 4M random samples (tools/probes/probe_rcp.hip) and 5 instructions against the IEEE
+            // sequence's 13
+            const double inv = rcp_newton(bq);
             const double pself = fma(-bq, inv, 1.0);
             best = (ui >= 0) ? fma(pself, V[2 * D], bnum * inv) : 0.0;
         }
@@ -683,7 +687,7 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     // SALU instructions per candidate before, 26 and 5 after).
     auto scan = [&](auto check_tag, auto exp_tag) __attribute__((always_inline)) {
         constexpr bool CHECK = decltype(check_tag)::value;
-        constexpr int EXPM = decltype(exp_tag)::value; // 0: four-term polynomial, 1: degree 7, 2: per-candidate vote (libm path possible)
+        constexpr int EXPM = decltype(exp_tag)::value; // 0: four-term polynomial, 1: degree 7, 2: per-candidate vote (libm path possible), 3: any of them, chosen here
         for (int c0 = 0; c0 < nc; c0 += CG) {
             double val[CG];
             bool ok[CG];
@@ -738,7 +742,8 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
                 const double pself = fma(-Qs, inv, 1.0);   // 1 - sum_i p_i/Q: rounding residue, as in the reference
                 const double ctg = fma(pself, V[2 * D], PV * inv);
                 const double xe = -discl * dt;
-                const double ebt = EXPM == 0 ? exp_tiny(xe) : (EXPM == 1 ? exp_small(xe) : exp_discount(xe)); // bellman.c:94
+                const double ebt = EXPM == 0 ? exp_tiny(xe) : (EXPM == 1 ? exp_small(xe) : (EXPM == 2 ? exp_discount(xe) : // bellman.c:94
+                                   (all_tiny ? exp_tiny(xe) : (all_small ? exp_small(xe) : exp_discount(xe)))));
                 val[q] = dt * stage + ebt * ctg;                                 // bellman.c:97
             }
 #pragma unroll
@@ -761,7 +766,11 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
     typedef std::integral_constant<int, 0> E0;
     typedef std::integral_constant<int, 1> E1;
     typedef std::integral_constant<int, 2> E2;
-    if (q0ok) {
+    typedef std::integral_constant<int, 3> E3; // the form is chosen inside the body (one copy of the scan)
+    // SPLIT = false: kernels at their register limit (the quad kernels) keep ONE scan body -- four copies of it perturb their
+    // allocation by 2-3 % even where the discounted branch never runs (scar4d), and their candidate lists are short
+    if constexpr (!SPLIT) scan(std::true_type{}, E3{});
+    else if (q0ok) {
         if (all_tiny) scan(std::false_type{}, E0{});
         else if (all_small) scan(std::false_type{}, E1{});
         else scan(std::false_type{}, E2{});

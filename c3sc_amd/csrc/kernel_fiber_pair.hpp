@@ -35,9 +35,19 @@
 #define FPP_NV 4 // vectors per pass over a staged matrix in the folding phase (2: 0.361 ms, 3: 0.343, 4: 0.340 on car7d)
 #endif
 
+#ifndef FPP_DIRECT_MAXD
+#define FPP_DIRECT_MAXD 3
+#endif
+
 namespace c3sc {
 
 constexpr int FPP_THREADS = 128;
+
+// Fold straight from the cores in global memory (fold_lds.hpp: apply_glb) instead of through a staged copy: a 3-D problem
+// folds through ONE matrix level at most, and the staged core (30 KB for dubins3d, per 64 fibers) is what holds its
+// workgroups at two wavefronts per SIMD -- without it the exchange rows are the LDS footprint (21 KB: three to four).
+template <class Model, int RP>
+__host__ __device__ constexpr bool fpp_direct() { return Model::D <= FPP_DIRECT_MAXD && RP <= 8; }
 
 // apply the staged matrix G to W[FIRST .. FIRST+COUNT) AND to one extra vector E in the same passes: every pass
 // re-reads the 100-element matrix of the lane's node from LDS, and LDS (gathered rows, ~2x bank conflicts) is the
@@ -143,6 +153,7 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
     constexpr int NOR = 2 * own_right_after<D, K, H>(K); // own right vectors (slots [NOL, NOL+NOR))
     constexpr int NOWN = (NOL + NOR) > 0 ? (NOL + NOR) : 1;
     constexpr int NP = NV + 1; // partial sums per node: NV neighbour values + the node value
+    constexpr bool DIRECT = fpp_direct<Model, RP>();
     static_assert(RP % 2 == 0, "rank-split kernel needs an even padded rank");
     const int lane = threadIdx.x & 63;
     const int N = A.N;
@@ -194,41 +205,63 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         if (!(C3SC_STAMPS_ON && (A.dbg & 1))) {
         if constexpr (K > 0) {
             {
-                constexpr int str = fpl_lds_stride(RP);
+                constexpr int str = DIRECT ? RP : fpl_lds_stride(RP);
+                const double *src = sK;
                 FPP_STAMP(1)
-                pair_barrier();
-                stage_core_image<H>(sK, A.img_base + A.pair_img_off[0], A.ngrid[0] * str);
-                pair_barrier();
+                if constexpr (DIRECT) src = ro + A.core_off[0];
+                else {
+                    pair_barrier();
+                    stage_core_image<H>(sK, A.img_base + A.pair_img_off[0], A.ngrid[0] * str);
+                    pair_barrier();
+                }
                 FPP_STAMP(7)
 #pragma unroll
                 for (int b = 0; b < RP; b++) {
-                    L[b] = sK[fi[0] * str + b];
+                    L[b] = src[fi[0] * str + b];
                     if constexpr (pair_owner<K>(0) == H) {
-                        W[0][b] = sK[nbm[0] * str + b];
-                        W[1][b] = sK[nbp[0] * str + b];
+                        W[0][b] = src[nbm[0] * str + b];
+                        W[1][b] = src[nbp[0] * str + b];
                     }
                 }
             }
             auto left_step = [&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value;
-                constexpr int str = fpl_lds_stride(RP * RP);
+                constexpr int str = DIRECT ? RP * RP : fpl_lds_stride(RP * RP);
                 constexpr int before = 2 * own_left_before<D, K, H>(m); // own vectors created so far
+                const double *src = sK;
                 FPP_STAMP(1)
-                pair_barrier();
-                stage_core_image<H>(sK, A.img_base + A.pair_img_off[m], A.ngrid[m] * str);
-                pair_barrier();
+                if constexpr (DIRECT) src = ro + A.core_off[m];
+                else {
+                    pair_barrier();
+                    stage_core_image<H>(sK, A.img_base + A.pair_img_off[m], A.ngrid[m] * str);
+                    pair_barrier();
+                }
                 FPP_STAMP(7)
-                const double *G = sK + fi[m] * str;
+                const double *G = src + fi[m] * str;
                 if constexpr (pair_owner<K>(m) == H) { // the new pair first: it needs the prefix BEFORE this core
                     double t0[1][RP], t1[1][RP];
 #pragma unroll
                     for (int a = 0; a < RP; a++) { t0[0][a] = L[a]; t1[0][a] = L[a]; }
-                    vecmat_lds<RP, 1>(sK + nbm[m] * str, t0);
-                    vecmat_lds<RP, 1>(sK + nbp[m] * str, t1);
+                    if constexpr (DIRECT) {
+                        apply_glb<RP, 1, true>(src + nbm[m] * str, t0);
+                        apply_glb<RP, 1, true>(src + nbp[m] * str, t1);
+                    } else {
+                        vecmat_lds<RP, 1>(src + nbm[m] * str, t0);
+                        vecmat_lds<RP, 1>(src + nbp[m] * str, t1);
+                    }
 #pragma unroll
                     for (int a = 0; a < RP; a++) { W[before][a] = t0[0][a]; W[before + 1][a] = t1[0][a]; }
                 }
-                apply_core_and<RP, NOWN, 0, before, true>(G, W, L);
+                if constexpr (DIRECT) {
+                    double tl[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) tl[0][a] = L[a];
+                    apply_glb<RP, 1, true>(G, tl);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) L[a] = tl[0][a];
+                    apply_range_glb<RP, NOWN, 0, before, true>(G, W);
+                } else
+                    apply_core_and<RP, NOWN, 0, before, true>(G, W, L);
             };
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (left_step(std::integral_constant<int, Ms + 1>{}), ...); }
             (std::make_integer_sequence<int, (K > 1 ? K - 1 : 0)>{});
@@ -237,41 +270,63 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         // ------------------------------------------------------------ fold the suffix side
         if constexpr (K < D - 1) {
             {
-                constexpr int str = fpl_lds_stride(RP);
+                constexpr int str = DIRECT ? RP : fpl_lds_stride(RP);
+                const double *src = sK;
                 FPP_STAMP(1)
-                pair_barrier();
-                stage_core_image<H>(sK, A.img_base + A.pair_img_off[D - 1], A.ngrid[D - 1] * str);
-                pair_barrier();
+                if constexpr (DIRECT) src = ro + A.core_off[D - 1];
+                else {
+                    pair_barrier();
+                    stage_core_image<H>(sK, A.img_base + A.pair_img_off[D - 1], A.ngrid[D - 1] * str);
+                    pair_barrier();
+                }
                 FPP_STAMP(7)
 #pragma unroll
                 for (int a = 0; a < RP; a++) {
-                    R[a] = sK[fi[D - 1] * str + a];
+                    R[a] = src[fi[D - 1] * str + a];
                     if constexpr (pair_owner<K>(D - 1) == H) {
-                        W[NOL][a] = sK[nbm[D - 1] * str + a];
-                        W[NOL + 1][a] = sK[nbp[D - 1] * str + a];
+                        W[NOL][a] = src[nbm[D - 1] * str + a];
+                        W[NOL + 1][a] = src[nbp[D - 1] * str + a];
                     }
                 }
             }
             auto right_step = [&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value; // D-2 down to K+1
-                constexpr int str = fpl_lds_stride(RP * RP);
+                constexpr int str = DIRECT ? RP * RP : fpl_lds_stride(RP * RP);
                 constexpr int after = 2 * own_right_after<D, K, H>(m);
+                const double *src = sK;
                 FPP_STAMP(1)
-                pair_barrier();
-                stage_core_image<H>(sK, A.img_base + A.pair_img_off[m], A.ngrid[m] * str);
-                pair_barrier();
+                if constexpr (DIRECT) src = ro + A.core_off[m];
+                else {
+                    pair_barrier();
+                    stage_core_image<H>(sK, A.img_base + A.pair_img_off[m], A.ngrid[m] * str);
+                    pair_barrier();
+                }
                 FPP_STAMP(7)
-                const double *G = sK + fi[m] * str;
+                const double *G = src + fi[m] * str;
                 if constexpr (pair_owner<K>(m) == H) {
                     double t0[1][RP], t1[1][RP];
 #pragma unroll
                     for (int a = 0; a < RP; a++) { t0[0][a] = R[a]; t1[0][a] = R[a]; }
-                    matvec_lds<RP, 1>(sK + nbm[m] * str, t0);
-                    matvec_lds<RP, 1>(sK + nbp[m] * str, t1);
+                    if constexpr (DIRECT) {
+                        apply_glb<RP, 1, false>(src + nbm[m] * str, t0);
+                        apply_glb<RP, 1, false>(src + nbp[m] * str, t1);
+                    } else {
+                        matvec_lds<RP, 1>(src + nbm[m] * str, t0);
+                        matvec_lds<RP, 1>(src + nbp[m] * str, t1);
+                    }
 #pragma unroll
                     for (int a = 0; a < RP; a++) { W[NOL + after][a] = t0[0][a]; W[NOL + after + 1][a] = t1[0][a]; }
                 }
-                apply_core_and<RP, NOWN, NOL, after, false>(G, W, R);
+                if constexpr (DIRECT) {
+                    double tr[1][RP];
+#pragma unroll
+                    for (int a = 0; a < RP; a++) tr[0][a] = R[a];
+                    apply_glb<RP, 1, false>(G, tr);
+#pragma unroll
+                    for (int a = 0; a < RP; a++) R[a] = tr[0][a];
+                    apply_range_glb<RP, NOWN, NOL, after, false>(G, W);
+                } else
+                    apply_core_and<RP, NOWN, NOL, after, false>(G, W, R);
             };
             [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (right_step(std::integral_constant<int, D - 2 - Ms>{}), ...); }
             (std::make_integer_sequence<int, (D - 2 - K > 0 ? D - 2 - K : 0)>{});

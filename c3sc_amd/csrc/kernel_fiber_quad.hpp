@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64 * NWV, 1)
             int ui = 0;
             const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
             double val = V[0] + V[2 * D - 1];
-            if (!(A.dbg & 1024)) val = node_backup<Model, 1, 1, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+            if (!(A.dbg & 1024)) val = node_backup<Model, 1, 1, CandLds<Model>, false>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
             if (nlive && flive) {
                 outv[(size_t)f * N + j] = val;
                 if (uidx) uidx[(size_t)f * N + j] = ui;
@@ -889,7 +889,7 @@ __device__ __attribute__((always_inline)) inline void quad_duo_body(const KArgs 
             int ui = 0;
             const int fu = forced ? A.forced[(size_t)f * N + j] : -1;
             double val = V[0] + V[2 * D - 1];
-            if (!(A.dbg & 1024)) val = node_backup<Model, FQD_CG, FQD_CG, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
+            if (!(A.dbg & 1024)) val = node_backup<Model, FQD_CG, FQD_CG, CandLds<Model>, false>(A, ro, x, tv, cr, V, ab, ui, st, forced, fu);
             if (nlive && flive) {
                 outv[(size_t)f * N + j] = val;
                 if (uidx) uidx[(size_t)f * N + j] = ui;

@@ -16,7 +16,7 @@ hipError_t launch_fpp_impl(const KArgs &A, const LaunchIO &io)
     const size_t exch = (size_t)(2 * RP + (NP + 1) * 2 + 2 * NP) * 64; // L, R rows + exchange rows
     if (exch > doubles) doubles = exch;
     for (int m = 0; m < D; m++) {
-        if (m == K) continue;
+        if (m == K || fpp_direct<Model, RP>()) continue; // no staged core when the fold reads the cores directly
         const int elems = (m == 0 || m == D - 1) ? RP : RP * RP;
         const size_t need = ((size_t)A.ngrid[m] * fpl_lds_stride(elems) + 1) & ~(size_t)1; // whole 16-byte LDS-DMA pieces
         if (need > doubles) doubles = need;

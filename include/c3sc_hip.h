@@ -68,7 +68,7 @@ enum {
 };
 
 /* kernel variants (c3sc_hip_set_variant); 0 lets the library choose.  Set the variant BEFORE uploading the value: the padded
- * rank of the device copy follows it (the quad kernel wants multiples of 4).  2 (one wavefront per 64 fibers) was retired.
+ * rank of the device copy follows it (the quad kernel wants multiples of 4).  2 (one wavefront per 64 fibers) was retired (twice: DESIGN.md 4.5).
  * FIBER_QUAD covers both forms of that kernel (one or two wavefronts per 16 fibers).  Within a variant -- and across variants
  * under AUTO -- an instantiation whose LDS layout does not hold the grid declines and the next one of the same padded rank
  * runs; C3SC_ERR_UNSUPPORTED comes back only when none fits. */

@@ -114,15 +114,15 @@ LANE = [("dubins3d", dict(ngrid=(21, 17, 16), rank=4)), ("dubins3d", dict(ngrid=
 
 
 @pytest.mark.parametrize("name,kw", LANE, ids=[f"{n}-r{k['rank']}-{i}" for i, (n, k) in enumerate(LANE)])
-def test_fiber_lane_kernel_vs_oracle(oracle, name, kw):
-    """The fiber-per-lane kernels (one wavefront per 64 fibers, low ranks; kernel_fiber_lane.hpp) against the oracle: ragged tiles,
-    boundary faces, the periodic wrap, every varying dimension.  Its policy-evaluation instantiation: applying the minimiser's
-    own argmin reproduces the (oracle-checked) minimum, and a random policy agrees with the per-wave kernel's evaluation
-    (itself held to the oracle by test_policy_evaluation_vs_oracle)."""
+def test_direct_fold_pair_kernels_vs_oracle(oracle, name, kw):
+    """The pair kernels of the 2-D / 3-D models fold straight from the cores in global memory (kernel_fiber_pair.hpp: fpp_direct,
+    no staged copy): ragged tiles, boundary faces, the periodic wrap, every varying dimension, ranks 4 / 6 / 8 against the oracle.
+    Their policy-evaluation instantiation: applying the minimiser's own argmin reproduces the (oracle-checked) minimum, and a
+    random policy agrees with the per-wave kernel's evaluation (itself held to the oracle by test_policy_evaluation_vs_oracle)."""
     w = wl.WORKLOADS[name]().scaled(**kw)
     cores = wl.synth_cores(w)
     P = oracle.Problem(w, cores)
-    eng = _engine(w, cores, 2)
+    eng = _engine(w, cores, 3)
     eng1 = _engine(w, cores, 1)
     rng = np.random.default_rng(5)
     for k in range(w.dx):
@@ -132,11 +132,11 @@ def test_fiber_lane_kernel_vs_oracle(oracle, name, kw):
         idx[2, :] = 1
         idx[:, k] = 0
         _check(eng, P, w, k, idx)
-        assert "fiber_lane" in eng.last_kernel()
+        assert "fiber_pair" in eng.last_kernel()
         out, ui, ab = eng.bellman_fibers_host(k, idx)
         scale = np.abs(out).max()
         back, ab2 = eng.policy_fibers_host(k, idx, ui)
-        assert "fiber_lane" in eng.last_kernel()
+        assert "fiber_pair" in eng.last_kernel()
         np.testing.assert_array_equal(ab2, ab)
         assert np.abs(back - out).max() <= REL_TOL * scale
         pol = rng.integers(0, w.ncand, size=out.shape).astype(np.int32)

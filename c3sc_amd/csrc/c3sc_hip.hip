@@ -347,6 +347,8 @@ int c3sc_hip_set_consistent_ends(c3sc_hip_ctx *c, int on)
     return C3SC_OK;
 }
 
+int c3sc_hip_get_consistent_ends(const c3sc_hip_ctx *c) { return c ? c->cends : -1; }
+
 int c3sc_hip_set_mca(c3sc_hip_ctx *c, double h2, const double *t, double discount)
 {
     if (!c || c->d == 0 || !t) return fail(c, C3SC_ERR_ARG, "set_mca: set_grid first");

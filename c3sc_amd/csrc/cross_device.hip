@@ -491,7 +491,7 @@ struct c3sc_cross_dev {
     } vmemo, pmemo;
     // per core step k: its fiber list and values stay on the device so that a step asked for the same list again in the same
     // generation is not recomputed (k_cross_idx / write_list_and_flag)
-    size_t offIdx[MAXD] = {0}, offOut[MAXD] = {0}, off_flags = 0, off_steps = 0;
+    size_t offIdx[MAXD] = {0}, offOut[MAXD] = {0}, off_flags = 0, off_steps = 0, work_stride = 0;
     unsigned long long gen = 0;
     long long policy_tag = -1; // the caller's policy-iteration counter the policy memo belongs to
     size_t off_uidx = 0;       // [Fmax][Nmax] candidate indices between the policy pass and the evaluation pass
@@ -603,7 +603,10 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     }
     x->off_flags = off; off += up256(MAXD * (sizeof(int) + sizeof(unsigned long long)) + 64);
     x->off_steps = off; off += up256(2 * MAXD * sizeof(CoreArgs) + 64);
-    x->off_work = off; off += up256(wmax * sizeof(double));
+    // scratch of a factorisation that does not fit LDS: one block per core step of an iteration (the batched confirmation runs all
+    // 2 d steps side by side; the sequential iteration uses the first block)
+    x->work_stride = up256(wmax * sizeof(double));
+    x->off_work = off; off += 2 * (size_t)d * x->work_stride;
     x->off_uidx = off; off += up256(fmax * nmax * sizeof(int32_t));
     if (off > x->slab_bytes) {
         if (x->slab) HIPCHK(c, hipFree(x->slab));
@@ -668,6 +671,91 @@ int c3sc_hip_cross_options(c3sc_hip_ctx *c, int warm_pivots, double swap_tol)
  * pol != null: bellman_pi's -- per core step the greedy policy of pol's value function (policy memo, first entry stays for
  * the whole policy iteration `policy_tag`), then the evaluation of that policy on c's value function (no value memo: the
  * reference's is never hit). */
+// the policy memo of policy iteration `policy_tag` (first entry stays for the whole policy iteration)
+static int prepare_policy_memo(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long policy_tag, int box)
+{
+    c3sc_cross_dev *x = c->cross;
+    const int d = x->d;
+    if (box) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: candidate lists only");
+    if (pol->d != d) return fail(c, C3SC_ERR_ARG, "cross_iteration_pi: the policy context has another grid");
+    size_t nodes = 0;
+    for (int k = 0; k < d; k++) nodes += (size_t)x->r[k] * x->r[k + 1] * x->N[k];
+    size_t want = 1 << 16;
+    while (want < 256 * nodes) want <<= 1; // a policy iteration runs ~10 evaluation sweeps over one policy memo
+    const bool fresh = policy_tag != x->policy_tag || x->pmemo.epoch == 0;
+    int rc = memo_ensure(c, x->pmemo, want, !fresh);
+    if (rc != C3SC_OK) return rc;
+    if (fresh) { rc = memo_new_epoch(c, x->pmemo); if (rc != C3SC_OK) return rc; x->policy_tag = policy_tag; }
+    return C3SC_OK;
+}
+
+// The fibers of core step k from its current list (x->offIdx[k]) into the step's block (x->offOut[k]), memo applied: bellman_vi's
+// (pol == null, value memo) or bellman_pi's (greedy policy of pol's value function through the policy memo, then its evaluation
+// on c's value function).  Sharded contexts evaluate their block of rows and all-gather in place.
+static int step_fibers(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, int box, int k, void *stream)
+{
+    c3sc_cross_dev *x = c->cross;
+    const int d = x->d;
+    hipStream_t st = (hipStream_t)stream;
+    c3sc_hip_comm *comm = c->shard_comm;
+    const int world = comm ? c3sc_hip_comm_world(comm) : 1, rank = comm ? c3sc_hip_comm_rank(comm) : 0;
+    c3sc_cross_dev::MemoTab &mt = pol ? x->pmemo : x->vmemo;
+    const int shift = memo_shift_of(mt.cap);
+    int32_t *uidx = (int32_t *)(x->slab + x->off_uidx);
+    int *skipf = (int *)(x->slab + x->off_flags);
+    const int r0 = x->r[k], r1 = x->r[k + 1], N = x->N[k];
+    const size_t F = (size_t)r0 * r1;
+    const long total = (long)F * N;
+    int32_t *idx = (int32_t *)(x->slab + x->offIdx[k]);
+    double *out = (double *)(x->slab + x->offOut[k]);
+    // a step that already holds the values of this very list (flag written by the kernel that made the list) is not recomputed
+    c->skip_flag = comm ? nullptr : skipf + k;
+    if (pol) pol->skip_flag = c->skip_flag;
+    // the fiber-per-wave kernel applies the memo in its epilogue (ctx->memo); any other kernel is followed by the memo pass
+    c3sc_hip_ctx *mc = pol ? pol : c; // the context whose launch carries the memo
+    mc->memo.keys = mt.keys; mc->memo.vals = mt.vals; mc->memo.capmask = (unsigned long long)(mt.cap - 1); mc->memo.shift = shift;
+    mc->memo.epoch_bits = (unsigned long long)mt.epoch << 49; mc->memo.counters = x->counters; mc->memo.mode = pol ? 1 : 0;
+    for (int m = 0; m < d; m++) mc->memo.stride[m] = x->strides.s[m];
+    mc->memo.applied = false;
+    int rc;
+    if (comm) { // sharded: this rank's block of rows, then the all-gather in place; the memo pass runs on the full array,
+                // in the same order on every rank, so that all ranks keep identical memos and take identical decisions
+        const size_t per = (F + world - 1) / world, lo = std::min(F, (size_t)rank * per), hi = std::min(F, lo + per);
+        mc->memo.keys = nullptr;
+        rc = C3SC_OK;
+        if (hi > lo)
+            rc = box ? c3sc_hip_bellman_fibers_box(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream)
+                     : c3sc_hip_bellman_fibers(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream);
+        if (rc == C3SC_OK) rc = c3sc_hip_comm_allgather(comm, out + (size_t)rank * per * N, out, per * N, stream);
+    } else if (pol) rc = c3sc_hip_bellman_fibers(pol, k, F, idx, out, uidx, nullptr, stream); // values unused: the policy is the output
+    else rc = box ? c3sc_hip_bellman_fibers_box(c, k, F, idx, out, nullptr, nullptr, stream)
+                  : c3sc_hip_bellman_fibers(c, k, F, idx, out, nullptr, nullptr, stream);
+    mc->memo.keys = nullptr;
+    if (pol) pol->skip_flag = nullptr;
+    if (rc != C3SC_OK) { c->skip_flag = nullptr; if (pol) c->err = pol->err; return rc; }
+    if (pol) {
+        if (!mc->memo.applied) { c->skip_flag = nullptr; return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: the policy pass needs the fiber-per-wave kernel"); }
+        rc = c3sc_hip_policy_fibers(c, k, F, idx, uidx, out, nullptr, stream);
+        c->skip_flag = nullptr;
+        if (rc != C3SC_OK) return rc;
+    } else if (!mc->memo.applied)
+        hipLaunchKernelGGL(k_cross_memo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, idx, out, total, N, d, k, x->strides, mt.keys,
+                           mt.vals, (unsigned long long)(mt.cap - 1), shift, (unsigned long long)mt.epoch << 49, x->counters);
+    c->skip_flag = nullptr;
+    return C3SC_OK;
+}
+
+static NextList next_list(c3sc_cross_dev *x, int k, bool enable)
+{
+    int *skipf = (int *)(x->slab + x->off_flags);
+    unsigned long long *tags = (unsigned long long *)(x->slab + x->off_flags + 64);
+    NextList L;
+    L.idx = (int32_t *)(x->slab + x->offIdx[k]); L.I = (int32_t *)(x->slab + x->offI[k]); L.J = (int32_t *)(x->slab + x->offJ[k]);
+    L.r0 = x->r[k]; L.r1 = x->r[k + 1]; L.k = k; L.d = x->d;
+    L.skip = skipf + k; L.tag = tags + k; L.gen = x->gen; L.enable = enable ? 1 : 0;
+    return L;
+}
+
 static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long policy_tag, int box, void *stream)
 {
     if (!c || !c->cross || c->cross->d == 0) return fail(c, C3SC_ERR_ARG, "cross_iteration: cross_setup first");
@@ -675,78 +763,26 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
     const int d = x->d;
     hipStream_t st = (hipStream_t)stream;
     c3sc_hip_comm *comm = c->shard_comm;
-    const int world = comm ? c3sc_hip_comm_world(comm) : 1, rank = comm ? c3sc_hip_comm_rank(comm) : 0;
+    const int world = comm ? c3sc_hip_comm_world(comm) : 1;
     if (comm && pol) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: not sharded (use the host-driven driver)");
     if (world > 64) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration: up to 64 ranks");
     if (pol) {
-        if (box) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: candidate lists only");
-        if (pol->d != d) return fail(c, C3SC_ERR_ARG, "cross_iteration_pi: the policy context has another grid");
-        size_t nodes = 0;
-        for (int k = 0; k < d; k++) nodes += (size_t)x->r[k] * x->r[k + 1] * x->N[k];
-        size_t want = 1 << 16;
-        while (want < 256 * nodes) want <<= 1; // a policy iteration runs ~10 evaluation sweeps over one policy memo
-        const bool fresh = policy_tag != x->policy_tag || x->pmemo.epoch == 0;
-        int rc = memo_ensure(c, x->pmemo, want, !fresh);
+        const int rc = prepare_policy_memo(c, pol, policy_tag, box);
         if (rc != C3SC_OK) return rc;
-        if (fresh) { rc = memo_new_epoch(c, x->pmemo); if (rc != C3SC_OK) return rc; x->policy_tag = policy_tag; }
     }
-    c3sc_cross_dev::MemoTab &mt = pol ? x->pmemo : x->vmemo;
-    const int shift = memo_shift_of(mt.cap);
-    int32_t *uidx = (int32_t *)(x->slab + x->off_uidx);
     auto setI = [&](int k) { return (int32_t *)(x->slab + x->offI[k]); };
     auto setJ = [&](int k) { return (int32_t *)(x->slab + x->offJ[k]); };
-    auto listOf = [&](int k) { return (int32_t *)(x->slab + x->offIdx[k]); };
     auto outOf = [&](int k) { return (double *)(x->slab + x->offOut[k]); };
-    int *skipf = (int *)(x->slab + x->off_flags);
-    unsigned long long *tags = (unsigned long long *)(x->slab + x->off_flags + 64);
-    auto nextList = [&](int k) {
-        NextList L;
-        L.idx = listOf(k); L.I = setI(k); L.J = setJ(k); L.r0 = x->r[k]; L.r1 = x->r[k + 1]; L.k = k; L.d = d;
-        L.skip = skipf + k; L.tag = tags + k; L.gen = x->gen; L.enable = comm ? 0 : 1;
-        return L;
-    };
+    auto nextList = [&](int k) { return next_list(x, k, comm == nullptr); };
     // the first step's fiber list; every later one is written by the core step before it
     hipLaunchKernelGGL(k_cross_idx, dim3(1), dim3(256), 0, st, nextList(0));
     for (int s = 0; s < 2 * d; s++) {
         const int half = s / d, k = half == 0 ? s : 2 * d - 1 - s;
         const int r0 = x->r[k], r1 = x->r[k + 1], N = x->N[k];
         const size_t F = (size_t)r0 * r1;
-        const long total = (long)F * N;
-        int32_t *idx = listOf(k);
         double *out = outOf(k);
-        // a step that already holds the values of this very list (flag written by the kernel that made the list) is not recomputed
-        c->skip_flag = comm ? nullptr : skipf + k;
-        if (pol) pol->skip_flag = c->skip_flag;
-        // the fiber-per-wave kernel applies the memo in its epilogue (ctx->memo); any other kernel is followed by the memo pass
-        c3sc_hip_ctx *mc = pol ? pol : c; // the context whose launch carries the memo
-        mc->memo.keys = mt.keys; mc->memo.vals = mt.vals; mc->memo.capmask = (unsigned long long)(mt.cap - 1); mc->memo.shift = shift;
-        mc->memo.epoch_bits = (unsigned long long)mt.epoch << 49; mc->memo.counters = x->counters; mc->memo.mode = pol ? 1 : 0;
-        for (int m = 0; m < d; m++) mc->memo.stride[m] = x->strides.s[m];
-        mc->memo.applied = false;
-        int rc;
-        if (comm) { // sharded: this rank's block of rows, then the all-gather in place; the memo pass runs on the full array,
-                    // in the same order on every rank, so that all ranks keep identical memos and take identical decisions
-            const size_t per = (F + world - 1) / world, lo = std::min(F, (size_t)rank * per), hi = std::min(F, lo + per);
-            mc->memo.keys = nullptr;
-            rc = C3SC_OK;
-            if (hi > lo)
-                rc = box ? c3sc_hip_bellman_fibers_box(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream)
-                         : c3sc_hip_bellman_fibers(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream);
-            if (rc == C3SC_OK) rc = c3sc_hip_comm_allgather(comm, out + (size_t)rank * per * N, out, per * N, stream);
-        } else if (pol) rc = c3sc_hip_bellman_fibers(pol, k, F, idx, out, uidx, nullptr, stream); // values unused: the policy is the output
-        else rc = box ? c3sc_hip_bellman_fibers_box(c, k, F, idx, out, nullptr, nullptr, stream)
-                      : c3sc_hip_bellman_fibers(c, k, F, idx, out, nullptr, nullptr, stream);
-        mc->memo.keys = nullptr;
-        if (pol) pol->skip_flag = nullptr;
-        if (rc != C3SC_OK) { c->skip_flag = nullptr; if (pol) c->err = pol->err; return rc; }
-        if (pol) {
-            if (!mc->memo.applied) { c->skip_flag = nullptr; return fail(c, C3SC_ERR_UNSUPPORTED, "cross_iteration_pi: the policy pass needs the fiber-per-wave kernel"); }
-            rc = c3sc_hip_policy_fibers(c, k, F, idx, uidx, out, nullptr, stream);
-            c->skip_flag = nullptr;
-            if (rc != C3SC_OK) return rc;
-        } else if (!mc->memo.applied)
-            hipLaunchKernelGGL(k_cross_memo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, idx, out, total, N, d, k, x->strides, mt.keys,
-                               mt.vals, (unsigned long long)(mt.cap - 1), shift, (unsigned long long)mt.epoch << 49, x->counters);
+        const int rc = step_fibers(c, pol, box, k, stream);
+        if (rc != C3SC_OK) return rc;
         CoreArgs P;
         P.out = out; P.r0 = r0; P.N = N; P.r1 = r1; P.k = k; P.d = d;
         P.dir = half;
@@ -758,7 +794,6 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         P.counters = x->counters;
         P.warm = x->warm;
         P.swap_tol = x->swap_tol;
-        c->skip_flag = nullptr;
         P.confirm = 0; P.mismatch = nullptr;
         std::memset(&P.next, 0, sizeof(P.next));
         if (s + 1 < 2 * d) {
@@ -806,7 +841,7 @@ int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
         P.set_in = (int32_t *)(x->slab + (half == 0 ? x->offI[k] : x->offJ[k]));
         P.set_out = P.copy_only ? nullptr : (int32_t *)(x->slab + (half == 0 ? x->offI[k + 1] : x->offJ[k - 1]));
         P.G = (double *)(x->slab + x->offG[k]);
-        P.work = nullptr;
+        P.work = (double *)(x->slab + x->off_work + (size_t)s * x->work_stride); // used when a step does not fit LDS
         P.counters = x->counters;
         P.warm = x->warm;
         P.swap_tol = x->swap_tol;
@@ -814,16 +849,49 @@ int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
         P.mismatch = mismatch;
         if (!P.copy_only) maxmn = std::max(maxmn, (size_t)P.r0 * P.r1 * P.N * sizeof(double));
     }
-    if (maxmn > LDS_CAP_BYTES) return C3SC_OK; // a step does not fit LDS: no batched confirmation, the ordinary iteration runs
     HIPCHK(c, hipMemsetAsync(mismatch, 0, sizeof(int), st));
     HIPCHK(c, hipMemcpyAsync(x->slab + x->off_steps, h, 2 * d * sizeof(CoreArgs), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_cross_confirm<true>, dim3(2 * d), dim3(NT), maxmn, st, (const CoreArgs *)(x->slab + x->off_steps));
+    // every step in LDS, or -- if one of them does not fit (rank 16 on 101 nodes is 207 KB) -- every step on its own block of
+    // global scratch: the same code either way (core_step<INLDS>), as in the sequential iteration
+    if (maxmn <= LDS_CAP_BYTES)
+        hipLaunchKernelGGL(k_cross_confirm<true>, dim3(2 * d), dim3(NT), maxmn, st, (const CoreArgs *)(x->slab + x->off_steps));
+    else
+        hipLaunchKernelGGL(k_cross_confirm<false>, dim3(2 * d), dim3(NT), 0, st, (const CoreArgs *)(x->slab + x->off_steps));
     HIPCHK(c, hipGetLastError());
     int flag = 1;
     HIPCHK(c, hipMemcpyAsync(&flag, mismatch, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     *confirmed = flag == 0;
     return C3SC_OK;
+}
+
+/* A whole iteration in d + 1 launches, for a sweep that starts from index sets believed to be its fixed point already (the
+ * previous sweep's: the value function moved a little, the warm-started pivot search usually picks the same rows).  The fiber
+ * lists of all d cores are formed from the CURRENT sets and evaluated back to back -- no factorisation in between, so nothing
+ * waits for a core step -- and the confirming launch (c3sc_hip_cross_confirm) factors all 2 d steps side by side.  *confirmed = 1:
+ * every step reproduced its index set, i.e. the sequential iteration would have asked for exactly these fibers in exactly this
+ * order (left-to-right lists, the right-to-left half all memo hits) and returned these cores: same kernels, same inputs, same
+ * bits.  *confirmed = 0: run c3sc_hip_cross_iteration; the lists evaluated here stay cached (same generation), so only the steps
+ * whose sets really change are evaluated again.  Value iteration, unsharded; otherwise *confirmed = 0 and nothing is launched. */
+int c3sc_hip_cross_speculate(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long policy_tag, int box, int *confirmed, void *stream)
+{
+    if (!c || !c->cross || c->cross->d == 0 || !confirmed) return fail(c, C3SC_ERR_ARG, "cross_speculate: cross_setup first");
+    *confirmed = 0;
+    c3sc_cross_dev *x = c->cross;
+    if (c->shard_comm) return C3SC_OK;
+    const int d = x->d;
+    hipStream_t st = (hipStream_t)stream;
+    if (pol) {
+        const int rc = prepare_policy_memo(c, pol, policy_tag, box);
+        if (rc != C3SC_OK) return rc;
+    }
+    for (int k = 0; k < d; k++) {
+        hipLaunchKernelGGL(k_cross_idx, dim3(1), dim3(256), 0, st, next_list(x, k, true));
+        const int rc = step_fibers(c, pol, box, k, stream);
+        if (rc != C3SC_OK) return rc;
+    }
+    HIPCHK(c, hipGetLastError());
+    return c3sc_hip_cross_confirm(c, confirmed, stream);
 }
 
 /* wait for the iteration and bring back: cores (working layout G[a + r_k (j + N_k b)]), both families of index sets, and

@@ -107,6 +107,7 @@ struct ValueF *valuef_copy(struct ValueF *vf)
     struct ValueF *c = valuef_create_nodal(vf->d, vf->N, vf->ranks, vf->cores);
     if (vf->grid) valuef_attach_grid(c, vf->grid);
     if (vf->isl) valuef_set_cross_indices(c, vf->nisl, vf->isl, vf->nisr, vf->isr);
+    c->sets_stable = vf->sets_stable;
     c->elem_class = vf->elem_class;
     return c;
 }

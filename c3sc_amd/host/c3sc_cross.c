@@ -123,6 +123,7 @@ static inline uint64_t pivot_key(double x, uint64_t index)
  * values (round 2: 15-27 % jumps of single control updates).  Both constants are part of the algorithm's definition: the device
  * twin uses the same. */
 #define WARM_BOOST_LOG2 6
+static size_t g_spec_tried = 0, g_spec_confirmed = 0; /* speculative first iterations of this process (valuef_interp_counter) */
 static double g_swap_tol = 0.05; /* swap while max |B| > 1 + tol (maxvol's usual 1e-2 .. 1e-1) */
 
 C3SC_CLONES static int lu_maxvol(size_t m, size_t n, double *A, size_t *rows, size_t *nswaps, const unsigned char *warm)
@@ -692,6 +693,7 @@ struct cross {
     long long dev_tag;            /* bellman_pi: the policy iteration the policy memo belongs to */
     unsigned long long dev_requested; /* nodes of all fibers asked for */
     int dev_confirm;                  /* try the one-launch confirming iteration (c3sc_hip_cross_confirm) */
+    int dev_speculate;                /* try the d + 1 launch first iteration of a warm-started sweep (c3sc_hip_cross_speculate) */
     unsigned long long dev_nodes; /* nodes stored in the device memo during this interpolation (the reference's nnode_evals) */
 };
 
@@ -836,16 +838,20 @@ static struct tt *cross_sweep_rl(struct cross *c)
  * node memo and the factorisations of all 2 d core steps on one stream; the host only uploads the index sets when they were
  * resized and reads the iteration's cores and index sets back.  Same arithmetic as cross_sweep_lr + cross_sweep_rl above
  * (lu_maxvol and k_cross_core return the same bits). */
+static void device_setup_if_fresh(struct cross *c)
+{
+    if (!c->dev_fresh) return;
+    if (c3sc_hip_cross_options(c->dev, c->warm, g_swap_tol) != 0) DIE("c3sc_hip_cross_options: %s", c3sc_hip_last_error(c->dev));
+    int rc = c3sc_hip_cross_setup(c->dev, c->r, (const int32_t *const *)c->I, (const int32_t *const *)c->J, c->dev_new_sweep);
+    if (rc != 0) DIE("c3sc_hip_cross_setup: %s", c3sc_hip_last_error(c->dev));
+    c->dev_fresh = 0;
+    c->dev_new_sweep = 0;
+}
+
 static struct tt *cross_iteration_device(struct cross *c)
 {
     const size_t d = c->d;
-    if (c->dev_fresh) {
-        if (c3sc_hip_cross_options(c->dev, c->warm, g_swap_tol) != 0) DIE("c3sc_hip_cross_options: %s", c3sc_hip_last_error(c->dev));
-        int rc = c3sc_hip_cross_setup(c->dev, c->r, (const int32_t *const *)c->I, (const int32_t *const *)c->J, c->dev_new_sweep);
-        if (rc != 0) DIE("c3sc_hip_cross_setup: %s", c3sc_hip_last_error(c->dev));
-        c->dev_fresh = 0;
-        c->dev_new_sweep = 0;
-    }
+    device_setup_if_fresh(c);
     int rc = c->dev_pol ? c3sc_hip_cross_iteration_pi(c->dev, c->dev_pol, c->dev_tag, NULL) : c3sc_hip_cross_iteration(c->dev, c->dev_box, NULL);
     if (rc != 0) DIE("c3sc_hip_cross_iteration: %s", c3sc_hip_last_error(c->dev));
     struct tt *t = tt_alloc(d, c->N, c->r);
@@ -905,7 +911,7 @@ static int same_sets(const struct cross *c, int **A, int **B, int right)
 }
 static void free_sets(const struct cross *c, int **S) { for (size_t k = 0; k < c->d; k++) free(S[k]); free(S); }
 
-struct dev_fibers { struct c3sc_hip_ctx *ctx, *pol; long long tag; int box; unsigned long long nodes, requested; };
+struct dev_fibers { struct c3sc_hip_ctx *ctx, *pol; long long tag; int box; unsigned long long nodes, requested; int speculate_ok; };
 
 static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber_idx_fn fi, void *args, const size_t *N, double **grid,
                                   struct ValueF *vref, struct ApproxArgs *aargs, int verbose, struct dev_fibers *dev)
@@ -928,7 +934,14 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     c.warm = getenv("C3SC_COLD_PIVOTS") == NULL;
     if (getenv("C3SC_SWAP_TOL")) g_swap_tol = atof(getenv("C3SC_SWAP_TOL"));
     c.dev_confirm = getenv("C3SC_NO_CONFIRM") == NULL;
+    /* the speculative first iteration needs sets that come from a previous sweep (a fresh solve starts from generic tuples) */
+    c.dev_speculate = c.dev_confirm && getenv("C3SC_NO_SPECULATE") == NULL && dev != NULL && dev->speculate_ok && vref != NULL &&
+                      vref->isl != NULL && (vref->sets_stable || getenv("C3SC_ALWAYS_SPECULATE") != NULL) && approx_args_get_adapt(aargs) == 1;
     if (dev != NULL) { c.dev = dev->ctx; c.dev_pol = dev->pol; c.dev_tag = dev->tag; c.dev_box = dev->box; c.dev_fresh = 1; c.dev_new_sweep = 1; }
+    if (getenv("C3SC_CROSS_TRACE") && dev != NULL)
+        fprintf(stderr, "c3sc cross trace: speculate %d (confirm %d, consistent ends %d, previous sets %s, stable %d, adapt %d)\n", c.dev_speculate,
+                c.dev_confirm, dev->speculate_ok, vref != NULL && vref->isl != NULL ? "yes" : "no", vref != NULL ? vref->sets_stable : -1,
+                (int)approx_args_get_adapt(aargs));
     c.r = xcalloc(d + 1, sizeof(size_t));
     c.r[0] = c.r[d] = 1;
     size_t base = approx_args_get_startrank(aargs);
@@ -950,6 +963,11 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
         c.J[k] = resize_tuples(oldJ, nJ, c.r[k + 1], d - 1 - k, N + k + 1, 1);
     }
     if (verbose > 0) { printf("Starting Ranks: "); for (size_t k = 0; k <= d; k++) printf("%zu ", c.r[k]); printf("\n"); }
+    /* the sets this interpolation starts from: if it ends with the very same ones (no rank kicked, no row swapped), the next
+     * sweep's first iteration is worth trying speculatively */
+    int **I0 = copy_sets(&c, c.I, 0), **J0 = copy_sets(&c, c.J, 1);
+    size_t *r_entry = xcalloc(d + 1, sizeof(size_t));
+    memcpy(r_entry, c.r, (d + 1) * sizeof(size_t));
 
     struct tt *best = NULL;
     const double t_all = tnow();
@@ -961,7 +979,31 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             c.deficient = 0;
             int **Iold = copy_sets(&c, c.I, 0), **Jold = copy_sets(&c, c.J, 1);
             struct tt *t2 = NULL;
-            if (c.dev && it > 0 && !c.dev_fresh && c.dev_confirm) {
+            if (c.dev && it == 0 && round == 0 && c.dev_speculate) {
+                /* A sweep that starts from the previous sweep's index sets usually ends with them: the value function moved a
+                 * little and the pivot search starts from the old rows.  The device evaluates the fiber lists of all d cores
+                 * from the current sets back to back and factors all 2 d steps in one launch; if every step reproduces its
+                 * set, that WAS the iteration (the sequential one would have asked for the same fibers in the same order and
+                 * returned the same cores) and it is also its own confirmation: the loop ends at the fixed-point test below.
+                 * If not, the ordinary iteration runs and finds the lists evaluated here cached. */
+                int ok = 0;
+                device_setup_if_fresh(&c);
+                if (c3sc_hip_cross_speculate(c.dev, c.dev_pol, c.dev_tag, c.dev_box, &ok, NULL) != 0)
+                    DIE("c3sc_hip_cross_speculate: %s", c3sc_hip_last_error(c.dev));
+                g_spec_tried++;
+                g_spec_confirmed += ok ? 1 : 0;
+                if (ok) {
+                    t2 = tt_alloc(d, c.N, c.r);
+                    unsigned long long info[4] = {0, 0, 0, 0};
+                    if (c3sc_hip_cross_fetch(c.dev, t2->G, NULL, NULL, info, NULL) != 0) DIE("c3sc_hip_cross_fetch: %s", c3sc_hip_last_error(c.dev));
+                    if (info[3]) DIE("valuef_interp: the device node memo overflowed");
+                    c.dev_nodes += info[0];
+                    if (info[1]) c.deficient = 1;
+                    for (size_t k = 0; k < d; k++) { c.nfibers += 2 * c.r[k] * c.r[k + 1]; c.dev_requested += 2 * c.r[k] * c.r[k + 1] * c.N[k]; }
+                    if (trace) fprintf(stderr, "c3sc cross trace: round 0: speculative iteration confirmed\n");
+                } else if (trace) fprintf(stderr, "c3sc cross trace: round 0: speculative iteration not confirmed\n");
+            }
+            if (t2 == NULL && c.dev && it > 0 && !c.dev_fresh && c.dev_confirm) {
                 /* The previous iteration changed index sets; the next one usually changes nothing.  The device can establish that
                  * in one launch -- all 2 d core steps side by side on the fiber values they already hold, comparing instead of
                  * writing their index sets -- and, if so, has the iteration's cores in place: same kernels, same inputs, same
@@ -1060,6 +1102,16 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
         valuef_set_cross_indices(vf, nl, c.I, nr, c.J);
         free(nl); free(nr);
     }
+    {
+        int same = vref != NULL && vref->isl != NULL && memcmp(r_entry, c.r, (d + 1) * sizeof(size_t)) == 0;
+        if (same) same = same_sets(&c, c.I, I0, 0) && same_sets(&c, c.J, J0, 1);
+        vf->sets_stable = same;
+        if (trace) fprintf(stderr, "c3sc cross trace: final index sets %s the ones this interpolation started from\n", same ? "are" : "are not");
+        /* I0 / J0 were sized by the entry ranks: free them under those */
+        memcpy(c.r, r_entry, (d + 1) * sizeof(size_t));
+        free_sets(&c, I0); free_sets(&c, J0);
+        free(r_entry);
+    }
     tt_free(best);
     for (size_t k = 0; k < d; k++) { free(c.I[k]); free(c.J[k]); }
     free(c.I); free(c.J); free(c.r);
@@ -1153,12 +1205,16 @@ struct ValueF *c3sc_interp_device(size_t d, struct c3sc_hip_ctx *ctx, int box, c
                                   struct ApproxArgs *aargs, int verbose, size_t *nodes, struct c3sc_hip_ctx *policy_ctx, long long policy_tag,
                                   size_t *requested)
 {
-    struct dev_fibers dv = {ctx, policy_ctx, policy_tag, box, 0, 0};
+    /* the speculative first iteration evaluates fibers before it knows they are needed: only where a node's value does not depend
+     * on the fiber that computes it (consistent end points -- the solver loops' default) does the memo's first-entry rule not care */
+    struct dev_fibers dv = {ctx, policy_ctx, policy_tag, box, 0, 0, c3sc_hip_get_consistent_ends(ctx) == 1};
     struct ValueF *vf = interp_impl(d, NULL, NULL, NULL, NULL, N, grid, vref, aargs, verbose, &dv);
     if (nodes) *nodes = (size_t)dv.nodes;
     if (requested) *requested = (size_t)dv.requested;
     return vf;
 }
+
+size_t valuef_interp_counter(int which) { return which == 0 ? g_spec_tried : (which == 1 ? g_spec_confirmed : 0); }
 
 struct ValueF *valuef_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
                                          const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,

@@ -21,6 +21,8 @@ struct ValueF {
     double **grid;               /* nodes per dimension, or NULL (valuef_create_nodal without valuef_attach_grid) */
     size_t *nisl, *nisr;         /* cross index sets of the last interpolation (warm start), or NULL */
     int **isl, **isr;
+    int sets_stable;             /* the interpolation that made this function ended with the index sets it started from (its predecessor's): the
+                                    next one may try its first iteration speculatively (c3sc_hip_cross_speculate) */
     int elem_class;              /* 0 / LINELM: piecewise-linear between the nodes; CONSTELM: piecewise-constant (valuefunc.c:661-669) */
     unsigned long version;       /* bumps on every construction: identifies an upload */
     struct c3sc_hip_ctx *bound;  /* device context the cores were uploaded to */

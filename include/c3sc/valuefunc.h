@@ -52,6 +52,10 @@ struct ValueF *valuef_interp_idx(size_t d, int (*fi)(size_t, size_t, const int32
  * run).  A rank whose fi fails still enters the exchange (its rows marked NaN) and all ranks return the error together.
  * SURVEY.md 8e; the reference hook is bellman.c:2201. */
 typedef int (*c3sc_exchange_fn)(double *out, size_t F, size_t N, size_t lo, size_t hi, void *xarg);
+/* diagnostics of this library's cross driver (no reference counterpart): 0 = sweeps whose first iteration was tried speculatively
+ * on the device (c3sc_hip_cross_speculate: a sweep whose predecessor ended with the index sets it started from), 1 = those that
+ * were confirmed, i.e. whose whole iteration took d + 1 kernel launches; process-wide counts */
+size_t valuef_interp_counter(int which);
 struct ValueF *valuef_interp_idx_sharded(size_t d, int (*fi)(size_t, size_t, const int32_t *, double *, void *), void *args,
                                          const size_t *N, double **grid, struct ValueF *vref, struct ApproxArgs *aargs,
                                          int verbose, size_t world, size_t rank, c3sc_exchange_fn exchange, void *xarg);

@@ -100,6 +100,7 @@ int c3sc_hip_set_boundary(c3sc_hip_ctx *ctx, const int *bctype, int nobs, const 
  * the node.  The solver loops of libc3sc.so switch it on (c3control_set_consistent_ends); the per-fiber entry points used
  * through the reference's callback ABI keep the literal behaviour. */
 int c3sc_hip_set_consistent_ends(c3sc_hip_ctx *ctx, int on);
+int c3sc_hip_get_consistent_ends(const c3sc_hip_ctx *ctx); /* 1 / 0; -1 for a null context */
 /* mca_add_grid_refs (bellman.c:171-188) + dp_param_create's discount (bellman.c:220-235) */
 int c3sc_hip_set_mca(c3sc_hip_ctx *ctx, double h2, const double *t, double discount);
 /* replaces c3control_add_drift/diff/stagecost/boundcost/obscost (bellman.c:2064-2103) */
@@ -221,6 +222,15 @@ int c3sc_hip_cross_iteration(c3sc_hip_ctx *ctx, int box, void *stream);
  * they already hold, comparing instead of writing their index sets).  *confirmed = 1: the iteration that would follow changes
  * nothing and its cores are in place -- fetch them; 0: run c3sc_hip_cross_iteration[_pi] as usual.  Synchronises the stream. */
 int c3sc_hip_cross_confirm(c3sc_hip_ctx *ctx, int *confirmed, void *stream);
+/* at the start of a sweep whose index sets come from the previous sweep: the whole iteration in d + 1 launches -- the fiber lists
+ * of all d cores from the current sets, evaluated back to back (no core step in between), then the confirming launch above.
+ * *confirmed = 1: every step reproduced its index set, so the sequential iteration would have returned exactly these cores (fetch
+ * them); 0: run c3sc_hip_cross_iteration[_pi] -- what was evaluated here stays cached.  policy_ctx == NULL: bellman_vi's fibers, else
+ * bellman_pi's as in c3sc_hip_cross_iteration_pi.  Unsharded contexts; otherwise nothing is launched and *confirmed = 0.  Because the
+ * lists are evaluated before any set is known to survive, a failed attempt may have put nodes into the memo that the sequential
+ * iteration would not have asked for: use it only where a node's value does not depend on the fiber that computes it
+ * (c3sc_hip_set_consistent_ends).  Synchronises the stream. */
+int c3sc_hip_cross_speculate(c3sc_hip_ctx *ctx, c3sc_hip_ctx *policy_ctx, long long policy_tag, int box, int *confirmed, void *stream);
 /* the same for bellman_pi (bellman.c:1702-1886): per core step the greedy policy of the value function uploaded to policy_ctx
  * (cached per node for the whole policy iteration policy_tag: the reference's prob table, bellman.c:1806, 1877), then its
  * evaluation on ctx's value function.  info[0] of the fetch then counts the nodes whose policy was computed (npol_evals). */

@@ -177,6 +177,76 @@ def test_rossler_example_outer_loop_device_vs_oracle_side_by_side(oracle):
     orc.close()
 
 
+@pytest.mark.parametrize("name,kw,aargs,must_take", [
+    ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=2), False),
+    ("dubins3d", dict(ngrid=(41, 41, 41), rank=4), dict(maxrank=12, kick=3), True),
+    ("lqg2d", dict(ngrid=(60, 60), rank=4), dict(maxrank=12, kick=3), True),
+], ids=["car7d-small", "dubins3d", "lqg2d"])
+def test_speculative_first_iteration_same_bits_and_actually_used(name, kw, aargs, must_take):
+    """A sweep whose predecessor ended with the index sets it started from first tries the whole iteration in d + 1 launches
+    (c3sc_hip_cross_speculate: the fiber lists of all d cores from the current sets back to back, bellman_vi's or bellman_pi's,
+    then every core step side by side).  When every step reproduces its set that WAS the iteration; otherwise the sequential one
+    runs.  Either way cores, ranks, sweep counts and last steps of the examples' control updates (policy-evaluation sweeps + one
+    value-iteration sweep) must be the bits of the sequential device iteration (C3SC_NO_SPECULATE=1) and of the host-driven driver
+    (C3SC_HOST_CROSS=1) -- and on the converging problems the short cut must actually have been taken.  The short cut exists
+    only under the solver loops' own end-point rule (c3control_set_consistent_ends, the library default; this file's other tests
+    run the reference's literal rule): with it a node's value does not depend on the fiber that computes it."""
+    w = wl.WORKLOADS[name]().scaled(**kw)
+    L, fl, ctl, aa = _setup(w, **aargs)
+    L.c3control_set_consistent_ends(ctl.h, C.c_int(1))
+    d = w.dx
+
+    def start(n, x, out, a):
+        X = np.ctypeslib.as_array(x, shape=(n, d))
+        np.ctypeslib.as_array(out, shape=(n,))[:] = 1.0 + 0.1 * ((X - 0.05) ** 2).sum(axis=1)
+        return 0
+
+    v0 = C.c_void_p(L.c3control_init_value(ctl.h, FIBER_FN(start), None, aa, 0))
+    results, taken, tried = {}, 0, 0
+    names = ("C3SC_HOST_CROSS", "C3SC_NO_SPECULATE", "C3SC_ALWAYS_SPECULATE")
+    L.valuef_interp_counter.restype = C.c_size_t
+    for path in ("speculative", "sequential", "host"):
+        for var in names:
+            os.environ.pop(var, None)
+        if path == "host":
+            os.environ["C3SC_HOST_CROSS"] = "1"
+        elif path == "sequential":
+            os.environ["C3SC_NO_SPECULATE"] = "1"
+        else:  # try it in EVERY warm-started sweep, not only after a sweep that kept its sets: the failing attempts are the hard case
+            os.environ["C3SC_ALWAYS_SPECULATE"] = "1"
+        before = (L.valuef_interp_counter(0), L.valuef_interp_counter(1))
+        v = C.c_void_p(L.valuef_copy(v0))
+        rows = []
+        for upd in range(6):
+            diag = C.c_void_p(None)
+            nxt = C.c_void_p(L.c3control_pi_solve(ctl.h, C.c_size_t(8), C.c_double(1e-12), v, aa, ctl.opt, 0, C.byref(diag)))
+            L.valuef_destroy(v)
+            v = C.c_void_p(L.c3control_vi_solve(ctl.h, C.c_size_t(2), C.c_double(1e-12), nxt, aa, ctl.opt, 0, C.byref(diag)))
+            L.valuef_destroy(nxt)
+            rows.append((L.diag_count(diag), L.diag_last_diff(diag)) + _cores_of(L, v, w))
+            L.diag_destroy(C.byref(diag))
+        results[path] = rows
+        L.valuef_destroy(v)
+        if path == "speculative":
+            tried, taken = L.valuef_interp_counter(0) - before[0], L.valuef_interp_counter(1) - before[1]
+        else:
+            assert L.valuef_interp_counter(0) == before[0]
+    for var in names:
+        os.environ.pop(var, None)
+    for other in ("sequential", "host"):
+        for it, (a, b) in enumerate(zip(results["speculative"], results[other])):
+            assert a[0] == b[0] and a[1] == b[1], f"{other}, update {it}: sweeps / last step {a[:2]} vs {b[:2]}"
+            assert a[2] == b[2], f"{other}, update {it}: ranks {a[2]} vs {b[2]}"
+            for m in range(d):
+                assert np.array_equal(a[3][m], b[3][m]), f"{other}, update {it}, core {m}: max diff {np.abs(a[3][m] - b[3][m]).max():.3e}"
+    print(f"{name} {w.ngrid}: 6 control updates (60 sweeps) bit-identical with and without the speculative first iteration and on the "
+          f"host driver; short cut tried in {tried} sweeps, confirmed in {taken}")
+    assert taken >= 1 or not must_take
+    L.valuef_destroy(v0)
+    L.approx_args_free(aa)
+    ctl.close()
+
+
 @pytest.mark.parametrize("name,kw,aargs", [
     ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=2)),
     ("car7d", dict(), dict(maxrank=10, kick=2)),                       # the bench's vi_sweep configuration: 41^7, rank cap 10

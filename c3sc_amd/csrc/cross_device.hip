@@ -141,6 +141,9 @@ struct CoreArgs {
     // confirm mode (k_cross_confirm): nothing is overwritten -- the index set the step produces is COMPARED with set_out, a
     // difference raises *mismatch; the core is written only by the right-to-left steps (they own G in a finished iteration)
     int confirm;
+#ifdef C3SC_CORE_STAMPS
+    unsigned long long *stamps; // diagnostic build: [8] cycle counts per phase of this step
+#endif
     int *mismatch;
 };
 
@@ -204,24 +207,31 @@ __device__ inline void mark_warm_rows(const CoreArgs &P, int m, int n, unsigned 
         for (int e = tid; e < n * lold; e += NT) s_old[e] = P.set_out[e];
     }
     __syncthreads();
-    if (P.warm && tid < n) {
+    // one thread per (old tuple q, candidate tuple a): the first matching a (lowest index, as a sequential scan would find it) names
+    // the row.  The sequential scan it replaces -- one thread per old tuple, up to nin x lin dependent LDS reads -- was 6-10 k
+    // cycles of a 64 k-cycle step.
+    __shared__ int firsta[32];
+    if (tid < 32) firsta[tid] = 0x7fffffff;
+    __syncthreads();
+    if (P.warm)
+        for (int e = tid; e < n * nin; e += NT) {
+            const int q = e / nin, a = e % nin;
+            const int *u = s_old + q * lold;
+            const int off = P.dir == 0 ? 0 : 1; // dir 0: (u_0..u_{k-1}, j) against I_k[a]; dir 1: (j, v_1..) against J_k[a]
+            bool eq = true;
+            for (int t = 0; t < lin; t++) eq = eq && (s_in[a * lin + t] == u[off + t]);
+            if (eq) atomicMin(&firsta[q], a);
+        }
+    __syncthreads();
+    if (P.warm && tid < n && firsta[tid] != 0x7fffffff) {
         const int *u = s_old + tid * lold;
-        if (P.dir == 0) { // tuple (u_0..u_{k-1}, j) is row a + r0 j if I_k[a] == (u_0..u_{k-1})
+        const int a = firsta[tid];
+        if (P.dir == 0) { // row a + r0 j
             const int j = u[lin];
-            if (j >= 0 && j < P.N)
-                for (int a = 0; a < nin; a++) {
-                    bool eq = true;
-                    for (int t = 0; t < lin; t++) eq = eq && (s_in[a * lin + t] == u[t]);
-                    if (eq) { warmf[a + P.r0 * j] = 1; break; }
-                }
-        } else { // tuple (j, v_1..) is row j + N b if J_k[b] == (v_1..)
+            if (j >= 0 && j < P.N) warmf[a + P.r0 * j] = 1;
+        } else { // row j + N b
             const int j = u[0];
-            if (j >= 0 && j < P.N)
-                for (int b = 0; b < nin; b++) {
-                    bool eq = true;
-                    for (int t = 0; t < lin; t++) eq = eq && (s_in[b * lin + t] == u[1 + t]);
-                    if (eq) { warmf[j + P.N * b] = 1; break; }
-                }
+            if (j >= 0 && j < P.N) warmf[j + P.N * a] = 1;
         }
     }
     __syncthreads();
@@ -285,10 +295,18 @@ __device__ inline void write_sets_and_next(const CoreArgs &P, int n, const int *
 // store into the matrix might alias the next load: the kernel was 45 us of pure latency that way).
 constexpr int CH = 8;
 
+#ifdef C3SC_CORE_STAMPS
+#define CORE_STAMP(slot) do { __syncthreads(); if (threadIdx.x == 0 && P.stamps) { const unsigned long long now__ = clock64(); P.stamps[slot] += now__ - tlast__; tlast__ = now__; } } while (0)
+#else
+#define CORE_STAMP(slot) do { } while (0)
+#endif
 template <bool INLDS>
 __device__ __forceinline__ void core_step(const CoreArgs &P)
 {
 #pragma clang fp contract(off) // products and sums round separately, as in the host twin (ISO C): the two return the same bits
+#ifdef C3SC_CORE_STAMPS
+    unsigned long long tlast__ = clock64();
+#endif
     extern __shared__ double smem[];
     __shared__ double Lr[32 * 32];
     __shared__ double rowv[32];
@@ -323,7 +341,9 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
             for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
         }
     }
+    CORE_STAMP(0);
     mark_warm_rows(P, m, n, warmf, s_in, s_old);
+    CORE_STAMP(1);
     const double boost = (double)(1 << WARM_BOOST_LOG2);
     int parity = 0;
     unsigned used = 0; // bit q: my q-th row (row tid + q NT) is a pivot row
@@ -366,6 +386,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
         // written again)
     }
     __syncthreads();
+    CORE_STAMP(2);
     // ---- B = L inv(L[rows]): L[rows] is unit lower triangular in pivot order
     for (int e = tid; e < n * n; e += NT) {
         const int q = e / n, j = e % n;
@@ -396,6 +417,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
         A[rows[q] + j * m] = (j == q) ? 1.0 : 0.0;
     }
     __syncthreads();
+    CORE_STAMP(3);
     // ---- maxvol: swap rows until the largest entry of B is <= 1 + swap_tol
     int nswaps = 0;
     for (int it = 0; it < 200; it++) {
@@ -441,6 +463,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
         // after that barrier, when every thread has finished this update)
     }
     __syncthreads();
+    CORE_STAMP(4);
     sort_rows(n, rows, srows, pos);
     // ---- results, columns in the order of ascending rows
     for (int i = tid; i < m; i += NT)
@@ -455,7 +478,12 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
                     else P.G[pos[c0 + u] + r0 * i] = x[u];                                // G[a' + r0 cc], cc = i
                 }
         }
+    CORE_STAMP(5);
     write_sets_and_next(P, n, srows, pivabs, nswaps);
+    CORE_STAMP(6);
+#ifdef C3SC_CORE_STAMPS
+    if (threadIdx.x == 0 && P.stamps) P.stamps[7] += (unsigned long long)nswaps;
+#endif
 }
 
 template <bool INLDS>
@@ -795,6 +823,23 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         P.warm = x->warm;
         P.swap_tol = x->swap_tol;
         P.confirm = 0; P.mismatch = nullptr;
+#ifdef C3SC_CORE_STAMPS
+        static unsigned long long *g_stamps = nullptr;
+        if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 64 * 8 * sizeof(unsigned long long)); (void)hipMemset(g_stamps, 0, 64 * 8 * sizeof(unsigned long long)); }
+        P.stamps = g_stamps + 8 * s;
+        if (s == 2 * d - 1) {
+            static int calls = 0;
+            if (++calls % 20 == 0) {
+                (void)hipStreamSynchronize(st);
+                unsigned long long hs[64 * 8];
+                (void)hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost);
+                for (int q = 0; q < 2 * d; q++)
+                    fprintf(stderr, "core step %2d (mean of %d): load %6.0f warm %6.0f lu %6.0f backsub %6.0f maxvol %6.0f results %6.0f sets+next %6.0f cycles, swaps %.2f\n", q, calls,
+                            hs[8 * q + 0] / (double)calls, hs[8 * q + 1] / (double)calls, hs[8 * q + 2] / (double)calls, hs[8 * q + 3] / (double)calls,
+                            hs[8 * q + 4] / (double)calls, hs[8 * q + 5] / (double)calls, hs[8 * q + 6] / (double)calls, hs[8 * q + 7] / (double)calls);
+            }
+        }
+#endif
         std::memset(&P.next, 0, sizeof(P.next));
         if (s + 1 < 2 * d) {
             const int nh = (s + 1) / d, nk = nh == 0 ? s + 1 : 2 * d - 2 - s;
@@ -847,6 +892,9 @@ int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
         P.swap_tol = x->swap_tol;
         P.confirm = 1;
         P.mismatch = mismatch;
+#ifdef C3SC_CORE_STAMPS
+        P.stamps = nullptr;
+#endif
         if (!P.copy_only) maxmn = std::max(maxmn, (size_t)P.r0 * P.r1 * P.N * sizeof(double));
     }
     HIPCHK(c, hipMemsetAsync(mismatch, 0, sizeof(int), st));

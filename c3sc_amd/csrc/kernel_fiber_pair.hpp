@@ -696,8 +696,16 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
     }
 }
 
+// registers: two wavefronts per SIMD in general (256 VGPRs); the direct-fold kernels at ranks <= 6 sit at 122-137 and are asked to stay
+// within 128 (four per SIMD: their LDS footprint allows it)
+#ifndef FPP_WPS_LOW
+#define FPP_WPS_LOW 4
+#endif
+template <class Model, int RP>
+__host__ __device__ constexpr int fpp_waves_per_simd() { return (fpp_direct<Model, RP>() && RP <= 6) ? FPP_WPS_LOW : 2; }
+
 template <class Model, int RP, int K, bool FORCED>
-__global__ void __launch_bounds__(FPP_THREADS, 2)
+__global__ void __launch_bounds__(FPP_THREADS, (fpp_waves_per_simd<Model, RP>()))
     k_fiber_pair(const KArgs A, const double *__restrict__ ro, const int32_t *__restrict__ idx, double *__restrict__ outv,
                  int32_t *__restrict__ uidx, int32_t *__restrict__ absorbed)
 {

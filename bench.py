@@ -343,6 +343,10 @@ def main():
                          "(default: 2^20 for car7d, the roofline batch of SURVEY.md 8d; 2^17 for the other workloads)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--overlap", action="store_true",
+                    help="issue the d independent launches of a step through c3sc_hip_bellman_fibers_all (three streams inside the library) "
+                         "in the timed region; per-kernel durations then overlap, so `roofline` is taken from the step span")
+    ap.add_argument("--no-overlap-probe", action="store_true", help="skip the untimed second pass that times a step the other way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solver", action="store_true", help="skip the vi_sweep / vi_iters_to_tol measurements after the timed region")
     ap.add_argument("--solver-budget", type=float, default=20.0)
@@ -452,8 +456,16 @@ def main():
     nodes_per_step_loc = sum(F_loc * w.ngrid[k] for k in range(d))
     ev = []
 
-    def step(record):
-        for k in range(d):
+    def step(record, overlap=False):
+        if overlap:  # the d independent launches as ONE call: the library spreads them over three streams (c3sc_hip_bellman_fibers_all)
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            eng.bellman_fibers_all(list(range(d)), idx_t, out_t, stream_ptr=sp)
+            if record:
+                e1.record(stream)  # after the join: the span of the d overlapping launches
+                ev.append((-1, e0, e1))
+        for k in range(d if not overlap else 0):
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -486,13 +498,24 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step(False)
+        step(False, args.overlap)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step(True, args.overlap)
     fence()
     elapsed = time.perf_counter() - t0
+    # the same steps the other way (untimed for `value`): with the launches of a step on one stream (default: the per-kernel
+    # durations behind `roofline` are then what rocprofv3 sees) or spread over three streams by the library (--overlap)
+    other = None
+    if not use_dist and not args.no_overlap_probe:
+        step(False, not args.overlap)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False, not args.overlap)
+        fence()
+        other = (time.perf_counter() - t1) / args.steps
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -500,7 +523,7 @@ def main():
     status = eng.status()
 
     # dominant kernel: average launch duration from the HIP events recorded on the launch stream
-    kms = [e0.elapsed_time(e1) for (_, e0, e1) in ev]
+    kms = [e0.elapsed_time(e1) / (d if kk < 0 else 1) for (kk, e0, e1) in ev]  # --overlap: span of a step's launches / their number
     avg_ms = float(np.mean(kms))
     Wf = wl.algorithmic_flops_per_node(w)
     nodes_per_launch = nodes_per_step_loc / d
@@ -554,6 +577,16 @@ def main():
                                   "peak_GBs": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS},
             },
         }
+        # the step the other way round, measured after the timed region (never `value`): the d launches of a step are independent,
+        # and c3sc_hip_bellman_fibers_all spreads them over three streams so that one dimension's tail overlaps the next one's head
+        res["step_launch_mode"] = "overlapped (c3sc_hip_bellman_fibers_all, three streams)" if args.overlap else "one stream, d launches in order"
+        if other is not None:
+            res["other_mode_step"] = {
+                "mode": "one stream, d launches in order" if args.overlap else "overlapped (c3sc_hip_bellman_fibers_all, three streams)",
+                "ms_per_step": 1e3 * other, "value": nodes_per_step_job / other, "unit": "nodes/s",
+                "roofline_frac_from_step_span": Wf * nodes_per_step_loc / other / 1e12 / FP64_PEAK_TFLOPS,
+                "what": "the same steps re-timed (wall clock over --steps steps, untimed for `value`) with the other launch mode; under "
+                        "overlap the per-kernel durations of a profile overlap, so the default keeps one stream and `roofline` per kernel"}
         res["vi_sweep"], res["vi_iters_to_tol"] = None, None
         if world == 1 and not args.no_solver:
             try:

@@ -295,6 +295,11 @@ void c3sc_hip_ctx_destroy(c3sc_hip_ctx *c)
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->pinned) (void)hipHostFree(c->pinned);
     c3sc_hip_cross_free(c);
+    for (int i = 0; i < c3sc_hip_ctx::NSIDE; i++) {
+        if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+        if (c->join_ev[i]) (void)hipEventDestroy(c->join_ev[i]);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -663,6 +668,66 @@ int c3sc_hip_bellman_fibers(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_i
                             int32_t *d_absorbed, void *stream)
 {
     return launch_bellman(c, k, F, d_idx, nullptr, d_out, d_uidx, d_absorbed, stream);
+}
+
+// All varying dimensions of one batch.  The launches are independent, so they are spread over the caller's stream and two side
+// streams (forked from and joined to the caller's stream by events): the next dimension's workgroups fill the slots the previous
+// dimension's last tiles leave.  Stream-ordered like a single launch: work enqueued on `stream` before / after the call runs
+// before / after all of it.  With a memo or skip flag armed (the cross iterations' sequential steps), small AUTO batches or
+// C3SC_NO_OVERLAP=1 the launches simply run in order on `stream`.
+static int launch_bellman_all(c3sc_hip_ctx *c, int nk, const int *ks, const size_t *F, const int32_t *const *d_idx,
+                              const int32_t *const *d_policy, double *const *d_out, int32_t *const *d_uidx, int32_t *const *d_absorbed,
+                              void *stream)
+{
+    if (!c) return C3SC_ERR_ARG;
+    if (nk < 1 || nk > MAXD || !ks || !F || !d_idx || !d_out) return fail(c, C3SC_ERR_ARG, "bellman_fibers_all: bad arguments");
+    static const bool no_overlap = getenv("C3SC_NO_OVERLAP") != nullptr;
+    bool overlap = nk > 1 && !no_overlap && c->memo.keys == nullptr && c->skip_flag == nullptr;
+    for (int s = 0; s < nk; s++) {
+        if (ks[s] < 0 || ks[s] >= c->d) return fail(c, C3SC_ERR_ARG, "bellman_fibers_all: dim_vary out of range");
+        if (F[s] > 0 && (!d_idx[s] || !d_out[s])) return fail(c, C3SC_ERR_ARG, "bellman_fibers_all: null buffer");
+        if (d_policy && !d_policy[s]) return fail(c, C3SC_ERR_ARG, "bellman_fibers_all: null policy");
+        for (int q = 0; q < s; q++)
+            if (d_out[q] == d_out[s] && F[s] > 0) return fail(c, C3SC_ERR_ARG, "bellman_fibers_all: two segments share an output array");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (overlap) {
+        HIPCHK(c, hipSetDevice(c->device));
+        if (!c->fork_ev) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+            for (int i = 0; i < c3sc_hip_ctx::NSIDE; i++) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+            }
+        }
+        HIPCHK(c, hipEventRecord(c->fork_ev, st));
+        for (int i = 0; i < c3sc_hip_ctx::NSIDE; i++) HIPCHK(c, hipStreamWaitEvent(c->side[i], c->fork_ev, 0));
+    }
+    int rc = C3SC_OK;
+    for (int s = 0; s < nk && rc == C3SC_OK; s++) {
+        const int lane = overlap ? s % (c3sc_hip_ctx::NSIDE + 1) : 0; // 0: the caller's stream
+        rc = launch_bellman(c, ks[s], F[s], d_idx[s], d_policy ? d_policy[s] : nullptr, d_out[s], d_uidx ? d_uidx[s] : nullptr,
+                            d_absorbed ? d_absorbed[s] : nullptr, lane == 0 ? stream : (void *)c->side[lane - 1]);
+    }
+    if (overlap) // join even after a failed launch: what was enqueued on the side streams must not outlive the call's ordering
+        for (int i = 0; i < c3sc_hip_ctx::NSIDE; i++) {
+            HIPCHK(c, hipEventRecord(c->join_ev[i], c->side[i]));
+            HIPCHK(c, hipStreamWaitEvent(st, c->join_ev[i], 0));
+        }
+    return rc;
+}
+
+int c3sc_hip_bellman_fibers_all(c3sc_hip_ctx *c, int nk, const int *ks, const size_t *F, const int32_t *const *d_idx, double *const *d_out,
+                                int32_t *const *d_uidx, int32_t *const *d_absorbed, void *stream)
+{
+    return launch_bellman_all(c, nk, ks, F, d_idx, nullptr, d_out, d_uidx, d_absorbed, stream);
+}
+
+int c3sc_hip_policy_fibers_all(c3sc_hip_ctx *c, int nk, const int *ks, const size_t *F, const int32_t *const *d_idx,
+                               const int32_t *const *d_policy, double *const *d_out, int32_t *const *d_absorbed, void *stream)
+{
+    if (!d_policy) return fail(c, C3SC_ERR_ARG, "policy_fibers_all: null policy");
+    return launch_bellman_all(c, nk, ks, F, d_idx, d_policy, d_out, nullptr, d_absorbed, stream);
 }
 
 static int launch_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, const double *d_policy_u, double *d_out,

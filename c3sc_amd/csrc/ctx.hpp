@@ -52,6 +52,11 @@ struct c3sc_hip_ctx {
     int variant = C3SC_VARIANT_AUTO;
     const char *last_kernel = "";
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // c3sc_hip_bellman_fibers_all: side streams the independent per-dimension launches of one batch are spread over, with the
+    // events that fork them from and join them to the caller's stream (created on first use)
+    static constexpr int NSIDE = 2;
+    hipStream_t side[NSIDE] = {nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[NSIDE] = {nullptr, nullptr};
     // scratch for the *_host convenience calls
     void *scratch = nullptr;
     size_t scratch_bytes = 0;

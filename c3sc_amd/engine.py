@@ -24,7 +24,7 @@ c_i32_p = C.POINTER(C.c_int32)
 # every symbol include/c3sc_hip.h declares (the CPU test-suite checks they are all exported)
 EXPORTS = [
     "c3sc_hip_ctx_create", "c3sc_hip_ctx_destroy", "c3sc_hip_last_error", "c3sc_hip_device_count", "c3sc_hip_max_rank",
-    "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_consistent_ends", "c3sc_hip_get_consistent_ends", "c3sc_hip_cross_setup", "c3sc_hip_cross_iteration", "c3sc_hip_cross_iteration_pi", "c3sc_hip_cross_confirm", "c3sc_hip_cross_speculate", "c3sc_hip_comm_unique_id", "c3sc_hip_comm_create", "c3sc_hip_comm_destroy", "c3sc_hip_comm_world", "c3sc_hip_comm_rank", "c3sc_hip_comm_allgather", "c3sc_hip_cross_set_comm", "c3sc_hip_comm_exchange", "c3sc_hip_cross_options", "c3sc_hip_cross_fetch", "c3sc_hip_cross_free", "c3sc_hip_set_mca", "c3sc_hip_set_model",
+    "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_consistent_ends", "c3sc_hip_get_consistent_ends", "c3sc_hip_cross_setup", "c3sc_hip_cross_iteration", "c3sc_hip_cross_iteration_pi", "c3sc_hip_cross_confirm", "c3sc_hip_bellman_fibers_all", "c3sc_hip_policy_fibers_all", "c3sc_hip_cross_speculate", "c3sc_hip_comm_unique_id", "c3sc_hip_comm_create", "c3sc_hip_comm_destroy", "c3sc_hip_comm_world", "c3sc_hip_comm_rank", "c3sc_hip_comm_allgather", "c3sc_hip_cross_set_comm", "c3sc_hip_comm_exchange", "c3sc_hip_cross_options", "c3sc_hip_cross_fetch", "c3sc_hip_cross_free", "c3sc_hip_set_mca", "c3sc_hip_set_model",
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
     "c3sc_hip_bellman_fibers", "c3sc_hip_bellman_fibers_tables", "c3sc_hip_bellman_fibers_tables_host", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
     "c3sc_hip_policy_fibers", "c3sc_hip_policy_fibers_host", "c3sc_hip_policy_fibers_tables", "c3sc_hip_policy_fibers_tables_host",
@@ -214,6 +214,25 @@ class BellmanEngine:
                                                  absorbed_t.data_ptr() if absorbed_t is not None else None,
                                                  stream_ptr), "bellman_fibers")
         return out_t
+
+    def bellman_fibers_all(self, ks, idx_ts, out_ts, stream_ptr: Optional[int] = None, policy_ts=None):
+        """Device API, several varying dimensions of one batch in one call (c3sc_hip_bellman_fibers_all / _policy_fibers_all): one
+        launch where a fused instantiation exists.  idx_ts[s]: int32 CUDA tensor (F_s, d); out_ts[s]: float64 (F_s, N_ks[s])."""
+        import torch
+
+        nk = len(ks)
+        KS = (C.c_int * nk)(*[int(k) for k in ks])
+        FS = (C.c_size_t * nk)(*[int(t.shape[0]) for t in idx_ts])
+        IDX = (C.c_void_p * nk)(*[t.data_ptr() for t in idx_ts])
+        OUT = (C.c_void_p * nk)(*[t.data_ptr() for t in out_ts])
+        if stream_ptr is None:
+            stream_ptr = torch.cuda.current_stream(idx_ts[0].device).cuda_stream
+        if policy_ts is None:
+            self._chk(self.L.c3sc_hip_bellman_fibers_all(self.h, nk, KS, FS, IDX, OUT, None, None, C.c_void_p(stream_ptr)), "bellman_fibers_all")
+        else:
+            POL = (C.c_void_p * nk)(*[t.data_ptr() for t in policy_ts])
+            self._chk(self.L.c3sc_hip_policy_fibers_all(self.h, nk, KS, FS, IDX, POL, OUT, None, C.c_void_p(stream_ptr)), "policy_fibers_all")
+        return out_ts
 
     def stencil_fibers(self, k: int, idx_t, costs_t=None, absorbed_t=None, stream_ptr: Optional[int] = None):
         import torch

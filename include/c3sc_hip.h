@@ -128,6 +128,16 @@ int c3sc_hip_set_variant(c3sc_hip_ctx *ctx, int variant);
  * Asynchronous on `stream`. */
 int c3sc_hip_bellman_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, double *d_out,
                             int32_t *d_uidx, int32_t *d_absorbed, void *stream);
+/* The same for SEVERAL varying dimensions of one batch -- a sweep over independent fiber batches (SURVEY.md 8d's roofline batch, a
+ * rank's share of it) -- as one call: segment s is dimension ks[s] with F[s] fibers, indices d_idx[s] (F[s] x d) and values
+ * d_out[s] (F[s] x N_ks[s], distinct arrays); d_uidx / d_absorbed may be NULL or hold NULL entries.  The per-dimension launches
+ * are independent, so the library spreads them over `stream` and two internal streams, forked from and joined to `stream` by
+ * events: the next dimension's workgroups take the slots the previous dimension's last tiles leave, which d launches on one
+ * stream cannot (car7d: 3 % off a sweep at 2^20 fibers per dimension, 8 % at 2^17; tools/multistream_probe.py).  Stream-ordered
+ * like a single launch; results are those of the per-dimension calls, bit for bit (the same kernels).  C3SC_NO_OVERLAP=1 keeps
+ * everything on `stream`. */
+int c3sc_hip_bellman_fibers_all(c3sc_hip_ctx *ctx, int nk, const int *ks, const size_t *F, const int32_t *const *d_idx, double *const *d_out,
+                                int32_t *const *d_uidx, int32_t *const *d_absorbed, void *stream);
 
 /* Policy evaluation: batched bellman_pi (bellman.c:1702-1886) without its memo tables.  Same stencil and
  * neighbour costs from the uploaded value function (the reference's vf_iteration), but every node applies the
@@ -139,6 +149,9 @@ int c3sc_hip_bellman_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d
  * rates are recomputed (a few dozen flops). */
 int c3sc_hip_policy_fibers(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *d_idx, const int32_t *d_policy,
                            double *d_out, int32_t *d_absorbed, void *stream);
+/* ... and policy evaluation for several varying dimensions in one call (see c3sc_hip_bellman_fibers_all) */
+int c3sc_hip_policy_fibers_all(c3sc_hip_ctx *ctx, int nk, const int *ks, const size_t *F, const int32_t *const *d_idx,
+                               const int32_t *const *d_policy, double *const *d_out, int32_t *const *d_absorbed, void *stream);
 int c3sc_hip_policy_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32_t *h_idx, const int32_t *h_policy,
                                 double *h_out, int32_t *h_absorbed);
 

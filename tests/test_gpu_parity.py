@@ -670,3 +670,43 @@ def test_stationary_node_raises_the_status_flag(oracle):
         eng2 = _engine(w, cores, variant)
         eng2.bellman_fibers_host(1, np.array([[7, 0]], dtype=np.int32))
         assert eng2.status() & 1
+
+
+def test_all_dimensions_call_matches_the_per_dimension_calls():
+    """c3sc_hip_bellman_fibers_all / c3sc_hip_policy_fibers_all: the independent per-dimension launches of one batch spread over the
+    caller's stream and two internal ones.  Same kernels, so the same bits as the per-dimension calls; and stream-ordered like a
+    single launch -- an operation enqueued on the caller's stream right after the call sees every segment's results."""
+    import torch
+
+    w = wl.WORKLOADS["car7d"]().scaled(ngrid=(11, 12, 9, 13, 10, 11, 12), rank=10)
+    cores = wl.synth_cores(w)
+    eng = _engine(w, cores, 3)
+    d = w.dx
+    F = 20000  # a large batch: the pair kernels
+    idx = [torch.from_numpy(wl.synth_fibers(w, k, F)).cuda() for k in range(d)]
+    ref = [eng.bellman_fibers(k, idx[k]).clone() for k in range(d)]
+    torch.cuda.synchronize()
+    out = [torch.zeros_like(r) for r in ref]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for rep in range(3):
+            for o in out:
+                o.zero_()
+            eng.bellman_fibers_all(list(range(d)), idx, out, stream_ptr=stream.cuda_stream)
+            sums = torch.stack([o.sum() for o in out])  # enqueued behind the call on the same stream: must see all of it
+            stream.synchronize()
+            for k in range(d):
+                assert torch.equal(out[k], ref[k]), f"dimension {k}, repetition {rep}"
+            assert torch.equal(sums, torch.stack([r.sum() for r in ref]))
+    # policy evaluation the same way
+    pol = [torch.randint(0, w.ncand, r.shape, dtype=torch.int32, device="cuda") for r in ref]
+    pref = []
+    for k in range(d):
+        o, _ = eng.policy_fibers_host(k, idx[k].cpu().numpy(), pol[k].cpu().numpy())
+        pref.append(o)
+    pout = [torch.zeros_like(r) for r in ref]
+    eng.bellman_fibers_all(list(range(d)), idx, pout, policy_ts=pol)
+    torch.cuda.synchronize()
+    for k in range(d):
+        assert np.array_equal(pout[k].cpu().numpy(), pref[k]), f"policy, dimension {k}"
+    assert eng.status() == 0

@@ -501,11 +501,29 @@ __device__ inline double rcp_newton(double q)
 // (nodeutil.c:267-406) + bellmanrhs (bellman.c:88-112).  V[2m], V[2m+1] = value at the (-,+)
 // neighbour in dim m, V[2D] = value at the node.  The candidate scan keeps the first minimum
 // (strict '<'), as the brute-force c3opt is assumed to.
-template <class Model, int CG = 1, int CGD = 1, class Cand = CandRegs<Model>, bool SPLIT = true>
+// precomputed rates of control-independent dimensions (NoPre: none).  MASK: the dimensions whose (p-, p+) come from pm(m) / pp(m)
+// instead of being formed from the node's drift -- the fiber-pair kernel keeps those that do not depend on the varying
+// dimension per fiber (PairPark)
+struct NoPre {
+    static constexpr unsigned MASK = 0u;
+    __device__ inline double pm(int) const { return 0.0; }
+    __device__ inline double pp(int) const { return 0.0; }
+};
+
+// upwind rates of one dimension (nodeutil.c:289-309): p-+ = t2 sigma^2 / 2 + t max(-+b, 0) with the +-1e-14 dead zone
+__device__ __forceinline__ void upwind_rates(double t, double t2, double b, double sg, double &pm, double &pp)
+{
+    const double half = t2 * (sg * sg) / 2.0;
+    const double tb = t * b;
+    pm = (b < -1e-14) ? half - tb : half;
+    pp = (b > 1e-14) ? half + tb : half;
+}
+
+template <class Model, int CG = 1, int CGD = 1, class Cand = CandRegs<Model>, bool SPLIT = true, class Pre = NoPre>
 __device__ inline double node_backup(const KArgs &A, const double *__restrict__ ro, const double (&x)[Model::D],
                                      const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1], const Cand &cr,
                                      const double (&V)[2 * Model::D + 1], int ab, int &ui, unsigned &st, bool forced = false,
-                                     int fu = -1)
+                                     int fu = -1, const Pre &pre = Pre())
 {
     // forced (wave-uniform) = policy evaluation, bellman_pi (bellman.c:1702-1886): the candidate fu (per lane) is
     // applied instead of the minimiser's; same rates, same bellmanrhs.
@@ -552,10 +570,9 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
 #pragma unroll
         for (int m = 0; m < D; m++) {
             if (!((UM >> m) & 1u)) {
-                const double half = A.t[2 * m + 1] * (s[m] * s[m]) / 2.0;
-                const double tb = A.t[2 * m] * b[m];
-                const double pm = (b[m] < -1e-14) ? half - tb : half;
-                const double pp = (b[m] > 1e-14) ? half + tb : half;
+                double pm, pp;
+                if ((Pre::MASK >> m) & 1u) { pm = pre.pm(m); pp = pre.pp(m); } // a constant of the fiber, formed once with upwind_rates
+                else upwind_rates(A.t[2 * m], A.t[2 * m + 1], b[m], s[m], pm, pp);
                 Q0 += pm;
                 Q0 += pp;
                 PV0 = fma(pm, V[2 * m], PV0);

@@ -132,6 +132,86 @@ __host__ __device__ constexpr int own_right_after(int m)
 template <int K>
 __host__ __device__ constexpr int gvec(int m, int s) { return (m < K ? 2 * m : 2 * (m - 1)) + s; }
 
+// What a fiber parks in LDS for the moment its nodes are finalised (rows of 64 lanes behind the exchange rows).  Without
+// dependency information (Model::HAS_DEPS absent): every fixed coordinate and every table value.  With it: the upwind rates of
+// the control-independent dimensions whose drift does not read the varying dimension are constants of the fiber -- formed once
+// (upwind_rates, the node loop's own arithmetic) and parked INSTEAD of the coordinates / table values only they needed; the node
+// then reads two doubles per such dimension where it formed a drift, two compares, four selects and three flops (car7d: 3.7 of
+// the 5 control-independent dimensions on average over K).
+template <class Model, int K>
+struct PairPark {
+    static constexpr int D = Model::D, NTAB = Model::NTAB;
+    static constexpr unsigned UM = Model::UDEP_MASK, UC = Model::UCONST_MASK, ALL = (1u << D) - 1u;
+    __host__ __device__ static constexpr bool has_deps()
+    {
+        if constexpr (requires { Model::HAS_DEPS; }) return Model::HAS_DEPS;
+        else return false;
+    }
+    __host__ __device__ static constexpr unsigned dep(int m)
+    {
+        if constexpr (has_deps()) return Model::dep_mask(m);
+        else return ALL;
+    }
+    __host__ __device__ static constexpr unsigned cost_dep()
+    {
+        if constexpr (has_deps()) return Model::COST_DEP;
+        else return ALL;
+    }
+    // control-independent dimensions (other than K... K itself may be one too) whose rates are constants of the fiber
+    __host__ __device__ static constexpr unsigned constd()
+    {
+        unsigned c = 0;
+        if (has_deps())
+            for (int m = 0; m < D; m++)
+                if (!((UM >> m) & 1u) && !((dep(m) >> K) & 1u)) c |= 1u << m;
+        return c;
+    }
+    // state dimensions whose coordinate (or tables) a node still needs: the costs', the non-constant control-independent drifts',
+    // the state-dependent controlled drifts'
+    __host__ __device__ static constexpr unsigned need()
+    {
+        unsigned n = cost_dep();
+        for (int m = 0; m < D; m++) {
+            const bool ctl = (UM >> m) & 1u, cst = (constd() >> m) & 1u;
+            if ((!ctl && !cst) || (ctl && !((UC >> m) & 1u))) n |= dep(m);
+        }
+        return n & ALL;
+    }
+    __host__ __device__ static constexpr bool need_x(int m) { return m != K && ((need() >> m) & 1u); }
+    __host__ __device__ static constexpr bool need_t(int t) { return Model::tab_dim(t) != K && ((need() >> Model::tab_dim(t)) & 1u); }
+    __host__ __device__ static constexpr int row_x(int m)
+    {
+        int r = 0;
+        for (int q = 0; q < m; q++) r += need_x(q);
+        return r;
+    }
+    __host__ __device__ static constexpr int nx() { return row_x(D); }
+    __host__ __device__ static constexpr int row_t(int t)
+    {
+        int r = nx();
+        for (int q = 0; q < t; q++) r += need_t(q);
+        return r;
+    }
+    __host__ __device__ static constexpr int nt() { return row_t(NTAB) - nx(); }
+    __host__ __device__ static constexpr int row_pm(int m)
+    {
+        int r = nx() + nt();
+        for (int q = 0; q < m; q++) r += 2 * ((constd() >> q) & 1u);
+        return r;
+    }
+    __host__ __device__ static constexpr int rows() { return row_pm(D); }
+};
+
+// the parked rates as node_backup's Pre
+template <class Model, int K>
+struct PairPre {
+    static constexpr unsigned MASK = PairPark<Model, K>::constd();
+    const double *PX;
+    int lane;
+    __device__ inline double pm(int m) const { return PX[PairPark<Model, K>::row_pm(m) * 64 + lane]; }
+    __device__ inline double pp(int m) const { return PX[(PairPark<Model, K>::row_pm(m) + 1) * 64 + lane]; }
+};
+
 #define FPP_STAMP(slot)                                                   \
     if (C3SC_STAMPS_ON && (A.dbg & 128)) {                                \
         const unsigned long long now__ = clock64();                       \
@@ -384,12 +464,36 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             // the fiber's coordinates and table values are only needed when a node is finalised: parked in LDS
             // (wave 0 writes; both waves hold the same numbers) they do not occupy VGPRs during the partial sums
             if constexpr (H == 0) {
+                typedef PairPark<Model, K> PK;
+                static_assert(PK::rows() <= NP, "parking rows exceed the reserved block");
                 double *PXw = sK + (2 * RP + 2 * (NP + 1) + NP) * 64;
 #pragma unroll
                 for (int m = 0; m < D; m++)
-                    if (m != K) PXw[m * 64 + lane] = x[m];
+                    if (PK::need_x(m)) PXw[PK::row_x(m) * 64 + lane] = x[m];
 #pragma unroll
-                for (int t = 0; t < Model::NTAB; t++) PXw[(D + t) * 64 + lane] = tv[t];
+                for (int t = 0; t < Model::NTAB; t++)
+                    if (PK::need_t(t)) PXw[PK::row_t(t) * 64 + lane] = tv[t];
+                if constexpr (PK::constd() != 0) {
+                    // x[K] and the K-indexed tables are node 0's here (fi[K] = 0): the rates kept do not read them
+                    typename Model::Node nd0;
+                    Model::prep(A.prm, x, tv, nd0);
+                    double u0[Model::DU], cf0[Model::NCF > 0 ? Model::NCF : 1], b0[D], s0[D];
+#pragma unroll
+                    for (int i = 0; i < Model::DU; i++) u0[i] = cr.get_u(i, 0);
+                    cf0[0] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < Model::NCF; i++) cf0[i] = cr.get_cf(i, 0);
+                    Model::drift(A.prm, nd0, x, u0, cf0, b0);
+                    Model::sigma(A.prm, x, u0, s0);
+#pragma unroll
+                    for (int m = 0; m < D; m++)
+                        if ((PK::constd() >> m) & 1u) {
+                            double pm, pp;
+                            upwind_rates(A.t[2 * m], A.t[2 * m + 1], b0[m], s0[m], pm, pp);
+                            PXw[PK::row_pm(m) * 64 + lane] = pm;
+                            PXw[(PK::row_pm(m) + 1) * 64 + lane] = pp;
+                        }
+                }
             }
             pair_barrier();
         }
@@ -547,7 +651,6 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
         double *B1 = B0 + (NP + 1) * 64;  // wave 1 -> wave 0 : P_1(j0)[NP], then v_1(j1)
         double *B2 = B1 + (NP + 1) * 64;  // wave 1 own       : P_1(j1)[NP]
         double *PX = B2 + NP * 64;        // parked per-fiber constants: x[m] (m != K) rows 0..D-1, model tables after
-        static_assert(D + Model::NTAB <= NP, "parking rows exceed the reserved block");
 
         // finalise one node from its assembled stencil (NV neighbour values in gvec order, node value last)
         auto finalize = [&](int jn, const double (&Vt)[NP], double vlo, double vhi) __attribute__((always_inline)) {
@@ -561,10 +664,12 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             double x[D], tv[Model::NTAB > 0 ? Model::NTAB : 1];
             tv[0] = 0.0;
 #pragma unroll
-            for (int m = 0; m < D; m++) x[m] = (m == K) ? nr.x_at(jn) : PX[m * 64 + lane];
+            for (int m = 0; m < D; m++) // a coordinate nothing per node reads any more is not parked (PairPark)
+                x[m] = (m == K) ? nr.x_at(jn) : (PairPark<Model, K>::need_x(m) ? PX[PairPark<Model, K>::row_x(m) * 64 + lane] : 0.0);
 #pragma unroll
             for (int t = 0; t < Model::NTAB; t++)
-                tv[t] = (Model::tab_dim(t) == K) ? nr.tab_at(t, jn) /* wave-uniform */ : PX[(D + t) * 64 + lane];
+                tv[t] = (Model::tab_dim(t) == K) ? nr.tab_at(t, jn) /* wave-uniform */
+                                                 : (PairPark<Model, K>::need_t(t) ? PX[PairPark<Model, K>::row_t(t) * 64 + lane] : 0.0);
             int ab = (obs_fixed & nr.mask_at(jn)) ? -1 : 0;
             if (fiber_abs) ab = 1;
             int lo, hi;
@@ -574,7 +679,8 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
             // FORCED (policy evaluation) is a separate instantiation: as a run-time flag it costs the minimising kernel 4 %
             int fu = -1;
             if constexpr (FORCED) fu = A.forced[(size_t)f * N + jn];
-            const double val = node_backup<Model, FPP_CG, FPP_CGD, CandLds<Model>>(A, ro, x, tv, cr, V, ab, ui, st, FORCED, fu);
+            const PairPre<Model, K> pre{PX, lane};
+            const double val = node_backup<Model, FPP_CG, FPP_CGD, CandLds<Model>, true, PairPre<Model, K>>(A, ro, x, tv, cr, V, ab, ui, st, FORCED, fu, pre);
             FPP_STAMP(9) // control scan
             // lanes past the last fiber duplicate fiber F-1 and store the same numbers to the same place: no
             // divergent branch in the node loop (see node_backup on spilled lane tables)

@@ -56,6 +56,11 @@ struct Dubins3D {
     __device__ static inline double stage(const double *, const double (&)[D], const double *) { return 1.0; }
     __device__ static inline double boundcost(const double *, const double (&)[D]) { return 10.0; }
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+    // state dimensions each drift / diffusion entry reads (its tables count through their tab_dim), and those the costs read:
+    // a rate whose inputs do not include the varying dimension is a constant of the fiber (kernel_fiber_pair.hpp: PairPark)
+    static constexpr bool HAS_DEPS = true;
+    __host__ __device__ static constexpr unsigned dep_mask(int m) { return m < 2 ? 1u << 2 : 0u; }
+    static constexpr unsigned COST_DEP = 0u;
 };
 
 // examples/skidding_car/scar.c:40-169 (order = {0,1,2,3})
@@ -126,6 +131,13 @@ struct Car7D {
     }
     __device__ static inline double boundcost(const double *, const double (&)[D]) { return 10.0; }
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+    // see Dubins3D: b0, b1 read v and theta; b2 omega; b3 a; b4 v, omega, delta; the stage cost x and y
+    static constexpr bool HAS_DEPS = true;
+    __host__ __device__ static constexpr unsigned dep_mask(int m)
+    {
+        return m < 2 ? (1u << 2) | (1u << 3) : (m == 2 ? 1u << 4 : (m == 3 ? 1u << 6 : (m == 4 ? (1u << 3) | (1u << 4) | (1u << 5) : 0u)));
+    }
+    static constexpr unsigned COST_DEP = 0x3u;
 };
 
 // examples/lqgnd/lqgnd.c:80-198 (dim = 2 is examples/lqg2d_new/lqg2d.c:72-153); prm = {dim, sig_even, sig_odd}
@@ -178,6 +190,10 @@ struct LqgNd {
     }
     __device__ static inline double boundcost(const double *, const double (&)[D]) { return 100.0; }
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+    // see Dubins3D: an even equation reads the next coordinate; the stage cost reads every coordinate
+    static constexpr bool HAS_DEPS = true;
+    __host__ __device__ static constexpr unsigned dep_mask(int m) { return (m % 2) == 0 ? 1u << ((m + 1 < DIM) ? m + 1 : m) : 0u; }
+    static constexpr unsigned COST_DEP = (1u << DIM) - 1u;
 };
 
 // examples/double_int/double_int.c:80-157; prm = {dim, sig, sig_last, stage_mode}

@@ -660,6 +660,7 @@ static int launch_bellman(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx
         declined.push_back(e);
     }
     g_launches++;
+    c->status_cache_valid = false;
     HIPCHK(c, he);
     return C3SC_OK;
 }
@@ -753,6 +754,7 @@ static int launch_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, co
     arm_memo(c, e, A);
     LaunchIO io{c->arena, d_idx, d_out, nullptr, d_absorbed, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
     g_launches++;
+    c->status_cache_valid = false;
     const hipError_t he = e->fn(A, io);
     if (he == hipErrorNotSupported) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: no box-minimiser instantiation for this model");
     HIPCHK(c, he);
@@ -860,6 +862,7 @@ static int launch_tables(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx,
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_out, d_uidx, d_absorbed, nullptr, nullptr, d_tables, d_costs2, (hipStream_t)stream};
     g_launches++;
+    c->status_cache_valid = false;
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
 }
@@ -944,6 +947,7 @@ int c3sc_hip_stencil_fibers_nb(c3sc_hip_ctx *c, int k, size_t F, const int32_t *
     c->last_kernel = e->name;
     LaunchIO io{c->arena, d_idx, d_costs, nullptr, d_absorbed, d_nb_fixed, d_nb_vary, nullptr, nullptr, (hipStream_t)stream};
     g_launches++;
+    c->status_cache_valid = false;
     HIPCHK(c, e->fn(A, io));
     return C3SC_OK;
 }
@@ -1108,8 +1112,12 @@ int c3sc_hip_get_status(c3sc_hip_ctx *c, unsigned *flags, int clear)
 {
     if (!c || !flags) return C3SC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(flags, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (clear && *flags) HIPCHK(c, hipMemset(c->d_status, 0, sizeof(unsigned))); /* nothing to clear otherwise */
+    if (c->status_cache_valid) *flags = c->status_cache; /* read with the last cross fetch; nothing was launched since */
+    else HIPCHK(c, hipMemcpy(flags, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (clear && *flags) { /* nothing to clear otherwise */
+        HIPCHK(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
+        c->status_cache = 0;
+    }
     return C3SC_OK;
 }
 

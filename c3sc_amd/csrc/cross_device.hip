@@ -529,6 +529,8 @@ struct c3sc_cross_dev {
     char *stage = nullptr;
     size_t stage_bytes = 0;
     bool lds_optin = false;
+    bool stage_fresh = false;                    // the pinned block holds the sets, cores and counters of the device as they are now
+    unsigned long long pending[4] = {0, 0, 0, 0}; // counters read from the device but not handed to the caller yet
     int warm = 1;
     double swap_tol = 0.05;
 };
@@ -642,6 +644,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
         HIPCHK(c, hipMalloc((void **)&x->slab, off));
         x->slab_bytes = off;
     }
+    x->stage_fresh = false;
     x->gen++; // every set-up starts a new generation of cached step values: the layout, the ranks or the sweep changed
     HIPCHK(c, hipMemsetAsync(x->slab + x->off_flags, 0, MAXD * (sizeof(int) + sizeof(unsigned long long)) + 64, nullptr));
     const size_t need_stage = x->sets_bytes + x->cores_bytes + 64 + 2 * MAXD * sizeof(CoreArgs) + 64;
@@ -788,6 +791,7 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
 {
     if (!c || !c->cross || c->cross->d == 0) return fail(c, C3SC_ERR_ARG, "cross_iteration: cross_setup first");
     c3sc_cross_dev *x = c->cross;
+    x->stage_fresh = false;
     const int d = x->d;
     hipStream_t st = (hipStream_t)stream;
     c3sc_hip_comm *comm = c->shard_comm;
@@ -865,6 +869,8 @@ int c3sc_hip_cross_iteration_pi(c3sc_hip_ctx *c, c3sc_hip_ctx *policy_ctx, long 
 /* The confirming iteration in one launch (k_cross_confirm): valid after a complete c3sc_hip_cross_iteration[_pi] -- every
  * step then holds the fiber values of its current index sets.  *confirmed = 1: all 2 d steps reproduced their index sets; the
  * cores of the iteration are in place (fetch them), nothing else changed.  *confirmed = 0: run the ordinary iteration. */
+static int stage_download(c3sc_hip_ctx *c, const void *extra, void *extra_host, size_t extra_bytes, hipStream_t st);
+
 int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
 {
     if (!c || !c->cross || c->cross->d == 0 || !confirmed) return fail(c, C3SC_ERR_ARG, "cross_confirm: cross_setup first");
@@ -906,10 +912,14 @@ int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
     else
         hipLaunchKernelGGL(k_cross_confirm<false>, dim3(2 * d), dim3(NT), 0, st, (const CoreArgs *)(x->slab + x->off_steps));
     HIPCHK(c, hipGetLastError());
-    int flag = 1;
-    HIPCHK(c, hipMemcpyAsync(&flag, mismatch, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    *confirmed = flag == 0;
+    // the flag and, in the same wait, everything a successful confirmation is followed by (c3sc_hip_cross_fetch then copies from
+    // the pinned block); after a mismatch the block is stale and the counters it brought wait in `pending`
+    int *hflag = (int *)(x->stage + x->sets_bytes + x->cores_bytes + 4 * sizeof(unsigned long long) + sizeof(unsigned) + 4);
+    *hflag = 1;
+    const int rc = stage_download(c, mismatch, hflag, sizeof(int), st);
+    if (rc != C3SC_OK) return rc;
+    *confirmed = *hflag == 0;
+    if (!*confirmed) x->stage_fresh = false;
     return C3SC_OK;
 }
 
@@ -926,6 +936,7 @@ int c3sc_hip_cross_speculate(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long polic
     if (!c || !c->cross || c->cross->d == 0 || !confirmed) return fail(c, C3SC_ERR_ARG, "cross_speculate: cross_setup first");
     *confirmed = 0;
     c3sc_cross_dev *x = c->cross;
+    x->stage_fresh = false;
     if (c->shard_comm) return C3SC_OK;
     const int d = x->d;
     hipStream_t st = (hipStream_t)stream;
@@ -944,24 +955,45 @@ int c3sc_hip_cross_speculate(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long polic
 
 /* wait for the iteration and bring back: cores (working layout G[a + r_k (j + N_k b)]), both families of index sets, and
  * info = {nodes stored in the memo since the last fetch, rank-deficient factorisation seen, maxvol swaps, memo overflow} */
+// device -> pinned block: index sets, cores, the four counters (then cleared on the device) and the context's status word; one
+// wait.  `extra` / `extra_bytes`: one more small device word to bring along (the confirming launch's mismatch flag).
+static int stage_download(c3sc_hip_ctx *c, const void *extra, void *extra_host, size_t extra_bytes, hipStream_t st)
+{
+    c3sc_cross_dev *x = c->cross;
+    const size_t nb = x->sets_bytes + x->cores_bytes;
+    unsigned *hstat = (unsigned *)(x->stage + nb + 4 * sizeof(unsigned long long));
+    HIPCHK(c, hipMemcpyAsync(x->stage, x->slab, nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(x->stage + nb, x->counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemsetAsync(x->counters, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(c, hipMemcpyAsync(hstat, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (extra) HIPCHK(c, hipMemcpyAsync(extra_host, extra, extra_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const unsigned long long *cnt = (const unsigned long long *)(x->stage + nb);
+    for (int i = 0; i < 4; i++) x->pending[i] += cnt[i];
+    c->status_cache = *hstat;
+    c->status_cache_valid = true; // until the next launch through this context
+    x->stage_fresh = true;
+    return C3SC_OK;
+}
+
 int c3sc_hip_cross_fetch(c3sc_hip_ctx *c, double *const *h_cores, int32_t *const *h_I, int32_t *const *h_J, unsigned long long *info,
                          void *stream)
 {
     if (!c || !c->cross) return fail(c, C3SC_ERR_ARG, "cross_fetch: cross_setup first");
     c3sc_cross_dev *x = c->cross;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t nb = x->sets_bytes + x->cores_bytes;
-    HIPCHK(c, hipMemcpyAsync(x->stage, x->slab, nb, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(x->stage + nb, x->counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemsetAsync(x->counters, 0, 4 * sizeof(unsigned long long), st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (!x->stage_fresh) { // a confirming launch that succeeded has brought everything over already
+        const int rc = stage_download(c, nullptr, nullptr, 0, (hipStream_t)stream);
+        if (rc != C3SC_OK) return rc;
+    }
+    x->stage_fresh = false;
     const int d = x->d;
     for (int k = 0; k < d; k++) {
         if (h_cores) std::memcpy(h_cores[k], x->stage + x->offG[k], (size_t)x->r[k] * x->N[k] * x->r[k + 1] * sizeof(double));
         if (h_I) std::memcpy(h_I[k], x->stage + x->offI[k], (size_t)x->r[k] * k * sizeof(int32_t));
         if (h_J) std::memcpy(h_J[k], x->stage + x->offJ[k], (size_t)x->r[k + 1] * (d - 1 - k) * sizeof(int32_t));
     }
-    if (info) std::memcpy(info, x->stage + nb, 4 * sizeof(unsigned long long));
+    if (info) std::memcpy(info, x->pending, 4 * sizeof(unsigned long long));
+    std::memset(x->pending, 0, sizeof(x->pending));
     return C3SC_OK;
 }
 

@@ -48,6 +48,10 @@ struct c3sc_hip_ctx {
     long qimgL_off[c3sc::MAXD] = {0}, qimgR_off[c3sc::MAXD] = {0}; // fiber-quad-duo LDS images (node stride elems + 2)
     int obs_off = 0, cands_off = 0, tab_off[4] = {0, 0, 0, 0}, cfeat_off = 0;
     unsigned *d_status = nullptr;
+    // the status word as of the last c3sc_hip_cross_fetch, valid until the next launch through this context: the solver reads the
+    // status once per sweep, right after the fetch that already waited for the stream -- no second device round trip
+    unsigned status_cache = 0;
+    bool status_cache_valid = false;
     unsigned long long *d_dbg = nullptr; // diagnostic stamps (C3SC_DBG & 128)
     int variant = C3SC_VARIANT_AUTO;
     const char *last_kernel = "";

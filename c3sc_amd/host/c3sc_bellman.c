@@ -1328,6 +1328,9 @@ static struct ApproxArgs *device_rank_cap(struct C3Control *c, struct ApproxArgs
 struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct ApproxArgs *apargs, struct c3Opt *opt, int verbose,
                                  size_t *nevals)
 { /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
+    const int prof = getenv("C3SC_PROFILE") != NULL;
+    const double t_step = prof ? now_s() : 0.0;
+    double t_sync = 0.0, t_interp = 0.0;
     struct VIparam *vi = c3control_begin_vi(c, vf, opt);
     struct ApproxArgs *aa = device_rank_cap(c, apargs);
     struct ValueF *next;
@@ -1339,17 +1342,24 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
     const int sharded = (c->shard_world > 1 && c->shard_exchange != NULL) && !rccl;
     const int checked = c->dp->model_checked || c->dp->stagecost == NULL || c->dp->boundcost == NULL || c->dp->obscost == NULL;
     if (dp_has_device_model(c->dp) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL) {
+        const double t0 = prof ? now_s() : 0.0;
         struct c3sc_hip_ctx *ctx = sync_device(vi);
         c3sc_hip_cross_set_comm(ctx, rccl ? c->shard_comm : NULL);
         size_t nodes = 0;
+        const double t1 = prof ? now_s() : 0.0;
         next = c3sc_interp_device(c->dx, ctx, !c3opt_is_bruteforce(opt), c->ngrid, c->xgrid, vf, aa, verbose, &nodes, NULL, 0, NULL);
+        if (prof) { t_sync = t1 - t0; t_interp = now_s() - t1; }
         vi->nnode_evals += nodes;
         vi->nstate_evals += nodes;
     } else
         next = c3sc_interp_idx_sharded(c->dx, bellman_vi_batch_idx, vi, c->ngrid, c->xgrid, vf, aa, verbose, c->shard_world,
                                        c->shard_rank, c->shard_exchange, c->shard_xarg, vi_absorb_foreign);
     approx_args_free(aa);
+    const double t_end0 = prof ? now_s() : 0.0;
     c3control_end_vi(c, vi, nevals);
+    if (prof)
+        fprintf(stderr, "c3sc step_vi profile: total %.3f ms = begin %.3f, value upload (sync_device) %.3f, interpolation %.3f, end (status read) %.3f\n",
+                1e3 * (now_s() - t_step), 1e3 * (t_end0 - t_step - t_sync - t_interp), 1e3 * t_sync, 1e3 * t_interp, 1e3 * (now_s() - t_end0));
     return next;
 }
 

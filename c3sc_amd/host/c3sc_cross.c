@@ -1009,6 +1009,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                  * writing their index sets -- and, if so, has the iteration's cores in place: same kernels, same inputs, same
                  * bits as the sequential iteration, which then need not run. */
                 int ok = 0;
+                const double t_cf = tnow();
                 if (c3sc_hip_cross_confirm(c.dev, &ok, NULL) != 0) DIE("c3sc_hip_cross_confirm: %s", c3sc_hip_last_error(c.dev));
                 if (ok) {
                     t2 = tt_alloc(d, c.N, c.r);
@@ -1017,9 +1018,10 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                     if (info[1]) c.deficient = 1;
                     for (size_t k = 0; k < d; k++) { c.nfibers += 2 * c.r[k] * c.r[k + 1]; c.dev_requested += 2 * c.r[k] * c.r[k + 1] * c.N[k]; }
                 }
+                g_tc[1] += tnow() - t_cf;
             }
             if (t2 != NULL) { /* confirmed: sets unchanged by construction */ }
-            else if (c.dev) t2 = cross_iteration_device(&c);
+            else if (c.dev) TIMED(0, t2 = cross_iteration_device(&c));
             else {
                 struct tt *t1 = cross_sweep_lr(&c);
                 t2 = cross_sweep_rl(&c);
@@ -1092,7 +1094,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     vf->elem_class = elem_class;
     if (getenv("C3SC_PROFILE")) {
         g_tc[5] = tnow() - t_all;
-        fprintf(stderr, "c3sc cross profile: total %.2f ms = fibers (callback + gather, or whole device iterations) %.2f, (unused) %.2f, lu + maxvol %.2f, convergence check %.2f, rounding %.2f\n",
+        fprintf(stderr, "c3sc cross profile: total %.2f ms = fibers (callback + gather, or whole device iterations incl. their fetch) %.2f, confirming launch + fetch %.2f, lu + maxvol %.2f, convergence check %.2f, rounding %.2f\n",
                 1e3 * g_tc[5], 1e3 * g_tc[0], 1e3 * g_tc[1], 1e3 * g_tc[2], 1e3 * g_tc[3], 1e3 * g_tc[4]);
     }
     memset(g_tc, 0, sizeof(g_tc));

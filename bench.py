@@ -429,15 +429,19 @@ def main():
         import ctypes as C
 
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idbuf = (C.c_char * 128)()
-            if eng.L.c3sc_hip_comm_unique_id(idbuf) != 0:
-                raise SystemExit("c3sc_hip_comm_unique_id failed")
-            idt.copy_(torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        idbytes = (C.c_char * 128).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
+        # every rank first shows that it can open librccl and make an id (rank 0's is the one used): a rank that cannot must not
+        # leave the others waiting inside the communicator's collective initialisation
+        idbuf = (C.c_char * 128)()
+        can = torch.tensor([1 if eng.L.c3sc_hip_comm_unique_id(idbuf) == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        rc_comm = 1
         comm = C.c_void_p()
-        rc_comm = eng.L.c3sc_hip_comm_create(eng.h, C.c_int(world), C.c_int(rank), idbytes, C.byref(comm))
+        if int(can.item()) == 1:
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            idbytes = (C.c_char * 128).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
+            rc_comm = eng.L.c3sc_hip_comm_create(eng.h, C.c_int(world), C.c_int(rank), idbytes, C.byref(comm))
         # every rank must take the same route: agree on whether all communicators came up; if not, the process group's own
         # all-gather (RCCL through torch.distributed) carries the sweep's collective instead
         okt = torch.tensor([1 if rc_comm == 0 else 0], dtype=torch.int32, device=dev)

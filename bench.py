@@ -529,6 +529,8 @@ def main():
     # dominant kernel: average launch duration from the HIP events recorded on the launch stream
     kms = [e0.elapsed_time(e1) / (d if kk < 0 else 1) for (kk, e0, e1) in ev]  # --overlap: span of a step's launches / their number
     avg_ms = float(np.mean(kms))
+    # per varying dimension (one kernel instantiation each): what a rocprofv3 kernel_stats row of the same run is compared with
+    ms_by_dim = [float(np.mean([e0.elapsed_time(e1) for (kk, e0, e1) in ev if kk == k])) for k in range(d)] if not args.overlap else None
     Wf = wl.algorithmic_flops_per_node(w)
     nodes_per_launch = nodes_per_step_loc / d
     achieved_tflops = Wf * nodes_per_launch / (avg_ms * 1e-3) / 1e12
@@ -566,7 +568,7 @@ def main():
                 "frac": achieved_tflops / FP64_PEAK_TFLOPS,
                 "traffic": pm["traffic"] if pm else None, "traffic_unit": "bytes/launch", "traffic_source": pm["source"] if pm else None,
                 "algorithmic_bytes_per_launch": bytes_per_node * nodes_per_launch,
-                "kernel": kern, "kernel_resources": kres, "avg_launch_ms": avg_ms, "launches": len(kms),
+                "kernel": kern, "kernel_resources": kres, "avg_launch_ms": avg_ms, "launches": len(kms), "launch_ms_by_dim": ms_by_dim,
                 "algorithmic_flops_per_node": Wf, "nodes_per_launch": nodes_per_launch,
                 # what the kernel actually executes (fold-once algebra), from the SQ_INSTS_VALU_*_F64 / MFMA counters of the
                 # committed PMC pass of this command; null when no such pass is committed for this kernel and batch

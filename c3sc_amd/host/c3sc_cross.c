@@ -373,9 +373,11 @@ static double tt_frob_of_core0(const struct tt *t)
     return sqrt(s);
 }
 
-/* TT rounding to relative accuracy eps in the nodal Frobenius norm (ranks never exceed maxrank) */
-C3SC_CLONES static void tt_round(struct tt *t, double eps)
+/* TT rounding to relative accuracy eps in the nodal Frobenius norm, ranks cut to rcap at most (rcap = 0: no cap).  eps_ranks (d + 1
+ * entries, or NULL) returns the ranks the accuracy alone asks for: the rank adaptation kicks a cross rank that eps does not reduce. */
+C3SC_CLONES static void tt_round(struct tt *t, double eps, size_t rcap, size_t *eps_ranks)
 {
+    if (eps_ranks) memcpy(eps_ranks, t->r, (t->d + 1) * sizeof(size_t));
     if (t->d < 2) return;
     tt_orthogonalize_rl(t);
     const double nrm = tt_frob_of_core0(t);
@@ -416,6 +418,8 @@ C3SC_CLONES static void tt_round(struct tt *t, double eps)
         size_t rnew = nn;
         double tail = 0.0;
         while (rnew > 1 && tail + S[rnew - 1] * S[rnew - 1] <= delta * delta) { tail += S[rnew - 1] * S[rnew - 1]; rnew--; }
+        if (eps_ranks) eps_ranks[k + 1] = rnew;
+        if (rcap > 0 && rnew > rcap) rnew = rcap;
         /* G_k <- U[:, :rnew]; G_{k+1} <- diag(S) V^T [:rnew, :] G_{k+1} */
         double *Gk = xcalloc(m * rnew, sizeof(double));
         for (size_t j = 0; j < rnew; j++) {
@@ -923,6 +927,24 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     for (size_t k = 0; k < d; k++) if (N[k] < minN) minN = N[k];
     size_t maxrank = approx_args_get_maxrank(aargs);
     if (maxrank >= minN) maxrank = minN; /* valuefunc.c:625-631 */
+    /* Ranks of the cross approximation itself (approx_args_set_crossrank, C3SC_CROSS_RANK_FACTOR): above maxrank the result is cut
+     * back to maxrank by the TT-SVD at the end -- an orthogonal projection onto the dominant subspaces of a more accurate
+     * interpolant instead of an interpolation through maxrank fibers per core. */
+    size_t crank = approx_args_get_crossrank(aargs);
+    if (getenv("C3SC_CROSS_RANK_FACTOR")) crank = (size_t)ceil(atof(getenv("C3SC_CROSS_RANK_FACTOR")) * (double)maxrank);
+    if (crank < maxrank) crank = maxrank;
+    if (dev != NULL && crank > 32) crank = 32 > maxrank ? 32 : maxrank; /* c3sc_hip_cross_setup: ranks up to 32 */
+    /* per bond: the reference's clamp to min N (Q12) holds for maxrank; an elevated cross rank is bounded by the sizes of the two
+     * sides of its unfolding only */
+    size_t *crk = xcalloc(d + 1, sizeof(size_t));
+    for (size_t k = 1; k < d; k++) {
+        double left = 1.0, right = 1.0;
+        for (size_t m = 0; m < k; m++) left *= (double)N[m];
+        for (size_t m = k; m < d; m++) right *= (double)N[m];
+        const double side = left < right ? left : right;
+        crk[k] = crank > maxrank ? ((double)crank < side ? crank : (size_t)side) : maxrank;
+        if (crk[k] < maxrank) crk[k] = maxrank < (size_t)side ? maxrank : (size_t)side;
+    }
     const size_t kick = approx_args_get_kickrank(aargs);
     const int adapt = approx_args_get_adapt(aargs);
     const double cross_tol = approx_args_get_cross_tol(aargs), round_tol = approx_args_get_round_tol(aargs);
@@ -950,7 +972,11 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     for (size_t k = 1; k < d; k++) c.r[k] = base;
     if (vref != NULL && adapt == 1) { /* valuefunc.c:636-649 */
         const size_t *rr = valuef_get_ranks(vref);
-        for (size_t k = 1; k < d; k++) c.r[k] = (rr[k] + 1) >= maxrank ? maxrank : rr[k] + 1;
+        for (size_t k = 1; k < d; k++) {
+            c.r[k] = (rr[k] + 1) >= maxrank ? maxrank : rr[k] + 1;
+            /* an elevated cross rank is not rebuilt by kicks in every sweep: the previous interpolation's own ranks are the start */
+            if (crank > maxrank && vref->isl != NULL && vref->nisl[k] > c.r[k]) c.r[k] = vref->nisl[k] > crk[k] ? crk[k] : vref->nisl[k];
+        }
     }
     c.I = xcalloc(d + 1, sizeof(int *));
     c.J = xcalloc(d + 1, sizeof(int *));
@@ -1054,7 +1080,8 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
         tt_free(prev);
         /* rounding; if a rank survives untouched and may still grow, kick it and cross again */
         struct tt *rounded = tt_copy(cur);
-        TIMED(4, tt_round(rounded, round_tol));
+        size_t *eps_r = xcalloc(d + 1, sizeof(size_t));
+        TIMED(4, tt_round(rounded, round_tol, maxrank, eps_r));
         int kicked = 0;
         if (adapt == 1) {
             /* Rounding dropped every rank, so the rule below would stop here.  If the last cross iteration worked on
@@ -1064,7 +1091,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             int confirm = 0;
             if (c.deficient) {
                 int dropped = 1, room = 0;
-                for (size_t k = 1; k < d; k++) { if (rounded->r[k] >= c.r[k]) dropped = 0; if (c.r[k] < maxrank) room = 1; }
+                for (size_t k = 1; k < d; k++) { if (eps_r[k] >= c.r[k]) dropped = 0; if (c.r[k] < crk[k]) room = 1; }
                 if (dropped && room) {
                     double r2 = 0.0;
                     const double accept = 10.0 * (cross_tol > round_tol ? cross_tol : round_tol);
@@ -1072,8 +1099,8 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                 }
             }
             for (size_t k = 1; k < d; k++)
-                if ((rounded->r[k] >= c.r[k] || confirm) && c.r[k] < maxrank) {
-                    const size_t rn = (c.r[k] + kick) >= maxrank ? maxrank : c.r[k] + kick;
+                if ((eps_r[k] >= c.r[k] || confirm) && c.r[k] < crk[k]) {
+                    const size_t rn = (c.r[k] + kick) >= crk[k] ? crk[k] : c.r[k] + kick;
                     int *In = resize_tuples(c.I[k], c.r[k], rn, k, N, 3 + round);
                     int *Jn = resize_tuples(c.J[k - 1], c.r[k], rn, d - k, N + k, 5 + round);
                     free(c.I[k]); c.I[k] = In;
@@ -1083,6 +1110,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                     c.dev_fresh = 1;
                 }
         }
+        free(eps_r);
         tt_free(best);
         best = rounded;
         tt_free(cur);
@@ -1116,7 +1144,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     }
     tt_free(best);
     for (size_t k = 0; k < d; k++) { free(c.I[k]); free(c.J[k]); }
-    free(c.I); free(c.J); free(c.r);
+    free(c.I); free(c.J); free(c.r); free(crk);
     if (dev != NULL) { dev->nodes = c.dev_nodes; dev->requested = c.dev_requested; }
     return vf;
 }

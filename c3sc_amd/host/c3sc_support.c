@@ -358,13 +358,14 @@ double *htable_get_element(struct HTable *ht, char *key, size_t *N)
 }
 
 /* ------------------------------------------------------------------------------ ApproxArgs */
-struct ApproxArgs { double cross_tol, round_tol; size_t kickrank, startrank, maxrank; int adapt; enum function_class fc; };
+struct ApproxArgs { double cross_tol, round_tol; size_t kickrank, startrank, maxrank, crossrank; int adapt; enum function_class fc; };
 
 struct ApproxArgs *approx_args_init(void)
 {
     struct ApproxArgs *a = xmalloc(sizeof(*a));
     a->cross_tol = 1e-10; a->round_tol = 1e-10; a->kickrank = 10; a->startrank = 5; a->maxrank = 40; /* util.c:124-130 */
     a->adapt = 1; a->fc = LINELM;
+    a->crossrank = 0;
     return a;
 }
 void approx_args_free(struct ApproxArgs *a) { free(a); }
@@ -381,6 +382,11 @@ size_t approx_args_get_maxrank(const struct ApproxArgs *a) { return a->maxrank; 
 void approx_args_set_startrank(struct ApproxArgs *a, size_t v) { a->startrank = v; }
 size_t approx_args_get_startrank(const struct ApproxArgs *a) { return a->startrank; }
 void approx_args_set_adapt(struct ApproxArgs *a, int v) { a->adapt = v; }
+/* new: the cross approximation may run at ranks up to `crossrank` (> maxrank) and is then rounded to maxrank by the TT-SVD --
+ * an orthogonal projection, so the result is close to the best train of that rank where interpolation through maxrank fibers
+ * is 2-4 times further away.  0 = maxrank (the reference's scheme: valuefunc.c:625-649). */
+void approx_args_set_crossrank(struct ApproxArgs *a, size_t v) { a->crossrank = v; }
+size_t approx_args_get_crossrank(const struct ApproxArgs *a) { return a->crossrank; }
 int approx_args_get_adapt(const struct ApproxArgs *a) { return a->adapt; }
 
 size_t uniform_stride(size_t N, size_t M)

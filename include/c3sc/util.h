@@ -26,6 +26,9 @@ void approx_args_set_startrank(struct ApproxArgs *, size_t);
 size_t approx_args_get_startrank(const struct ApproxArgs *);
 void approx_args_set_adapt(struct ApproxArgs *, int);
 int approx_args_get_adapt(const struct ApproxArgs *);
+/* new (no reference counterpart): ranks of the cross approximation before its result is rounded to maxrank; 0 = maxrank */
+void approx_args_set_crossrank(struct ApproxArgs *, size_t);
+size_t approx_args_get_crossrank(const struct ApproxArgs *);
 size_t uniform_stride(size_t N, size_t M); /* util.c:995-1006 */
 
 #include <stdio.h>

@@ -57,6 +57,8 @@ def _interp(L, fl, func, grids, vref=None, batch=False, **kw):
     L.approx_args_set_startrank(aa, C.c_size_t(kw.get("startrank", 2)))
     L.approx_args_set_maxrank(aa, C.c_size_t(kw.get("maxrank", 12)))
     L.approx_args_set_adapt(aa, C.c_int(kw.get("adapt", 1)))
+    if "crossrank" in kw:
+        L.approx_args_set_crossrank(aa, C.c_size_t(kw["crossrank"]))
     if batch:
         cb = BATCH_FN(many)
         vf = C.c_void_p(L.valuef_interp_batch(C.c_size_t(d), cb, None, fl.sp(N), gp, vref, aa, 0))
@@ -109,6 +111,54 @@ def test_cross_rank_adaptation_and_warm_start():
     assert 0 < d < 0.2
     L.valuef_destroy(vf)
     L.valuef_destroy(vf2)
+
+
+def test_elevated_cross_rank_rounded_to_the_cap_is_near_the_best_train():
+    """approx_args_set_crossrank: a function whose TT ranks exceed the cap (a kinked, non-separable function -- the value functions
+    of exit-time problems look like this).  Interpolation through maxrank fibers per core is a multiple of the best rank-capped
+    train's error away; the cross approximation at 2x / 3x the cap, cut back to the cap by the TT-SVD, must be within 1.5x of the
+    TT-SVD truncation of the full tensor and better than plain interpolation at the cap."""
+    L, fl = _lib()
+    L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
+    n, d, cap = 13, 4, 5
+    grids = [np.linspace(-1.0, 1.0, n) + 0.01 * m for m in range(d)]
+    f = lambda X: np.abs(X[:, 0] + 0.7 * X[:, 1] - 0.5 * X[:, 2] + 0.3 * X[:, 3]) + 0.2 * np.sqrt(0.1 + (X ** 2).sum(axis=1))
+    mesh = np.stack(np.meshgrid(*grids, indexing="ij"), axis=-1).reshape(-1, d)
+    full = f(mesh).reshape((n,) * d)
+
+    def ttsvd_err(T, r):
+        A, r0, cores = T.copy(), 1, []
+        for m in range(d - 1):
+            A = A.reshape(r0 * n, -1)
+            U, S, Vt = np.linalg.svd(A, full_matrices=False)
+            rr = min(r, len(S))
+            cores.append(U[:, :rr].reshape(r0, n, rr))
+            A, r0 = S[:rr, None] * Vt[:rr], rr
+        cores.append(A.reshape(r0, n, 1))
+        acc = cores[0]
+        for G in cores[1:]:
+            acc = np.tensordot(acc, G, axes=([acc.ndim - 1], [0]))
+        return np.linalg.norm(acc.reshape(T.shape) - T) / np.linalg.norm(T)
+
+    def dense(vf, ranks):
+        pp = L.valuef_get_cores(vf)
+        acc = np.ones((1, 1))
+        for m in range(d):
+            G = np.ctypeslib.as_array(pp[m], shape=(n * ranks[m] * ranks[m + 1],)).reshape(n, ranks[m + 1], ranks[m]).transpose(2, 0, 1)
+            acc = np.tensordot(acc, G, axes=([acc.ndim - 1], [0]))
+        return acc.reshape((n,) * d)
+
+    best = ttsvd_err(full, cap)
+    errs = {}
+    for cr in (0, 2 * cap, 3 * cap):
+        vf, ranks, calls = _interp(L, fl, f, grids, startrank=cap, kickrank=cap, maxrank=cap, crossrank=cr, cross_tol=1e-8, round_tol=1e-8, batch=True)
+        assert max(ranks) <= cap, ranks  # the result never exceeds maxrank, whatever the cross ran at
+        errs[cr] = np.linalg.norm(dense(vf, ranks) - full) / np.linalg.norm(full)
+        L.valuef_destroy(vf)
+    print(f"best rank-{cap} train {best:.3e}; interpolation at the cap {errs[0]:.3e}; cross at {2 * cap} / {3 * cap} rounded to {cap}: "
+          f"{errs[2 * cap]:.3e} / {errs[3 * cap]:.3e}")
+    assert errs[2 * cap] < errs[0] and errs[3 * cap] < errs[0]
+    assert errs[3 * cap] <= 1.5 * best
 
 
 def test_continuous_norms_and_offgrid_eval():

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 FIBER_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 
-def _setup(w, maxrank=12, startrank=3, round_tol=1e-9, kick=3):
+def _setup(w, maxrank=12, startrank=3, round_tol=1e-9, kick=3, crossrank=0):
     import facade_lib
 
     L = facade_lib.lib()
@@ -36,6 +36,8 @@ def _setup(w, maxrank=12, startrank=3, round_tol=1e-9, kick=3):
     L.approx_args_set_kickrank(aa, C.c_size_t(kick))
     L.approx_args_set_startrank(aa, C.c_size_t(startrank))
     L.approx_args_set_maxrank(aa, C.c_size_t(maxrank))
+    if crossrank:
+        L.approx_args_set_crossrank(aa, C.c_size_t(crossrank))  # the cross approximation runs above maxrank, its result is rounded to it
     return L, facade_lib, ctl, aa
 
 
@@ -252,7 +254,9 @@ def test_speculative_first_iteration_same_bits_and_actually_used(name, kw, aargs
     ("car7d", dict(), dict(maxrank=10, kick=2)),                       # the bench's vi_sweep configuration: 41^7, rank cap 10
     ("dubins3d", dict(ngrid=(41, 41, 41), rank=4), dict(maxrank=12, kick=3)),
     ("lqg2d", dict(ngrid=(60, 60), rank=4), dict(maxrank=20, kick=5)),  # core steps of up to 60 x 20 x 20: the factorisation leaves LDS
-], ids=["car7d-small", "car7d-41", "dubins3d", "lqg2d"])
+    ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=2, crossrank=10)),  # cross at rank 10, rounded to 5
+    ("car7d", dict(), dict(maxrank=10, kick=4, crossrank=20)),          # the bench's vi_iters_to_tol configuration: cross rank 20 -> 10
+], ids=["car7d-small", "car7d-41", "dubins3d", "lqg2d", "car7d-small-crossrank10", "car7d-41-crossrank20"])
 def test_device_resident_cross_iterations_match_the_host_driver(name, kw, aargs):
     """c3control_step_vi with whole cross iterations on the device (c3sc_hip_cross_*: fiber index lists, Bellman launches, node
     memo, pivoted factorisation + maxvol of every core step on one stream) against the same sweeps driven from the host

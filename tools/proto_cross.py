@@ -110,10 +110,31 @@ def rect_extra(B, rows, p, cand=None):
     return chosen[len(rows):]
 
 
+def tt_round_rank(cores, rmax):
+    """TT-SVD rounding to ranks <= rmax: right-to-left orthogonalisation, then left-to-right truncated SVDs"""
+    cores = [c.copy() for c in cores]
+    d = len(cores)
+    for k in range(d - 1, 0, -1):
+        r0, N, r1 = cores[k].shape
+        Q, R = np.linalg.qr(cores[k].reshape(r0, N * r1).T)  # (N r1, q), (q, r0)
+        q = Q.shape[1]
+        cores[k] = Q.T.reshape(q, N, r1)
+        cores[k - 1] = np.tensordot(cores[k - 1], R.T, axes=([2], [0]))
+    for k in range(d - 1):
+        r0, N, r1 = cores[k].shape
+        U, S, Vt = np.linalg.svd(cores[k].reshape(r0 * N, r1), full_matrices=False)
+        rr = min(rmax, len(S))
+        cores[k] = U[:, :rr].reshape(r0, N, rr)
+        cores[k + 1] = np.tensordot(S[:rr, None] * Vt[:rr], cores[k + 1], axes=([1], [0]))
+    return cores
+
+
 class Cross:
     def __init__(self, w, r, variant="interp", extra=0, swap_tol=0.05, consistent=True, fit="ls"):
         self.w, self.d, self.N = w, w.dx, list(w.ngrid)
         self.r = [1] + [r] * (self.d - 1) + [1]
+        for k in range(1, self.d):  # ranks cannot exceed the size of either unfolding side
+            self.r[k] = min(self.r[k], int(np.prod(self.N[:k])), int(np.prod(self.N[k:])))
         self.variant, self.p, self.tol = variant, extra, 1.0 + swap_tol
         self.fit = fit
         self.P = oracle_lib.Problem(w, consistent_ends=consistent)
@@ -125,6 +146,7 @@ class Cross:
         self.Iext = [np.zeros((0, k), dtype=np.int32) for k in range(d)]
         self.nfib = 0
         self.nswaps = 0
+        self.frozen = False
 
     def _rand_tuples(self, rng, k, n):
         return np.stack([rng.integers(0, self.N[m], size=n) for m in range(k)], axis=1).astype(np.int32)
@@ -161,14 +183,15 @@ class Cross:
                 hit = [a for a in range(r0) if k == 0 or np.array_equal(L[a], old[q][:k])]
                 if hit:
                     rows0.append(hit[0] * N[k] + int(old[q][k]))
-            rows, B, ns = maxvol(C, rows0 if len(rows0) == r1 else None, self.tol)
+            rows, B, ns = maxvol(C, rows0 if len(rows0) == r1 else None, 1e300 if self.frozen else self.tol)
             self.nswaps += ns
             rows_sorted = sorted(rows)
             new = np.array([list(L[rw // N[k]]) + [rw % N[k]] for rw in rows_sorted], dtype=np.int32).reshape(r1, k + 1)
             if not np.array_equal(new, old):
                 changed = True
             self.I[k + 1] = new
-            if self.p > 0:
+            sticky = os.environ.get("STICKY") == "1" and len(self.Iext[k + 1]) == self.p and np.array_equal(new, old)
+            if self.p > 0 and not self.frozen and not sticky:
                 ex = rect_extra(B, rows, self.p)
                 self.Iext[k + 1] = np.array([list(L[rw // N[k]]) + [rw % N[k]] for rw in sorted(ex)], dtype=np.int32).reshape(len(ex), k + 1)
         return changed
@@ -191,16 +214,17 @@ class Cross:
                 hit = [b for b in range(r1) if k == d - 1 or np.array_equal(R[b], old[q][1:])]
                 if hit:
                     rows0.append(int(old[q][0]) * r1 + hit[0])
-            if self.p > 0 and self.fit == "svd":
+            tol = 1e300 if self.frozen else self.tol
+            if self.p > 0 and self.fit in ("svd", "svdls"):
                 U, S, Vt = np.linalg.svd(Ct_full, full_matrices=False)
-                rows, B, ns = maxvol(U[:, :r0], rows0 if len(rows0) == r0 else None, self.tol)
+                rows, B, ns = maxvol(U[:, :r0], rows0 if len(rows0) == r0 else None, tol)
             else:
-                rows, B, ns = maxvol(Ct, rows0 if len(rows0) == r0 else None, self.tol)
+                rows, B, ns = maxvol(Ct, rows0 if len(rows0) == r0 else None, tol)
             self.nswaps += ns
             order = np.argsort(rows)
             rows = [rows[i] for i in order]
             B = B[:, order]
-            if self.p > 0 and self.fit == "ls":
+            if self.p > 0 and self.fit in ("ls", "svdls"):
                 B = Ct_full @ np.linalg.pinv(Ct_full[rows])  # least squares over the K left tuples
             new = np.array([[rw // r1] + list(R[rw % r1]) for rw in rows], dtype=np.int32).reshape(r0, d - k)
             if not np.array_equal(new, old):
@@ -227,23 +251,63 @@ def main():
     variant = sys.argv[4] if len(sys.argv) > 4 else "interp"
     extra = int(sys.argv[5]) if len(sys.argv) > 5 else (r if variant != "interp" else 0)
     swap_tol = float(os.environ.get("SWAP_TOL", "0.05"))
-    Vs = dense_vstar(n)
-    vnorm, vmax = np.linalg.norm(Vs), np.abs(Vs).max()
+    Vs = dense_vstar(n) if n <= 11 else None
+    vnorm, vmax = (np.linalg.norm(Vs), np.abs(Vs).max()) if Vs is not None else (1.0, 1.0)
     w = wl.c4_car7d().scaled(ngrid=(n,) * 7, rank=4)
-    cr = Cross(w, min(r, n), variant, extra if variant != "interp" else 0, swap_tol, fit=variant)
-    cores = [np.zeros((cr.r[k], n, cr.r[k + 1])) for k in range(7)]
+    rcross = int(os.environ.get("CROSS_RANK", str(min(r, n))))
+    cr = Cross(w, rcross, variant, extra if variant != "interp" else 0, swap_tol, fit=variant)
+    cores = [np.zeros((1 if k == 0 else min(r, n), n, 1 if k == 6 else min(r, n))) for k in range(7)]
     t0 = time.time()
     errs, steps = [], []
+    freeze_at = int(os.environ.get("FREEZE", "1000000"))
     for s in range(sweeps):
+        if s == freeze_at:
+            cr.frozen = True
+        W = int(os.environ.get("ANNEAL", "0"))
+        if W and s >= 2 * W and s % W == 0 and not cr.frozen:
+            a, b = np.median(steps[-W:]), np.median(steps[-2 * W:-W])
+            if a > 0.7 * b:
+                cr.tol = 1.0 + 2.0 * (cr.tol - 1.0)
+                print(f"  anneal at sweep {s}: swap tol -> {cr.tol - 1.0:g}")
+        if os.environ.get("TAU_SCHED"):
+            tmax, s0 = float(os.environ.get("TAU_MAX", "1.0")), float(os.environ.get("TAU_SCHED"))
+            cr.tol = 1.0 + min(tmax, 0.05 * 2.0 ** np.floor(np.log2(1.0 + s / s0)))
+        Wn = int(os.environ.get("NOISE_W", "0"))
+        if Wn:
+            if s == 0:
+                snap, path = None, 0.0
+            if s > 0:
+                path += steps[-1] * np.sqrt(tt_dot(cores, cores))
+            if s % Wn == 0:
+                if snap is not None:
+                    aa_, bb_, ab_ = tt_dot(cores, cores), tt_dot(snap, snap), tt_dot(cores, snap)
+                    disp = np.sqrt(max(aa_ - 2 * ab_ + bb_, 0.0))
+                    ratio = disp / max(path, 1e-300)
+                    if ratio < float(os.environ.get("NOISE_RATIO", "0.5")) and cr.tol - 1.0 < float(os.environ.get("TAU_MAX", "1.0")):
+                        cr.tol = 1.0 + 2.0 * (cr.tol - 1.0)
+                    print(f"  gauge at sweep {s}: displacement/path {ratio:.3f} -> swap tol {cr.tol - 1.0:g}")
+                snap, path = [c.copy() for c in cores], 0.0
+        cap = int(os.environ.get("HOLD_CAP", "0"))
+        if cap:
+            if s == 0:
+                hold_left, hold_len = 0, 1
+            if hold_left > 0:
+                cr.frozen, hold_left = True, hold_left - 1
+            else:
+                cr.frozen = False
+                hold_len = min(2 * hold_len, cap)
+                hold_left = hold_len - 1
         cr.set_value(cores)
-        new, iters = cr.interp()
+        new, iters = cr.interp(1 if cr.frozen else 5)
+        if rcross > r:
+            new = tt_round_rank(new, r)
         aa, bb, ab = tt_dot(new, new), tt_dot(cores, cores), tt_dot(new, cores)
         step = np.sqrt(max(aa - 2 * ab + bb, 0.0)) / np.sqrt(aa)
         steps.append(step)
         cores = new
         if s % 20 == 0 or s == sweeps - 1:
-            D = tt_dense(cores)
-            e2, em = np.linalg.norm(D - Vs) / vnorm, np.abs(D - Vs).max() / vmax
+            D = tt_dense(cores) if Vs is not None else None
+            e2, em = (np.linalg.norm(D - Vs) / vnorm, np.abs(D - Vs).max() / vmax) if Vs is not None else (np.sqrt(aa), 0.0)
             errs.append(e2)
             print(f"sweep {s:4d} iters {iters} step {step:.3e} err L2 {e2:.3e} max {em:.3e} fibers {cr.nfib} swaps {cr.nswaps} {time.time() - t0:.0f}s", flush=True)
     h = len(steps) // 2

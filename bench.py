@@ -146,8 +146,9 @@ def solver_measurements(workload, budget_s):
     ctl = facade_lib.Control(w, consistent_ends=None)  # the library's default (c3control_set_consistent_ends: on)
     rmax = max(w.ranks)
 
-    def aargs(cross, rnd, kick, start, maxrank):
+    def aargs(cross, rnd, kick, start, maxrank, crossrank=0):
         aa = C.c_void_p(L.approx_args_init())
+        L.approx_args_set_crossrank(aa, C.c_size_t(crossrank))  # 0: the cross approximation runs at maxrank (the reference's scheme)
         L.approx_args_set_cross_tol(aa, C.c_double(cross))
         L.approx_args_set_round_tol(aa, C.c_double(rnd))
         L.approx_args_set_kickrank(aa, C.c_size_t(kick))
@@ -165,7 +166,7 @@ def solver_measurements(workload, budget_s):
     v0 = C.c_void_p(L.c3control_init_value(ctl.h, cb, None, aa, 0))
     ne = C.c_size_t(0)
 
-    def sweeps(nsweeps, host_driven):
+    def sweeps(nsweeps, host_driven, aa=aa):
         # the same sweeps twice: whole cross iterations on the device (default) and driven from the host (round 2's path)
         if host_driven:
             os.environ["C3SC_HOST_CROSS"] = "1"
@@ -187,6 +188,11 @@ def solver_measurements(workload, budget_s):
     allrows, ranks = sweeps(28, False)
     rows, steady = allrows[:8], allrows[8:]  # sweeps 4..11 (round 2's window) and sweeps 12..27 (the regime a solve spends its time in)
     hrows, _ = sweeps(8, True)
+    aa2 = aargs(1e-6, 1e-5, 4, 4, rmax, 2 * rmax)  # cross approximation at twice the rank cap, rounded to the cap (what vi_iters_to_tol runs)
+    xrows, xranks = sweeps(20, False, aa2)
+    xrows = xrows[6:]
+    xms, xnb = 1e3 * float(np.mean([r[0] for r in xrows])), float(np.mean([r[1] for r in xrows]))
+    L.approx_args_free(aa2)
     ms = 1e3 * float(np.mean([r[0] for r in rows]))
     sms = 1e3 * float(np.mean([r[0] for r in steady]))
     snb = float(np.mean([r[1] for r in steady]))
@@ -198,6 +204,9 @@ def solver_measurements(workload, budget_s):
                 "cross_iterations_per_sweep": float(np.mean([r[2] for r in rows])) / (2.0 * d),
                 "host_driven_ms_per_sweep": hms, "host_driven_node_backups_per_sweep": float(np.mean([r[1] for r in hrows])),
                 "ranks": ranks,
+                "crossrank2x": {"ms_per_sweep": xms, "node_backups_per_sweep": xnb, "nodes_per_s_through_the_driver": xnb / (xms * 1e-3), "ranks": xranks,
+                                "what": f"the same sweeps with approx_args_set_crossrank({2 * rmax}): the cross approximation runs at twice the rank cap "
+                                        "(4x the fibers per core step) and its result is rounded to the cap by the TT-SVD; sweeps 10..19 of the series"},
                 "what": f"c3control_step_vi through libc3sc.so on {w.name} (rank cap {rmax}), mean of sweeps 4..11 of a solve from a smooth start (round 2's window): whole cross "
                         "iterations device-resident (c3sc_hip_cross_*: index lists, Bellman launches, node memo, pivoted LU + maxvol per core "
                         "step on one stream); steady_* = the following 16 sweeps of the same series (ranks at their cap, one cross iteration + "
@@ -210,7 +219,7 @@ def solver_measurements(workload, budget_s):
 
     # "VI iterations to tolerance": c3control_vi_solve's own loop (bellman.c:2282-2340: stop when the L2 step between iterates falls
     # below abs_conv_tol), one sweep per call so that the step series is kept; start value 0
-    aa = aargs(1e-6, 1e-6, 2, 4, rmax)
+    aa = aargs(1e-6, 1e-6, 4, 4, rmax, 2 * rmax)
     zero = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.0), 0)[1])
     cost = C.c_void_p(L.c3control_init_value(ctl.h, zero, None, aa, 0))
     diag = C.c_void_p(None)
@@ -232,11 +241,13 @@ def solver_measurements(workload, budget_s):
              "last_step_L2": steps[-1], "norm_L2": norm, "last_step_rel": steps[-1] / norm if norm else None,
              "median_step_rel_last_200": float(np.median(tail)) / norm if norm else None,
              "first_sweep_with_step_rel_below_1e-2": next((i for i, sv in enumerate(steps) if sv < 1e-2 * norm), None),
-             "rank_cap": rmax, "wall_budget_s": budget_s,
+             "rank_cap": rmax, "cross_rank": 2 * rmax, "wall_budget_s": budget_s,
+             "end_point_rule": "consistent ends (c3control_set_consistent_ends, the C3Control default; C3SC_LITERAL_ENDS=1 restores nodeutil.c:570-612)",
              "what": "pure value iteration (c3control_vi_solve's loop, one sweep per call) through libc3sc.so from the start value 0 until "
-                     "|V_i+1 - V_i|_L2 < tol_rel |V|_L2.  On this exit-time problem (discount 0, contraction ~1 - 1e-3 per sweep) the "
-                     "rank-capped interpolation error of each sweep (~1e-3 relative) is amplified by 1 / (1 - contraction): the iteration "
-                     "reaches a noise floor instead of the tolerance (DESIGN.md 6.2); dubins3d below converges"}
+                     "|V_i+1 - V_i|_L2 < tol_rel |V|_L2; cross approximation at twice the rank cap, rounded to the cap (approx_args_set_crossrank). "
+                     "On this exit-time problem (discount 0, contraction ~1 - 2.5e-3 per sweep) every sweep's approximation error enters a "
+                     "weakly contracting iteration: the step reaches a floor set by that error (3.6e-3 relative with the cross at the cap, "
+                     "2.5e-3 at twice, 1.3e-3 at three times the cap -- DESIGN.md 6.2) instead of the tolerance; dubins3d below converges"}
     L.valuef_destroy(cost)
     L.approx_args_free(aa)
     ctl.close()
@@ -245,7 +256,8 @@ def solver_measurements(workload, budget_s):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import dense_truth
 
-            iters["reduced_grid_truth"] = dense_truth.reduced_grid_truth(9, 9, 600)
+            iters["reduced_grid_truth"] = dense_truth.reduced_grid_truth(9, 9, 400, crossrank=18)
+            iters["reduced_grid_truth_cross_at_the_cap"] = dense_truth.reduced_grid_truth(9, 9, 400, crossrank=0)
         except Exception as e:
             iters["reduced_grid_truth"] = {"error": repr(e)}
 

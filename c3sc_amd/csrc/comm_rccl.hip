@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.hpp"
@@ -25,6 +26,7 @@ struct Rccl {
     ncclResult (*GetUniqueId)(ncclUniqueIdBytes *) = nullptr;
     ncclResult (*CommInitRank)(ncclComm *, int, ncclUniqueIdBytes, int) = nullptr;
     ncclResult (*CommDestroy)(ncclComm) = nullptr;
+    ncclResult (*CommAbort)(ncclComm) = nullptr;
     ncclResult (*AllGather)(const void *, void *, size_t, int, ncclComm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult) = nullptr;
     std::string err;
@@ -43,6 +45,7 @@ Rccl &rccl()
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) { r.err = "librccl lacks an expected symbol"; r.lib = nullptr; }
@@ -106,6 +109,7 @@ int c3sc_hip_comm_rank(const c3sc_hip_comm *m) { return m ? m->rank : -1; }
 int c3sc_hip_comm_allgather(c3sc_hip_comm *m, const double *d_send, double *d_recv, size_t count, void *stream)
 {
     if (!m || !d_send || !d_recv) return C3SC_ERR_ARG;
+    if (!m->comm) { if (m->ctx) m->ctx->err = "comm_allgather: the communicator was aborted after a local failure"; return C3SC_ERR_HIP; }
     Rccl &r = rccl();
     const ncclResult rc = r.AllGather(d_send, d_recv, count, NCCL_FLOAT64, m->comm, (hipStream_t)stream);
     if (rc != 0) { m->ctx->err = std::string("ncclAllGather: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"); return C3SC_ERR_HIP; }
@@ -125,25 +129,45 @@ int c3sc_hip_cross_set_comm(c3sc_hip_ctx *c, c3sc_hip_comm *m)
 /* c3sc_exchange_fn of include/c3sc/valuefunc.h for the HOST-driven sharded driver (valuef_interp_idx_sharded,
  * c3control_set_fiber_sharding): xarg = the communicator.  Rank r has filled rows [lo, hi) of the host array out[F][N];
  * afterwards every rank holds all F rows.  The rows travel through a device staging buffer and one ncclAllGather. */
+/* A rank that cannot take part in a collective the others are about to enter (or are already waiting in) must not just
+ * return: the peers would wait for ever, and a plain C main() has no watchdog.  Where a send buffer still exists the rank
+ * enters the all-gather with its rows set to NaN (no fiber value ever is one: every rank sees the mark and all of them
+ * return the error together -- the callers check); where it does not (staging allocation failed), the communicator is
+ * aborted, which makes the peers' collective return an error instead of blocking. */
+static int comm_fail(c3sc_hip_comm *m, const char *what)
+{
+    if (m->ctx) m->ctx->err = std::string("comm_exchange: ") + what + "; communicator aborted";
+    Rccl &r = rccl();
+    if (r.CommAbort && m->comm) { (void)r.CommAbort(m->comm); m->comm = nullptr; }
+    return 1;
+}
+
 int c3sc_hip_comm_exchange(double *out, size_t F, size_t N, size_t lo, size_t hi, void *xarg)
 {
     c3sc_hip_comm *m = (c3sc_hip_comm *)xarg;
     if (!m || !out) return 1;
+    if (!m->comm) return 1; // aborted earlier: the peers have been released already
     c3sc_hip_ctx *c = m->ctx;
     const size_t per = (F + m->world - 1) / m->world, need = per * m->world * N;
-    if (hipSetDevice(c->device) != hipSuccess) return 1;
+    const bool inject = getenv("C3SC_INJECT_EXCHANGE_FAILURE") != nullptr; // tests: a local failure before the collective
+    if (hipSetDevice(c->device) != hipSuccess) return comm_fail(m, "hipSetDevice failed");
     if (need > m->stage_doubles) {
         if (m->stage) (void)hipFree(m->stage);
         m->stage = nullptr; m->stage_doubles = 0;
-        if (hipMalloc((void **)&m->stage, need * sizeof(double)) != hipSuccess) return 1;
+        if (hipMalloc((void **)&m->stage, need * sizeof(double)) != hipSuccess) return comm_fail(m, "staging buffer allocation failed");
         m->stage_doubles = need;
     }
     double *mine = m->stage + (size_t)m->rank * per * N;
-    if (hipMemsetAsync(mine, 0, per * N * sizeof(double), nullptr) != hipSuccess) return 1;
-    if (hi > lo && hipMemcpyAsync(mine, out + lo * N, (hi - lo) * N * sizeof(double), hipMemcpyHostToDevice, nullptr) != hipSuccess) return 1;
-    if (c3sc_hip_comm_allgather(m, mine, m->stage, per * N, nullptr) != C3SC_OK) return 1;
+    // local trouble from here on: the rank still ENTERS the collective, with NaN rows (0xFF bytes are a quiet NaN)
+    bool bad = inject;
+    if (!bad && hipMemsetAsync(mine, 0, per * N * sizeof(double), nullptr) != hipSuccess) bad = true;
+    if (!bad && hi > lo && hipMemcpyAsync(mine, out + lo * N, (hi - lo) * N * sizeof(double), hipMemcpyHostToDevice, nullptr) != hipSuccess) bad = true;
+    if (bad && hipMemsetAsync(mine, 0xFF, per * N * sizeof(double), nullptr) != hipSuccess) return comm_fail(m, "device unusable");
+    if (c3sc_hip_comm_allgather(m, mine, m->stage, per * N, nullptr) != C3SC_OK) return 1; // RCCL itself failed: nobody is waiting on us
     if (hipMemcpyAsync(out, m->stage, F * N * sizeof(double), hipMemcpyDeviceToHost, nullptr) != hipSuccess) return 1;
-    return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : 1;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return 1;
+    if (bad) { if (c) c->err = "comm_exchange: local failure before the all-gather (rows sent as NaN)"; return 1; }
+    return 0;
 }
 
 } // extern "C"

@@ -116,11 +116,13 @@ __global__ void k_cross_memo(const int32_t *__restrict__ idx, double *__restrict
         unsigned long long id = (unsigned long long)j * (unsigned long long)S.s[k];
         for (int m = 0; m < d; m++)
             if (m != k) id += (unsigned long long)idx[f * d + m] * (unsigned long long)S.s[m];
-        out[e] = memo_merge(keys, vals, capmask, shift, epoch_bits, id, out[e], inserted, overflow);
+        const double v = out[e];
+        if (v != v) overflow = 2; // a NaN row: the mark of a rank whose fibers failed in a sharded step (step_fibers) -- every rank sees it here
+        else out[e] = memo_merge(keys, vals, capmask, shift, epoch_bits, id, v, inserted, overflow);
     }
     const unsigned long long mask = __ballot(inserted);
     if (mask != 0 && (threadIdx.x & 63) == (unsigned)__ffsll((long long)mask) - 1) atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
-    if (overflow) atomicExch(&counters[3], 1ull);
+    if (overflow) atomicMax(&counters[3], (unsigned long long)overflow); // 1: memo full, 2: a peer's rows arrived as NaN
 }
 
 // ------------------------------------------------------------------------------------------------ core step
@@ -522,7 +524,8 @@ struct c3sc_cross_dev {
     size_t offIdx[MAXD] = {0}, offOut[MAXD] = {0}, off_flags = 0, off_steps = 0, work_stride = 0;
     unsigned long long gen = 0;
     long long policy_tag = -1; // the caller's policy-iteration counter the policy memo belongs to
-    size_t off_uidx = 0;       // [Fmax][Nmax] candidate indices between the policy pass and the evaluation pass
+    size_t offUidx[MAXD] = {0}; // per core step: [F_k][N_k] candidate indices between the policy pass and the evaluation pass (a block of
+                                // its own per step: a step whose policy pass was skipped must find ITS policy there, not another step's)
     Strides strides;
     unsigned long long *counters = nullptr; // device [4]
     // pinned host staging for the one-copy upload / download
@@ -637,7 +640,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     // 2 d steps side by side; the sequential iteration uses the first block)
     x->work_stride = up256(wmax * sizeof(double));
     x->off_work = off; off += 2 * (size_t)d * x->work_stride;
-    x->off_uidx = off; off += up256(fmax * nmax * sizeof(int32_t));
+    for (int k = 0; k < d; k++) { x->offUidx[k] = off; off += up256(((size_t)x->r[k] * x->r[k + 1] + 64) * x->N[k] * sizeof(int32_t)); }
     if (off > x->slab_bytes) {
         if (x->slab) HIPCHK(c, hipFree(x->slab));
         x->slab = nullptr; x->slab_bytes = 0;
@@ -732,7 +735,7 @@ static int step_fibers(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, int box, int k, void 
     const int world = comm ? c3sc_hip_comm_world(comm) : 1, rank = comm ? c3sc_hip_comm_rank(comm) : 0;
     c3sc_cross_dev::MemoTab &mt = pol ? x->pmemo : x->vmemo;
     const int shift = memo_shift_of(mt.cap);
-    int32_t *uidx = (int32_t *)(x->slab + x->off_uidx);
+    int32_t *uidx = (int32_t *)(x->slab + x->offUidx[k]);
     int *skipf = (int *)(x->slab + x->off_flags);
     const int r0 = x->r[k], r1 = x->r[k + 1], N = x->N[k];
     const size_t F = (size_t)r0 * r1;
@@ -757,7 +760,20 @@ static int step_fibers(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, int box, int k, void 
         if (hi > lo)
             rc = box ? c3sc_hip_bellman_fibers_box(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream)
                      : c3sc_hip_bellman_fibers(c, k, hi - lo, idx + lo * d, out + lo * N, nullptr, nullptr, stream);
-        if (rc == C3SC_OK) rc = c3sc_hip_comm_allgather(comm, out + (size_t)rank * per * N, out, per * N, stream);
+        if (getenv("C3SC_INJECT_SHARD_FAILURE")) rc = fail(c, C3SC_ERR_HIP, "cross_iteration: injected failure of this rank's fibers");
+        // A rank whose launch failed still ENTERS the all-gather -- its peers are about to wait in it -- with its rows set to NaN
+        // (0xFF bytes; no fiber value ever is one).  The memo pass that follows on every rank sees the mark and raises
+        // counters[3] = 2, so that all ranks fail this sweep together instead of hanging (c3sc_cross.c: sharded_fibers_idx does the
+        // same on the host-driven path).
+        const int local_rc = rc;
+        if (local_rc != C3SC_OK) (void)hipMemsetAsync(out + (size_t)rank * per * N, 0xFF, per * N * sizeof(double), st);
+        rc = c3sc_hip_comm_allgather(comm, out + (size_t)rank * per * N, out, per * N, stream);
+        if (local_rc != C3SC_OK) {
+            if (rc == C3SC_OK)
+                hipLaunchKernelGGL(k_cross_memo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, idx, out, total, N, d, k, x->strides, mt.keys,
+                                   mt.vals, (unsigned long long)(mt.cap - 1), shift, (unsigned long long)mt.epoch << 49, x->counters);
+            rc = local_rc;
+        }
     } else if (pol) rc = c3sc_hip_bellman_fibers(pol, k, F, idx, out, uidx, nullptr, stream); // values unused: the policy is the output
     else rc = box ? c3sc_hip_bellman_fibers_box(c, k, F, idx, out, nullptr, nullptr, stream)
                   : c3sc_hip_bellman_fibers(c, k, F, idx, out, nullptr, nullptr, stream);

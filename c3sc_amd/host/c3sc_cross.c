@@ -857,11 +857,12 @@ static struct tt *cross_iteration_device(struct cross *c)
     const size_t d = c->d;
     device_setup_if_fresh(c);
     int rc = c->dev_pol ? c3sc_hip_cross_iteration_pi(c->dev, c->dev_pol, c->dev_tag, NULL) : c3sc_hip_cross_iteration(c->dev, c->dev_box, NULL);
-    if (rc != 0) DIE("c3sc_hip_cross_iteration: %s", c3sc_hip_last_error(c->dev));
+    if (rc != 0) DIE("c3sc_hip_cross_iteration: %s", c3sc_hip_last_error(c->dev)); /* a sharded rank has entered its all-gather before this returns */
     struct tt *t = tt_alloc(d, c->N, c->r);
     unsigned long long info[4] = {0, 0, 0, 0};
     rc = c3sc_hip_cross_fetch(c->dev, t->G, (int32_t *const *)c->I, (int32_t *const *)c->J, info, NULL);
     if (rc != 0) DIE("c3sc_hip_cross_fetch: %s", c3sc_hip_last_error(c->dev));
+    if (info[3] >= 2) DIE("valuef_interp: a rank of the sharded sweep failed (its rows arrived as NaN): all ranks stop here");
     if (info[3]) DIE("valuef_interp: the device node memo overflowed");
     c->dev_nodes += info[0];
     if (info[1]) c->deficient = 1;

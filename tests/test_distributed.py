@@ -3,6 +3,7 @@ result exactly.  (No GPU here, so the per-rank compute in this test is the oracl
 standing in for the kernel; the plumbing under test is c3sc_amd/distributed.py.)"""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -86,7 +87,7 @@ def test_gloo_world2_shard_and_gather(oracle):
 
 
 # ---- the sharded solver path of libc3sc.so (valuef_interp_idx_sharded / c3control_set_fiber_sharding) ---------------------
-def _sharded_worker(rank, world, port, q, use_gpu):
+def _sharded_worker(rank, world, port, q, use_gpu, mode="vi"):
     import ctypes as C
     import sys
 
@@ -104,7 +105,8 @@ def _sharded_worker(rank, world, port, q, use_gpu):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L = facade_lib.lib()
-    for n in ("valuef_interp_idx", "valuef_interp_idx_sharded", "c3control_init_value", "c3control_step_vi"):
+    for n in ("valuef_interp_idx", "valuef_interp_idx_sharded", "c3control_init_value", "c3control_step_vi", "c3control_step_pi",
+              "c3control_begin_pi", "valuef_copy"):
         getattr(L, n).restype = C.c_void_p
     L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
     L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
@@ -131,10 +133,17 @@ def _sharded_worker(rank, world, port, q, use_gpu):
         FI = C.CFUNCTYPE(C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p)
         calls = []
 
+        polvf = None
+        if mode == "pi":  # bellman_pi's fibers: the greedy policy of another value function, evaluated on P's (bellman.c:1702-1886)
+            wp = wl.Workload(w.name, w.model, w.params, w.dx, w.du, w.lb, w.ub, w.ngrid, w.ranks, w.discount, w.bc, list(w.obstacles), w.cands)
+            polvf = oracle_lib.ValueF(w.ngrid, w.ranks, [c * (1.0 + 0.3 * np.sin(np.arange(c.size)).reshape(c.shape)) for c in wl.synth_cores(wp)])
+
         def fi(F, k, idx_p, out_p, _a):
             idx = np.ctypeslib.as_array(idx_p, shape=(F, w.dx)).copy()
             out = np.ctypeslib.as_array(out_p, shape=(F, w.ngrid[k]))
-            out[:] = P.bellman_fibers(k, idx, want_absorbed=False)[0]
+            if mode == "fail" and rank == 1 and len(calls) >= 2:
+                return 7  # this rank's fibers fail in its third core step: BOTH ranks must come back with an error, nobody may hang
+            out[:] = P.policy_fibers(polvf, k, idx)[0] if mode == "pi" else P.bellman_fibers(k, idx, want_absorbed=False)[0]
             calls.append(F)
             return 0
 
@@ -162,10 +171,20 @@ def _sharded_worker(rank, world, port, q, use_gpu):
             L.c3control_set_fiber_sharding(ctl.h, C.c_size_t(world if sharded else 1), C.c_size_t(rank), ex if sharded else None, None)
             vf = C.c_void_p(L.c3control_init_value(ctl.h, zero, None, aa, 0))
             ne = C.c_size_t(0)
-            for _ in range(3):
+            for _ in range(3 if mode == "vi" else 1):
                 nxt = C.c_void_p(L.c3control_step_vi(ctl.h, vf, aa, ctl.opt, 0, C.byref(ne)))
                 L.valuef_destroy(vf)
                 vf = nxt
+            if mode == "pi":  # c3control_step_pi x3 under the policy of the value function reached so far (bellman.c:2214-2262, 2343-2407)
+                pol = C.c_void_p(L.c3control_begin_pi(ctl.h, vf))
+                it = C.c_void_p(L.valuef_copy(vf))
+                for _ in range(3):
+                    nxt = C.c_void_p(L.c3control_step_pi(ctl.h, it, pol, aa, ctl.opt, 0, C.byref(ne)))
+                    L.valuef_destroy(it)
+                    it = nxt
+                L.pi_param_destroy(pol)
+                L.valuef_destroy(vf)
+                vf = it
             outs.append((cores_of(vf, w), ne.value))
         (ra, ca), na = outs[0]
         (rb, cb_), nb = outs[1]
@@ -175,13 +194,13 @@ def _sharded_worker(rank, world, port, q, use_gpu):
     dist.destroy_process_group()
 
 
-def _run_sharded(use_gpu):
+def _run_sharded(use_gpu, mode="vi"):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, use_gpu)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, use_gpu, mode)) for r in range(2)]
     for p in procs:
         p.start()
     import queue as _queue
@@ -214,6 +233,49 @@ def test_gloo_world2_sharded_cross_driver(oracle):
     for rank, same, n_sharded, n_full in res:
         assert same, f"rank {rank}: sharded result differs from the unsharded one"
         assert 0 < n_sharded < 0.75 * n_full  # about half of the fibers ran on this rank
+
+
+def test_gloo_world2_sharded_policy_evaluation_fibers(oracle):
+    """The same driver with bellman_pi's fibers (the greedy policy of one value function evaluated on another,
+    bellman.c:1702-1886) sharded over two gloo ranks: cores identical to the unsharded interpolation on both ranks."""
+    for rank, same, n_sharded, n_full in _run_sharded(False, "pi"):
+        assert same, f"rank {rank}: sharded policy-evaluation result differs from the unsharded one"
+        assert 0 < n_sharded < 0.75 * n_full
+
+
+def test_gloo_world2_failing_rank_takes_every_rank_down_instead_of_hanging(oracle):
+    """One rank's fibers fail in the middle of a sweep.  It must still enter the exchange (rows marked NaN) so that its peer,
+    which is about to wait there, sees the mark: both processes end with the library's error exit -- neither hangs."""
+    import time as _time
+
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, False, "fail")) for r in range(2)]
+    for p in procs:
+        p.start()
+    deadline = _time.time() + 120
+    try:
+        for p in procs:
+            p.join(timeout=max(1.0, deadline - _time.time()))
+        codes = [p.exitcode for p in procs]
+        assert all(c is not None for c in codes), f"a rank is still waiting in the exchange: exit codes {codes}"
+        assert all(c == 1 for c in codes), f"both ranks must stop with the library's error exit (1): {codes}"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+
+
+@pytest.mark.gpu
+def test_world2_sharded_policy_iteration_step_matches_single_rank(oracle):
+    """c3control_step_pi on two gloo ranks sharing the box's GPU (host-driven sharded driver, consistent end points): three
+    policy-evaluation sweeps end with cores bit-identical to the unsharded run on both ranks."""
+    for rank, same, na, nb in _run_sharded(True, "pi"):
+        assert same, f"rank {rank}: sharded c3control_step_pi differs from the unsharded one"
 
 
 @pytest.mark.gpu
@@ -327,3 +389,50 @@ def test_rccl_communicator_in_c_shards_the_device_resident_sweeps(tmp_path):
     for rank, same, counts in sorted(res):
         assert same, f"rank {rank}: sharded sweeps differ from the unsharded ones"
     print(f"RCCL communicator in C, world {world}: sharded device-resident sweeps identical to the unsharded ones; node evaluations {sorted(res)[0][2]}")
+
+
+_INJECT_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import facade_lib
+from c3sc_amd import workloads as wl
+from c3sc_amd.engine import load_library
+H = load_library(); L = facade_lib.lib()
+for n in ("c3control_init_value", "c3control_step_vi"):
+    getattr(L, n).restype = C.c_void_p
+w = wl.c4_car7d().scaled(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4)
+ctl = facade_lib.Control(w, consistent_ends=None)
+idbuf = (C.c_char * 128)()
+assert H.c3sc_hip_comm_unique_id(idbuf) == 0
+assert L.c3control_shard_over_gpus(ctl.h, C.c_size_t(1), C.c_size_t(0), idbuf) == 0
+aa = C.c_void_p(L.approx_args_init())
+L.approx_args_set_maxrank(aa, C.c_size_t(5)); L.approx_args_set_startrank(aa, C.c_size_t(3)); L.approx_args_set_kickrank(aa, C.c_size_t(2))
+one = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(1.0), 0)[1])
+v = C.c_void_p(L.c3control_init_value(ctl.h, one, None, aa, 0))
+ne = C.c_size_t(0)
+v = C.c_void_p(L.c3control_step_vi(ctl.h, v, aa, ctl.opt, 0, C.byref(ne)))   # clean sweep
+os.environ[{var!r}] = "1"
+v = C.c_void_p(L.c3control_step_vi(ctl.h, v, aa, ctl.opt, 0, C.byref(ne)))   # this rank's fibers / exchange fail: the library stops the process
+print("NOT REACHED")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var,host", [("C3SC_INJECT_SHARD_FAILURE", False), ("C3SC_INJECT_EXCHANGE_FAILURE", True)],
+                         ids=["device-resident-step", "host-driven-exchange"])
+def test_rank_failure_in_a_sharded_sweep_enters_the_collective_and_stops(var, host):
+    """A rank whose launch (device-resident step, cross_device.hip: step_fibers) or whose staging copy (host-driven exchange,
+    comm_rccl.hip: c3sc_hip_comm_exchange) fails must still enter the RCCL all-gather with NaN rows and only then report the
+    error: here with a one-rank communicator -- the collective is entered (it would otherwise not return the marked rows), the
+    failure is detected on the gathered array, and the process ends with the library's error exit instead of 'NOT REACHED'."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if host:
+        env["C3SC_HOST_CROSS"] = "1"
+    r = subprocess.run([sys.executable, "-c", _INJECT_SCRIPT.format(root=root, var=var)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "NOT REACHED" not in r.stdout
+    assert "c3sc:" in r.stderr, r.stderr[-1500:]

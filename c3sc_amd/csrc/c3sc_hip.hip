@@ -133,6 +133,7 @@ using namespace c3sc;
 // gives): the car models' speed factor v / (0.2 (1 + v/8)) costs a ~15-instruction dependent chain per node otherwise.
 static int model_ntab(int model)
 {
+    if (model == C3SC_MODEL_SKID5D) return 2; // cos / sin of the orientation x2
     return model == C3SC_MODEL_DUBINS3D ? 2 : (model == C3SC_MODEL_SCAR4D ? 3 : ((model == C3SC_MODEL_CAR7D || model == C3SC_MODEL_PERCH7D) ? 4 : 0));
 }
 static int model_tab_dim(int model, int t)
@@ -152,10 +153,15 @@ static double model_table_value(int model, int t, double xv)
     if (model == C3SC_MODEL_SCAR4D && t == 2) return (1.0 / (1.0 + (xv / 8.0))) * (xv / 0.2); /* scar.c:68-71 with L = 0.2, vcar = 8 */
     return tan(xv);
 }
-static int model_ncf(int model) { return model == C3SC_MODEL_SCAR4D ? 1 : 0; }
+static int model_ncf(int model) { return model == C3SC_MODEL_SCAR4D ? 1 : (model == C3SC_MODEL_COTHRUST6D ? 3 : 0); }
 static double model_cand_feature(int model, int q, const double *u)
 {
-    (void)model; (void)q;
+    if (model == C3SC_MODEL_COTHRUST6D) { /* copterposethrust.c:104-117, the callback's own expressions */
+        const double m = 1.227, g = 9.81, mg = m * g;
+        const double cphi = cos(u[1]), sphi = sin(u[1]), cth = cos(u[2]), sth = sin(u[2]);
+        return q == 0 ? cphi * sth * (u[0] - mg) / m : (q == 1 ? -sphi * (u[0] - mg) / m : g + cth * cphi * (u[0] - mg) / m);
+    }
+    (void)q;
     return tan(u[0]); /* scar.c:67 */
 }
 
@@ -736,7 +742,8 @@ static int launch_box(c3sc_hip_ctx *c, int k, size_t F, const int32_t *d_idx, co
 {
     if (!c) return C3SC_ERR_ARG;
     if (c->box_du == 0) return fail(c, C3SC_ERR_ARG, "bellman_fibers_box: c3sc_hip_set_control_box first");
-    if (model_ncf(c->model) != 0) return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: this model needs transcendental functions of the control");
+    if (model_ncf(c->model) != 0 && c->model != C3SC_MODEL_COTHRUST6D) // cothrust forms its features from u on the device (models.hpp: CF_FROM_U)
+        return fail(c, C3SC_ERR_UNSUPPORTED, "bellman_fibers_box: this model needs transcendental functions of the control");
     KArgs A;
     int rc = fill_args(c, k, F, A, true);
     if (rc != C3SC_OK) return rc;

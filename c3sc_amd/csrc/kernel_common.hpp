@@ -805,8 +805,9 @@ __device__ inline double node_backup(const KArgs &A, const double *__restrict__ 
 // unseeded for du >= 2, so nothing about its trajectory is pinned.  Here: a dense tensor grid of
 // `ugrid` points per control dimension (wave-uniform candidates generated arithmetically) followed by `upolish`
 // rounds of per-lane coordinate golden-section search inside the cell around the best grid point.  Fixed trip
-// counts and selects only; the objective is exactly node_backup's (rates, dt, bellmanrhs).  Requires NCF == 0
-// (a transcendental feature of a continuous control would have to be evaluated on the device).
+// counts and selects only; the objective is exactly node_backup's (rates, dt, bellmanrhs).  Models with per-candidate
+// features (NCF > 0) must be able to form them from u on the device (Model::CF_FROM_U, Model::features): Cothrust6D does, with the
+// device's sin / cos; Scar4D (tan u0) is not served in this mode.
 template <class Model>
 __device__ inline double node_backup_box(const KArgs &A, const double (&x)[Model::D],
                                          const double (&tv)[Model::NTAB > 0 ? Model::NTAB : 1],
@@ -822,7 +823,10 @@ __device__ inline double node_backup_box(const KArgs &A, const double (&x)[Model
     typename Model::Node nd;
     Model::prep(A.prm, x, tv, nd);
     constexpr unsigned UM = Model::UDEP_MASK;
-    double cf0[1] = {0.0};
+    constexpr int NCFb = Model::NCF > 0 ? Model::NCF : 1;
+    double cf0[NCFb];
+#pragma unroll
+    for (int i = 0; i < NCFb; i++) cf0[i] = 0.0;
     double Q0 = 0.0, PV0 = 0.0;
     {
         double u0[DU], b[D], s[D];
@@ -846,7 +850,12 @@ __device__ inline double node_backup_box(const KArgs &A, const double (&x)[Model
     bool any_stationary = false;
     auto evalu = [&](const double (&u)[DU]) -> double {
         double b[D], s[D];
-        Model::drift(A.prm, nd, x, u, cf0, b);
+        if constexpr (Model::NCF > 0) { // features of a continuous control: formed from u here (models that can: CF_FROM_U)
+            double cfu[NCFb];
+            Model::features(u, cfu);
+            Model::drift(A.prm, nd, x, u, cfu, b);
+        } else
+            Model::drift(A.prm, nd, x, u, cf0, b);
         Model::sigma(A.prm, x, u, s);
         const double stage = Model::stage(A.prm, x, u);
         double Q = Q0, PV = PV0;

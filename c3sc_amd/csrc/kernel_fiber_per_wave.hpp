@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256, (RP >= 20 ? 1 : 2)) // rank 20 is LDS-bou
                     val = node_backup_tables<D>(A, tbl + node * A.ncand * S, tcost + node * 2, V, ab, ui, st, forced, fu);
                 } else if constexpr (BOX) { // continuous controls in a box: a separate instantiation (the minimiser
                                             // costs ~60 VGPRs, which halves the occupancy of the rank-16 kernels)
-                    static_assert(Model::NCF == 0, "box minimiser: no transcendental functions of the control");
+                    static_assert(Model::NCF == 0 || requires { Model::CF_FROM_U; }, "box minimiser: per-candidate features must be computable from u on the device");
                     double tv[Model::NTAB > 0 ? Model::NTAB : 1];
                     table_values<Model>(A, ro, ix, tv);
                     {

@@ -389,6 +389,103 @@ struct Perch7D {
     __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
 };
 
+// examples/skidding5d/scar.c:39-176 (order = {0,1,2,3,4}): the skidding car with lateral dynamics -- state (x, y, orientation,
+// yaw rate, lateral speed) at the constant forward speed s = 27, control = steering angle.  Diffusion (:111-134): the callback
+// zero-fills its 5 x 5 matrix and then writes out[0], out[6], out[12], out[28] (sic: outside the matrix) and
+// out[24] -- the diagonal entry out[18] of the yaw rate is never set, so its noise is 0; mirrored here, not fixed.
+struct Skid5D {
+    static constexpr bool IS_TABLE = false;
+    static constexpr int D = 5, DU = 1;
+    static constexpr int NTAB = 2, NCF = 0; // tables: cos(x2), sin(x2)
+    static constexpr unsigned UDEP_MASK = (1u << 3) | (1u << 4); // the front tyre force carries the steering angle
+    static constexpr unsigned UCONST_MASK = 0;                   // ... next to the state
+    static constexpr bool STAGE_UDEP = false;
+    __host__ __device__ static constexpr int tab_dim(int) { return 2; }
+    struct Node { double b0, b1, fs, ft; };
+    __device__ static inline void prep(const double *, const double (&x)[D], const double (&tv)[2], Node &n)
+    {
+        const double cf = 17000.0, ct = 20000.0, a = 1.2, b = 1.5, s = 27.0;
+        const double angvel = x[3], speed = x[4];
+        n.b0 = s * tv[0] - speed * tv[1];          // s * co - speed * so (:82)
+        n.b1 = s * tv[1] + speed * tv[0];          // s * so + speed * co (:83)
+        n.fs = (speed + a * angvel) / s;           // the state's share of ff = cf * ((speed + a * angvel) / s + steering) (:76)
+        n.ft = ct * (speed - b * angvel) / s;      // (:77)
+        (void)cf;
+    }
+    __device__ static inline void drift(const double *, const Node &n, const double (&x)[D], const double *u, const double *,
+                                        double (&bb)[D])
+    {
+        const double m = 1460.0, cf = 17000.0, a = 1.2, b = 1.5, In = 2170.0, s = 27.0;
+        const double ff = cf * (n.fs + u[0]);
+        bb[0] = n.b0; bb[1] = n.b1; bb[2] = x[3];
+        bb[3] = (a * ff - b * n.ft) / In;          // (:85)
+        bb[4] = -s * x[3] + (ff + n.ft) / m;       // (:86)
+    }
+    __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&sg)[D])
+    {
+        sg[0] = 1e-5; sg[1] = 1e-5; sg[2] = 1e-5; sg[3] = 0.0; sg[4] = 1e-5; // Q13: out[28] instead of out[18]
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *)
+    { // :143-144, the reference's order
+        double o = 1.0 + 0.02 * (x[0] * x[0]) + 0.02 * (x[1] * x[1]);
+        o = o + x[3] * x[3] + x[4] * x[4];
+        return o;
+    }
+    __device__ static inline double boundcost(const double *, const double (&x)[D])
+    { // :158-159
+        double o = 0.1 * (x[0] * x[0]) + 0.1 * (x[1] * x[1]);
+        o = o + 0.1 * (x[3] * x[3]) + 0.1 * (x[4] * x[4]);
+        return o;
+    }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
+// examples/cothrust2/copterposethrust.c:40-222 (order = {0,..,5}): quadcopter position (x, y, z) and velocity, controls (thrust,
+// roll phi, pitch theta).  The three accelerations are functions of the control alone (:115-117): they are the candidate's FEATURES,
+// evaluated on the host with libm exactly as the callback writes them (cos / sin of the angles included), so candidate lists need
+// no transcendental on the device; the continuous-control (box) minimiser evaluates the same expressions with the device's
+// sin / cos (parity to the minimiser's tolerance, as for every box run).  Diffusion diag (:147-152), stage (:171-176).
+struct Cothrust6D {
+    static constexpr bool IS_TABLE = false;
+    static constexpr int D = 6, DU = 3;
+    static constexpr int NTAB = 0, NCF = 3; // features: the accelerations b3, b4, b5 of the candidate
+    static constexpr unsigned UDEP_MASK = (1u << 3) | (1u << 4) | (1u << 5);
+    static constexpr unsigned UCONST_MASK = UDEP_MASK; // ... of the control alone: rates are per-candidate constants
+    static constexpr bool STAGE_UDEP = true;
+    static constexpr bool CF_FROM_U = true; // the features can be formed from u on the device (box minimiser)
+    __host__ __device__ static constexpr int tab_dim(int) { return 0; }
+    struct Node {};
+    __device__ static inline void prep(const double *, const double (&)[D], const double (&)[1], Node &) {}
+    __device__ static inline void features(const double *u, double *cf)
+    {
+        const double m = 1.227, g = 9.81, mg = m * g;
+        const double cphi = cos(u[1]), sphi = sin(u[1]), cth = cos(u[2]), sth = sin(u[2]);
+        cf[0] = cphi * sth * (u[0] - mg) / m;
+        cf[1] = -sphi * (u[0] - mg) / m;
+        cf[2] = g + cth * cphi * (u[0] - mg) / m;
+    }
+    __device__ static inline void drift(const double *, const Node &, const double (&x)[D], const double *, const double *cf,
+                                        double (&b)[D])
+    {
+        b[0] = x[3]; b[1] = x[4]; b[2] = x[5]; b[3] = cf[0]; b[4] = cf[1]; b[5] = cf[2];
+    }
+    __device__ static inline void sigma(const double *, const double (&)[D], const double *, double (&s)[D])
+    {
+        s[0] = 1e-1; s[1] = 1e-1; s[2] = 2e-1; s[3] = 12e-1; s[4] = 12e-1; s[5] = 12e-1;
+    }
+    __device__ static inline double stage(const double *, const double (&x)[D], const double *u)
+    { // :171-176, the reference's order
+        double o = 0.0;
+        o = o + 60.0 + 2.0 * (u[0] * u[0]) + 1.0 * (u[1] * u[1]) + 6.0 * (u[2] * u[2]);
+        o = o + 8.0 * (x[2] * x[2]);
+        o = o + 6.0 * (x[1] * x[1]);
+        o = o + 8.0 * (x[0] * x[0]);
+        return o;
+    }
+    __device__ static inline double boundcost(const double *, const double (&)[D]) { return 10.0; }
+    __device__ static inline double obscost(const double *, const double (&)[D]) { return 0.0; }
+};
+
 // Universal model for arbitrary host callbacks (the reference's examples unchanged): the HOST evaluates the
 // user's drift / diffusion / stage-cost callbacks for every (node, candidate) of the fibers it submits and the
 // kernel reads the numbers from a table: per fiber [N][U][2D+1] = (drift[D], diag sigma[D], stage) and

@@ -29,6 +29,8 @@ MODEL_CHAIN = 5
 MODEL_ROSSLER3D = 6
 MODEL_TPROB3D = 7
 MODEL_PERCH7D = 8
+MODEL_SKID5D = 9
+MODEL_COTHRUST6D = 10
 
 BC_ABSORB, BC_PERIODIC, BC_REFLECT = 1, 2, 3  # enum EBTYPE, src/boundary.h:42-47
 _BC_NAME = {BC_ABSORB: "absorb", BC_PERIODIC: "periodic", BC_REFLECT: "reflect"}
@@ -157,9 +159,38 @@ def tprob3d(n=25, r=10) -> Workload:
                     (BC_ABSORB,) * 3, [], _grid_cands([ax.clip(-5.0, 5.0)] * 3))
 
 
+def skid5d(n=40, r=15) -> Workload:
+    """examples/skidding5d/scar.c:266-357: the skidding car with lateral dynamics -- (x, y, orientation, yaw rate, lateral speed),
+    N = 40 per dimension, x / y reflecting, orientation periodic, the last two dimensions absorbing (c3control_create's default: the
+    example leaves them unset, :333-334 are commented out), beta = 1, maxrank 15, the goal box |x|, |y| <= 20 as an obstacle of
+    cost 0, 20 steering candidates linspace(-5 pi/180, 5 pi/180) (:290-295)."""
+    lb = (-500.0, -500.0, -math.pi, -0.5, -10.0)
+    ub = (500.0, 500.0, math.pi, 0.5, 10.0)
+    goal = ((0.0, 0.0, 0.0, 0.0, 0.0), (40.0, 40.0, 2.0 * math.pi, 1.0, 20.0))
+    bc = (BC_REFLECT, BC_REFLECT, BC_PERIODIC, BC_ABSORB, BC_ABSORB)
+    i = np.arange(20, dtype=np.float64)
+    cands = (-5.0 * math.pi / 180.0 + (5.0 * math.pi / 180.0 - -5.0 * math.pi / 180.0) * i / 19.0).reshape(-1, 1)  # C3 linspace
+    return Workload("skid5d", MODEL_SKID5D, (), 5, 1, lb, ub, (n,) * 5, uniform_ranks(5, r), 1.0, bc, [goal], cands)
+
+
+def cothrust6d(n=20, r=10) -> Workload:
+    """examples/cothrust2/copterposethrust.c:277-383: quadcopter position + velocity, N = 20, every face reflecting, beta = 1,
+    rank 10 (start = max), obstacle = the target box around (0, 0, 0, 1, 0, 0); its BFGS box (thrust, roll, pitch) in
+    [-1.5, 1.5] x [-0.4, 0.4]^2 as a 5 x 5 x 5 candidate list, slightly off-centre (set_control_box gives the continuous minimiser
+    over the same box)."""
+    lb = (-3.5, -3.5, -2.0, -5.0, -5.0, -5.0)
+    ub = (0.2, 3.5, 2.0, 5.0, 5.0, 5.0)
+    goal = ((0.0, 0.0, 0.0, 1.0, 0.0, 0.0), (0.4, 0.4, 0.4, 0.5, 0.4, 0.4))
+    a0 = (np.linspace(-1.5, 1.5, 5) + 0.011).clip(-1.5, 1.5)
+    a1 = (np.linspace(-0.4, 0.4, 5) + 0.003).clip(-0.4, 0.4)
+    return Workload("cothrust6d", MODEL_COTHRUST6D, (), 6, 3, lb, ub, (n,) * 6, uniform_ranks(6, r), 1.0, (BC_REFLECT,) * 6, [goal],
+                    _grid_cands([a0, a1, a1]))
+
+
 WORKLOADS = {
     "lqg2d": c1_lqg2d, "dubins3d": c2_dubins, "lqg6d": c3_lqg6d, "car7d": c4_car7d, "quad10d": c5_quad10d,
     "scar4d": scar4d, "rossler3d": rossler3d, "tprob3d": tprob3d, "perch7d": perch7d,
+    "skid5d": skid5d, "cothrust6d": cothrust6d,
 }
 
 _GOLD = np.uint64(0x9E3779B97F4A7C15)

@@ -58,6 +58,8 @@ enum {
     C3SC_MODEL_ROSSLER3D = 6, /* examples/rossler/rossler.c:80-157; params {3, sig, sig_last} */
     C3SC_MODEL_PERCH7D = 8,  /* examples/perching/perch.c:36-273: glider perching, 7 states, elevator rate u in [-2 pi, 2 pi] */
     C3SC_MODEL_TPROB3D = 7,  /* the reference tests' 3-D problem: test/transition_prob/tprob_test.c f3 :223-251, s2, stagecost3d */
+    C3SC_MODEL_SKID5D = 9,   /* examples/skidding5d/scar.c:39-176: 5-D skidding car (x, y, orientation, yaw rate, lateral speed), steering u */
+    C3SC_MODEL_COTHRUST6D = 10, /* examples/cothrust2/copterposethrust.c:40-222: quadcopter position + velocity, controls (thrust, roll, pitch) */
     C3SC_MODEL_TABLE = 100   /* host-evaluated callbacks (c3sc_hip_bellman_fibers_tables); not set with set_model */
 };
 

@@ -702,6 +702,8 @@ int orc_model_dims(int model, const double *p, size_t *dx, size_t *du)
     case ORC_MODEL_ROSSLER3D: *dx = 3; *du = 1; return 0;
     case ORC_MODEL_TPROB3D: *dx = 3; *du = 3; return 0;
     case ORC_MODEL_PERCH7D: *dx = 7; *du = 1; return 0;
+    case ORC_MODEL_SKID5D: *dx = 5; *du = 1; return 0;
+    case ORC_MODEL_COTHRUST6D: *dx = 6; *du = 3; return 0;
     default: return 1;
     }
 }
@@ -770,6 +772,32 @@ int orc_model_drift(int model, const double *p, const double *x, const double *u
         out[6] = (-f_w * l_w - f_e * (l * c_p + l_e)) / In;
         return 0;
     }
+    case ORC_MODEL_SKID5D: { /* skidding5d/scar.c:39-109 with order = {0,1,2,3,4} */
+        const double orient = x[2], angvel = x[3], speed = x[4], steering = u[0];
+        const double m = 1460.0, cf = 17000.0, ct = 20000.0, a = 1.2, b = 1.5, In = 2170.0, s = 27.0;
+        const double co = cos(orient), so = sin(orient);
+        const double ff = cf * ((speed + a * angvel) / s + steering);
+        const double ft = ct * (speed - b * angvel) / s;
+        out[0] = s * co - speed * so;
+        out[1] = s * so + speed * co;
+        out[2] = angvel;
+        out[3] = (a * ff - b * ft) / In;
+        out[4] = -s * angvel + (ff + ft) / m;
+        return 0;
+    }
+    case ORC_MODEL_COTHRUST6D: { /* copterposethrust.c:40-117 with order = {0,..,5} (the callback's range checks return 1) */
+        const double lbu[3] = {-1.5, -0.4, -0.4}, ubu[3] = {1.5, 0.4, 0.4};
+        for (int i = 0; i < 3; i++) if (u[i] < lbu[i] || u[i] > ubu[i]) return 1;
+        const double m = 1.227, g = 9.81, mg = m * g;
+        const double cphi = cos(u[1]), sphi = sin(u[1]), cth = cos(u[2]), sth = sin(u[2]);
+        out[0] = x[3];
+        out[1] = x[4];
+        out[2] = x[5];
+        out[3] = cphi * sth * (u[0] - mg) / m;
+        out[4] = -sphi * (u[0] - mg) / m;
+        out[5] = g + cth * cphi * (u[0] - mg) / m;
+        return 0;
+    }
     case ORC_MODEL_TPROB3D: /* tprob_test.c:223-251 (f3) */
         out[0] = x[0] * pow(x[2], 2) * u[0];
         out[1] = -x[1] * u[2] + u[1];
@@ -807,6 +835,20 @@ int orc_model_diff_diag(int model, const double *p, const double *x, const doubl
     case ORC_MODEL_ROSSLER3D: out[0] = p[1]; out[1] = p[1]; out[2] = p[2]; return 0; /* rossler.c:113-117 */
     case ORC_MODEL_TPROB3D: out[0] = 1.; out[1] = 1.; out[2] = 1.; return 0; /* tprob_test.c:197-220 (s2) */
     case ORC_MODEL_PERCH7D: for (size_t i = 0; i < 7; i++) out[i] = 1e-9; return 0; /* perch.c:165-176 */
+    case ORC_MODEL_SKID5D: { /* skidding5d/scar.c:111-134, written as the callback writes it: the 5 x 5 matrix is zero-filled, then
+                                out[0], out[6], out[12], out[28] (sic -- outside the 25 elements; the slab behind it
+                                absorbs the store in the reference, a larger buffer does here) and out[24]; transition_assemble reads
+                                the diagonal out[m * 5 + m] only (nodeutil.c:294), so the yaw rate's entry out[18] stays 0 */
+        double mat[36];
+        for (size_t ii = 0; ii < 36; ii++) mat[ii] = 0.0;
+        const double vpos = 1e-5, vorient = 1e-5, vspeed = 1e-5;
+        mat[0] = vpos; mat[6] = vpos; mat[12] = vorient; mat[28] = vspeed; mat[24] = vspeed;
+        for (size_t i = 0; i < 5; i++) out[i] = mat[i * 5 + i];
+        return 0;
+    }
+    case ORC_MODEL_COTHRUST6D: /* copterposethrust.c:128-152 */
+        out[0] = 1e-1; out[1] = 1e-1; out[2] = 2e-1; out[3] = 12e-1; out[4] = 12e-1; out[5] = 12e-1;
+        return 0;
     default: return 1;
     }
 }
@@ -825,6 +867,17 @@ int orc_model_stage(int model, const double *p, const double *x, const double *u
         *out = s;
         return 0;
     }
+    case ORC_MODEL_SKID5D: /* skidding5d/scar.c:136-152 */
+        *out = 1.0 + 0.02 * pow(x[0], 2) + 0.02 * pow(x[1], 2);
+        *out = *out + pow(x[3], 2) + pow(x[4], 2);
+        return 0;
+    case ORC_MODEL_COTHRUST6D: /* copterposethrust.c:160-198 */
+        *out = 0.0;
+        *out = *out + 60.0 + 2 * pow(u[0], 2) + 1 * pow(u[1], 2) + 6 * pow(u[2], 2);
+        *out = *out + 8.0 * pow(x[2], 2.0);
+        *out = *out + 6.0 * pow(x[1], 2.0);
+        *out = *out + 8.0 * pow(x[0], 2.0);
+        return 0;
     case ORC_MODEL_PERCH7D: /* perch.c:185-215 */
         *out = 0.0;
         *out += 20.0 * x[0] * x[0];
@@ -873,6 +926,11 @@ int orc_model_boundcost(int model, const double *p, const double *x, double *out
     case ORC_MODEL_CHAIN: *out = 1000.0; return 0; /* double_int.c:139 */
     case ORC_MODEL_ROSSLER3D: *out = 1000.0; return 0; /* rossler.c:156 */
     case ORC_MODEL_TPROB3D: *out = 100.0; return 0; /* tprob_test.c:302-309 */
+    case ORC_MODEL_SKID5D: /* skidding5d/scar.c:154-163 */
+        *out = 0.1 * pow(x[0], 2) + 0.1 * pow(x[1], 2);
+        *out = *out + 0.1 * pow(x[3], 2) + 0.1 * pow(x[4], 2);
+        return 0;
+    case ORC_MODEL_COTHRUST6D: *out = 10.0; return 0; /* copterposethrust.c:200-209 */
     case ORC_MODEL_PERCH7D: /* perch.c:222-241 */
         *out = 0.0;
         *out += 600.0 * x[0] * x[0];

@@ -110,6 +110,8 @@ enum orc_model {
     ORC_MODEL_CHAIN = 5,    /* examples/double_int/double_int.c:80-157; params[2]=1 -> stage sum x^2 */
     ORC_MODEL_ROSSLER3D = 6, /* examples/rossler/rossler.c:80-157 */
     ORC_MODEL_PERCH7D = 8,   /* examples/perching/perch.c:36-273 */
+    ORC_MODEL_SKID5D = 9,    /* examples/skidding5d/scar.c:39-176 (Q13: the diffusion callback writes out[28] of a 25-element matrix) */
+    ORC_MODEL_COTHRUST6D = 10, /* examples/cothrust2/copterposethrust.c:40-222 */
     ORC_MODEL_TPROB3D = 7    /* test/transition_prob/tprob_test.c: f3 :223-251, s2 :197-220, stagecost3d :273-300, boundcost, ocost */
 };
 int orc_model_dims(int model, const double *params, size_t *dx, size_t *du);

@@ -163,7 +163,10 @@ def _sharded_worker(rank, world, port, q, use_gpu, mode="vi"):
     else:
         # GPU: the whole solver step (c3control_step_vi, device kernels) sharded over two ranks on the one device of the box
         w = wl.c4_car7d().scaled(ngrid=(11,) * 7, rank=4)
-        ctl = facade_lib.Control(w)
+        # value iteration: the reference's literal end-point rule (the rows other ranks computed enter this rank's memo, so even the
+        # direction-dependent nodes agree); policy evaluation: the solver's default, consistent end points -- the per-node policy memo
+        # holds this rank's rows only, and the bit-identity claim of include/c3sc/valuefunc.h is made for that rule
+        ctl = facade_lib.Control(w, consistent_ends=(mode == "pi"))
         aa = aargs()
         zero = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(1.0), 0)[1])
         outs = []

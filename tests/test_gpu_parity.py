@@ -37,6 +37,10 @@ SMALL = [
     ("tprob3d", dict(ngrid=(25, 19, 22), rank=10)),   # the reference tests' own 3-D problem (tprob_test.c f3): 3 controls, 125 candidates
     ("perch7d", dict(ngrid=(6, 5, 7, 6, 5, 6, 5), rank=4)),     # examples/perching: 7-D glider (atan2 / sin in the reference, sqrt on the device)
     ("perch7d", dict(ngrid=(20,) * 7, rank=15)),               # ... at the example's own size: N = 20, maxrank 15 (padded 16)
+    ("skid5d", dict(ngrid=(9, 8, 11, 7, 10), rank=5)),          # examples/skidding5d: lateral tyre forces, state-dependent boundcost, Q13
+    ("skid5d", dict(ngrid=(40,) * 5, rank=15)),                 # ... at the example's own size: N = 40, maxrank 15
+    ("cothrust6d", dict(ngrid=(7, 8, 6, 9, 5, 7), rank=6)),     # examples/cothrust2: 3 controls, accelerations = per-candidate features
+    ("cothrust6d", dict(ngrid=(20,) * 6, rank=10)),             # ... at the example's own size: N = 20, rank 10 (125 candidates)
 ]
 
 
@@ -379,8 +383,9 @@ def _with_cands(w, cands):
                                                ("lqg6d", dict(ngrid=(7, 8, 9, 6, 5, 7), rank=8), 9, 41),
                                                ("rossler3d", dict(ngrid=(17, 21, 19), rank=6), 33, 20001),
                                                ("perch7d", dict(ngrid=(6, 5, 7, 6, 5, 6, 5), rank=4), 65, 20001),
-                                               ("tprob3d", dict(ngrid=(9, 8, 7), rank=6), 21, 41)],
-                         ids=["lqg2d-du1", "lqg6d-du3", "rossler3d-du1", "perch7d-du1", "tprob3d-du3"])
+                                               ("tprob3d", dict(ngrid=(9, 8, 7), rank=6), 21, 41),
+                                               ("cothrust6d", dict(ngrid=(6, 5, 6, 7, 5, 6), rank=5), 9, 41)],
+                         ids=["lqg2d-du1", "lqg6d-du3", "rossler3d-du1", "perch7d-du1", "tprob3d-du3", "cothrust6d-du3"])
 def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
     """c3sc_hip_bellman_fibers_box: the non-BRUTEFORCE branch of bellman_optimal (bellman.c:545-1118).  The optimiser
     there is C3's BFGS (third party, unpinned), so the check is the reference's own (tprob_test.c:1494-1540):
@@ -397,6 +402,8 @@ def test_continuous_control_box_minimiser(oracle, name, kw, grid, fine):
         lb, ub = -2.0 * np.pi * np.ones(1), 2.0 * np.pi * np.ones(1)    # perch.c:329-330
     elif name == "tprob3d":
         lb, ub = -5.0 * np.ones(3), 5.0 * np.ones(3)                    # tprob_test.c:2463-2466
+    elif name == "cothrust6d":
+        lb, ub = np.array([-1.5, -0.4, -0.4]), np.array([1.5, 0.4, 0.4])  # copterposethrust.c:330-331 (features formed on the device)
     eng = _engine(w, cores, 0)
     eng.set_control_box(lb, ub, grid=grid, polish=2)
     n100 = 100 if w.du == 1 else 11

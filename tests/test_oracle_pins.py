@@ -586,3 +586,68 @@ def test_perch7d_model_restates_the_example(oracle):
         assert s.value == want_b
         out7 = np.zeros(7)
         assert L.orc_model_diff_diag(wl.MODEL_PERCH7D, None, oracle.dp(x), oracle.dp(u), oracle.dp(out7)) == 0 and (out7 == 1e-9).all()
+
+
+def test_skid5d_and_cothrust6d_models_restate_the_examples(oracle):
+    """ORC_MODEL_SKID5D against examples/skidding5d/scar.c:39-163 and ORC_MODEL_COTHRUST6D against
+    examples/cothrust2/copterposethrust.c:40-209, the callbacks written out here with Python's libm.  skidding5d's diffusion
+    callback writes out[28] of its 25-element matrix where out[18] was meant: the yaw rate's diagonal entry is
+    therefore 0 in the reference, and must be 0 here -- mirrored, not fixed."""
+    import ctypes as C
+    import math
+
+    from c3sc_amd import workloads as wl
+
+    L = oracle.lib()
+    rng = np.random.default_rng(31)
+    w = wl.WORKLOADS["skid5d"]()
+    assert w.bc == (wl.BC_REFLECT, wl.BC_REFLECT, wl.BC_PERIODIC, wl.BC_ABSORB, wl.BC_ABSORB) and w.discount == 1.0 and w.ncand == 20
+    m, cf, ct, a, b, In, s = 1460.0, 17000.0, 20000.0, 1.2, 1.5, 2170.0, 27.0
+    for _ in range(200):
+        x = rng.uniform(w.lb, w.ub)
+        u = rng.uniform(-5.0 * math.pi / 180.0, 5.0 * math.pi / 180.0, 1)
+        co, so = math.cos(x[2]), math.sin(x[2])
+        ff = cf * ((x[4] + a * x[3]) / s + u[0])
+        ft = ct * (x[4] - b * x[3]) / s
+        want = [s * co - x[4] * so, s * so + x[4] * co, x[3], (a * ff - b * ft) / In, -s * x[3] + (ff + ft) / m]
+        out = np.zeros(5)
+        assert L.orc_model_drift(wl.MODEL_SKID5D, None, oracle.dp(x), oracle.dp(u), oracle.dp(out)) == 0
+        np.testing.assert_allclose(out, want, rtol=4e-16, atol=0)
+        sv = C.c_double(0)
+        assert L.orc_model_stage(wl.MODEL_SKID5D, None, oracle.dp(x), oracle.dp(u), C.byref(sv)) == 0
+        o = 1.0 + 0.02 * x[0] ** 2 + 0.02 * x[1] ** 2
+        o = o + x[3] ** 2 + x[4] ** 2
+        assert sv.value == pytest.approx(o, rel=4e-16)
+        assert L.orc_model_boundcost(wl.MODEL_SKID5D, None, oracle.dp(x), C.byref(sv)) == 0
+        o = 0.1 * x[0] ** 2 + 0.1 * x[1] ** 2
+        o = o + 0.1 * x[3] ** 2 + 0.1 * x[4] ** 2
+        assert sv.value == pytest.approx(o, rel=4e-16)
+        sg = np.full(5, np.nan)
+        assert L.orc_model_diff_diag(wl.MODEL_SKID5D, None, oracle.dp(x), oracle.dp(u), oracle.dp(sg)) == 0
+        assert list(sg) == [1e-5, 1e-5, 1e-5, 0.0, 1e-5]  # Q13: out[28] instead of out[18]
+    w = wl.WORKLOADS["cothrust6d"]()
+    assert w.bc == (wl.BC_REFLECT,) * 6 and w.discount == 1.0 and w.ncand == 125
+    mq, g = 1.227, 9.81
+    mg = mq * g
+    for _ in range(200):
+        x = rng.uniform(w.lb, w.ub)
+        u = rng.uniform([-1.5, -0.4, -0.4], [1.5, 0.4, 0.4])
+        cphi, sphi, cth, sth = math.cos(u[1]), math.sin(u[1]), math.cos(u[2]), math.sin(u[2])
+        want = [x[3], x[4], x[5], cphi * sth * (u[0] - mg) / mq, -sphi * (u[0] - mg) / mq, g + cth * cphi * (u[0] - mg) / mq]
+        out = np.zeros(6)
+        assert L.orc_model_drift(wl.MODEL_COTHRUST6D, None, oracle.dp(x), oracle.dp(u), oracle.dp(out)) == 0
+        np.testing.assert_allclose(out, want, rtol=4e-16, atol=0)
+        sv = C.c_double(0)
+        assert L.orc_model_stage(wl.MODEL_COTHRUST6D, None, oracle.dp(x), oracle.dp(u), C.byref(sv)) == 0
+        o = 0.0
+        o = o + 60.0 + 2 * u[0] ** 2 + 1 * u[1] ** 2 + 6 * u[2] ** 2
+        o = o + 8.0 * x[2] ** 2
+        o = o + 6.0 * x[1] ** 2
+        o = o + 8.0 * x[0] ** 2
+        assert sv.value == pytest.approx(o, rel=4e-16)
+        assert L.orc_model_boundcost(wl.MODEL_COTHRUST6D, None, oracle.dp(x), C.byref(sv)) == 0 and sv.value == 10.0
+        sg = np.zeros(6)
+        assert L.orc_model_diff_diag(wl.MODEL_COTHRUST6D, None, oracle.dp(x), oracle.dp(u), oracle.dp(sg)) == 0
+        assert list(sg) == [1e-1, 1e-1, 2e-1, 12e-1, 12e-1, 12e-1]
+    # the callback refuses controls outside its box (copterposethrust.c:92-100)
+    assert L.orc_model_drift(wl.MODEL_COTHRUST6D, None, oracle.dp(np.zeros(6)), oracle.dp(np.array([2.0, 0.0, 0.0])), oracle.dp(np.zeros(6))) == 1

@@ -13,9 +13,9 @@ from c3sc_amd.engine import BellmanEngine, C3scHipError
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-BASES = ["lqg2d", "dubins3d", "lqg6d", "car7d", "quad10d", "scar4d", "rossler3d", "perch7d", "tprob3d"]
-MAXN = {"lqg2d": 128, "dubins3d": 128, "lqg6d": 40, "car7d": 48, "quad10d": 28, "scar4d": 64, "rossler3d": 64, "perch7d": 40, "tprob3d": 64}
-MAXR = {"lqg2d": 20, "dubins3d": 20, "lqg6d": 20, "car7d": 20, "quad10d": 20, "scar4d": 20, "rossler3d": 20, "perch7d": 20, "tprob3d": 20}
+BASES = ["lqg2d", "dubins3d", "lqg6d", "car7d", "quad10d", "scar4d", "rossler3d", "perch7d", "tprob3d", "skid5d", "cothrust6d"]
+MAXN = {"lqg2d": 128, "dubins3d": 128, "lqg6d": 40, "car7d": 48, "quad10d": 28, "scar4d": 64, "rossler3d": 64, "perch7d": 40, "tprob3d": 64, "skid5d": 48, "cothrust6d": 40}
+MAXR = {"lqg2d": 20, "dubins3d": 20, "lqg6d": 20, "car7d": 20, "quad10d": 20, "scar4d": 20, "rossler3d": 20, "perch7d": 20, "tprob3d": 20, "skid5d": 20, "cothrust6d": 20}
 t0 = time.time(); ncase = nfail = nrun = 0
 last_note = t0
 worst = 0.0

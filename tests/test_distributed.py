@@ -421,21 +421,54 @@ print("NOT REACHED")
 """
 
 
+_EXCHANGE_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from c3sc_amd.engine import load_library
+H = load_library()
+ctx = C.c_void_p()
+assert H.c3sc_hip_ctx_create(C.c_int(0), C.byref(ctx)) == 0
+idbuf = (C.c_char * 128)()
+assert H.c3sc_hip_comm_unique_id(idbuf) == 0
+comm = C.c_void_p()
+assert H.c3sc_hip_comm_create(ctx, C.c_int(1), C.c_int(0), idbuf, C.byref(comm)) == 0
+H.c3sc_hip_comm_exchange.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+F, N = 13, 7
+out = np.arange(F * N, dtype=np.float64).reshape(F, N)
+want = out.copy()
+assert H.c3sc_hip_comm_exchange(out.ctypes.data, F, N, 0, F, comm) == 0 and np.array_equal(out, want)   # the clean exchange
+os.environ["C3SC_INJECT_EXCHANGE_FAILURE"] = "1"
+rc = H.c3sc_hip_comm_exchange(out.ctypes.data, F, N, 0, F, comm)
+# the rank still went through the all-gather: what came back are its rows as it sent them -- marked NaN -- and the error code
+assert rc == 1 and np.isnan(out).all(), (rc, out[:2])
+print("ENTERED THE COLLECTIVE WITH NAN ROWS")
+"""
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("var,host", [("C3SC_INJECT_SHARD_FAILURE", False), ("C3SC_INJECT_EXCHANGE_FAILURE", True)],
-                         ids=["device-resident-step", "host-driven-exchange"])
-def test_rank_failure_in_a_sharded_sweep_enters_the_collective_and_stops(var, host):
-    """A rank whose launch (device-resident step, cross_device.hip: step_fibers) or whose staging copy (host-driven exchange,
-    comm_rccl.hip: c3sc_hip_comm_exchange) fails must still enter the RCCL all-gather with NaN rows and only then report the
-    error: here with a one-rank communicator -- the collective is entered (it would otherwise not return the marked rows), the
-    failure is detected on the gathered array, and the process ends with the library's error exit instead of 'NOT REACHED'."""
+def test_rank_failure_in_a_device_resident_sharded_sweep_enters_the_collective_and_stops():
+    """A rank whose launch fails in a device-resident sharded core step (cross_device.hip: step_fibers) must still enter the RCCL
+    all-gather with NaN rows and only then report the error: here with a one-rank communicator -- the failure is detected on the
+    gathered array (counters[3] = 2) and the process ends with the library's error exit instead of 'NOT REACHED'."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if host:
-        env["C3SC_HOST_CROSS"] = "1"
-    r = subprocess.run([sys.executable, "-c", _INJECT_SCRIPT.format(root=root, var=var)], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", _INJECT_SCRIPT.format(root=root, var="C3SC_INJECT_SHARD_FAILURE")], env=env, capture_output=True,
+                       text=True, timeout=300)
     assert r.returncode == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     assert "NOT REACHED" not in r.stdout
     assert "c3sc:" in r.stderr, r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_local_failure_in_the_host_driven_exchange_still_enters_the_all_gather():
+    """c3sc_hip_comm_exchange (comm_rccl.hip): a local failure before the collective (staging copy) no longer returns early -- the
+    peers would wait for ever -- but sends the rank's rows as NaN through ncclAllGather and returns 1 afterwards."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _EXCHANGE_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ENTERED THE COLLECTIVE WITH NAN ROWS" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])

@@ -147,6 +147,45 @@ def test_car7d_outer_loop_device_vs_oracle_side_by_side(oracle):
     orc.close()
 
 
+def test_literal_end_point_rule_outer_loop_device_vs_oracle_side_by_side(oracle):
+    """The REFERENCE'S OWN end-point rule (process_fibers_neighbor, nodeutil.c:570-612: the flags of a fiber's two end points come
+    from the varying dimension's boundary type, whatever the fixed dimensions say -- C3SC_LITERAL_ENDS=1 /
+    c3control_set_consistent_ends(0)) at solver level: the Dubins car has two absorbing dimensions, a periodic one and an obstacle,
+    so nodes on an absorbing face that are end points of a periodic fiber, and obstacle nodes that are end points, take the value of
+    whichever fiber reaches them first (memo: first stored wins, bellman.c:1349-1353).  The device-resident loop (device memo, same
+    order of core steps) and the oracle-fed loop (string memo) must make the same choice at every such node: every control update
+    from the same state agrees to 1e-6 of max |V| node by node.  The solver's default (consistent end points) is covered by the car7d
+    test above; this one keeps the literal rule covered at solver level."""
+    import regression_lib as R
+
+    w0 = wl.c2_dubins().scaled(ngrid=(21, 19, 17), rank=4)
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, w0.ranks, w0.discount, w0.bc, list(w0.obstacles),
+                    np.array([[-1.0], [0.07], [0.93]]))  # no exact ties between +u and -u (the scan's tie-break lives in C3)
+    cfg = dict(w=w, max_updates=13, conv=1e-9, adapt=1, startrank=4, maxrank=17, kick=3, cross_tol=1e-10, round_tol=1e-9, literal_ends=True,
+               start_fn=lambda X: 1.0 + ((X - 0.1) ** 2 * np.array([0.3, 0.5, 0.2])).sum(axis=1))
+    gpu, orc = R.GpuLoop(cfg), R.OracleLoop(cfg)
+    assert not gpu.consistent_ends and not orc.consistent_ends
+    Lb = gpu.L
+    # the rule really is in force: the literal and the consistent backup of the start value differ at end points (oracle, one fiber batch)
+    state = gpu.run(max_updates=1)
+    worst, diffs = 0.0, []
+    for _ in range(12):
+        a = gpu.run(max_updates=1, cost=C.c_void_p(Lb.valuef_copy(state)))
+        b = orc.run(max_updates=1, cost=C.c_void_p(Lb.valuef_copy(state)))
+        vb = orc.nodal(b)
+        diffs.append(np.abs(gpu.nodal(a) - vb).max() / np.abs(vb).max())
+        worst = max(worst, diffs[-1])
+        Lb.valuef_destroy(b)
+        Lb.valuef_destroy(state)
+        state = a
+    print("per update (literal end points):", " ".join(f"{x:.1e}" for x in diffs))
+    print(f"dubins3d {w.ngrid}, literal end-point rule: 12 control updates in lock-step: worst {worst:.1e}; |V| = {gpu.norm(state):.6e}, rank {gpu.rank(state)}")
+    assert worst <= 1e-6
+    Lb.valuef_destroy(state)
+    gpu.close()
+    orc.close()
+
+
 def test_rossler_example_outer_loop_device_vs_oracle_side_by_side(oracle):
     """examples/rossler/rossler.c:208-360 with its own settings (N = 20 on [-1,1]^3, reflecting box, beta = 0.1, start cost
     10 |x|^2, rank adaptation 2 -> N with kick 2, cross tol 1e-10, rounding 1e-8, pi_solve(10) + one vi step per update) and

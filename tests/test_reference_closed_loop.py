@@ -18,6 +18,7 @@ import regression_lib as R
 from c3sc_amd import workloads as wl
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOAL_HALF = 0.2  # goal_width / 2, tprob_test.c:1827, 1883-1886
 
 
@@ -119,3 +120,43 @@ def test_ref_bellman_pi3d_closed_loop_oracle_path(oracle):
     print(f"goal box reached: {bool(np.all(np.abs(xT) < PI3D_GOAL_HALF))}")
     assert np.all(np.isfinite(xT)) and np.all(xT > np.array(w.lb)) and np.all(xT < np.array(w.ub))
     assert abs(xT[0]) < PI3D_GOAL_HALF and abs(xT[1]) < 0.5
+
+
+def test_ref_bellman_pi3d_goal_box_is_missed_by_the_exact_discrete_optimum_too(oracle):
+    """WHY no path reproduces the goal box Test_bellman_pi3d asserts (tprob_test.c:2530-2535; the reference's runner never executes
+    that test, AllMyTests.c:59-62): the same problem solved without any low-rank format -- tests/golden/pi3d_dense_vstar.npz, the
+    dense V* on all 25^3 nodes by policy iteration with sparse direct solves (tools/run_reference_pi3d_dense.py) -- misses it as well.
+    (1) The fixture IS the fixed point of the oracle's operator: one sweep of orc bellman_vi over every fiber returns it to 1e-9
+        (measured 1.7e-13), so it is the exact solution of the discrete problem the reference's test sets up (discount 0.1 :2461,
+        boundary cost 100 :2498 / :302-309, unit noise s2, 5^3 candidates over the reference's control box).
+    (2) Its profile along x2 through the origin has its minimum near the MIDDLE of the x2 interval [-3, 1], not at 0: with unit
+        noise and absorbing faces of cost 100 one unit from the origin, staying away from the faces is worth more than the stage cost
+        2 x2^2 saved (V* ~ 62-64 there is almost all expected exit cost).  The optimal feedback therefore steers x2 to about -1.
+    (3) The noise-free closed loop of run_sim_3d_3d under the greedy policy of this exact V* ends with x2 outside the box.
+    The assertion is stale with respect to the problem as the test defines it; the replays assert what holds instead."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("run_reference_pi3d_dense", os.path.join(ROOT, "tools", "run_reference_pi3d_dense.py"))
+    RD = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(RD)
+    g = np.load(os.path.join(GOLDEN, "pi3d_dense_vstar.npz"))
+    V = g["V"]
+    w0 = wl.WORKLOADS["tprob3d"]()
+    assert V.shape == tuple(w0.ngrid) and np.array_equal(g["cands"], w0.cands)
+    Tv, _ = RD.oracle_sweep(w0, V)
+    err = np.abs(Tv - V).max()
+    print(f"dense V*: |T(V*) - V*|_max = {err:.2e} by the oracle's bellman_vi on every fiber (max V* {V.max():.1f})")
+    assert err <= 1e-9
+    xg = w0.xgrid()
+    i0, i1 = int(np.argmin(np.abs(xg[0]))), int(np.argmin(np.abs(xg[1])))
+    prof = V[i0, i1, 1:-1]
+    kmin = 1 + int(np.argmin(prof))
+    k0 = int(np.argmin(np.abs(xg[2])))
+    print(f"profile through the origin: minimum {prof.min():.3f} at x2 = {xg[2][kmin]:+.3f}, V*(0,0,0) = {V[i0, i1, k0]:.3f}")
+    assert -1.7 <= xg[2][kmin] <= -0.7 and V[i0, i1, k0] - prof.min() > 1.0
+    ranks, cores = RD.exact_train(V)
+    w = wl.Workload(w0.name, w0.model, w0.params, w0.dx, w0.du, w0.lb, w0.ub, w0.ngrid, ranks, w0.discount, w0.bc, [], w0.cands)
+    P = oracle.Problem(w, cores, consistent_ends=True)
+    xT = CL.simulate_rk4(CL.f3, CL.oracle_controller(oracle, P, w.cands), [-0.5, -0.5, 0.5], 10.0, 1e-2, 1e-2)
+    print(f"closed loop under the exact discrete optimum ends at {xT}: goal box reached: {bool(np.all(np.abs(xT) < PI3D_GOAL_HALF))}")
+    assert abs(xT[0]) < PI3D_GOAL_HALF and abs(xT[2]) > PI3D_GOAL_HALF and xT[2] < 0.0

@@ -40,7 +40,8 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 REFERENCE_CPU = {"value": 3.26e5, "unit": "nodes/s", "cores": 1,
                  "what": "the reference's own bellman_vi (src/*.c, gcc -O2 -ftree-vectorize, 1 thread; 5.76e4 with 8 OpenMP threads), "
                          "car7d batch, measured by the survey on the build container's Xeon @2.1 GHz (SURVEY.md section 6); "
-                         "context only -- the reference cannot travel to the GPU box"}
+                         "context only -- the reference cannot travel to the GPU box, and it cannot be re-measured in this repository: its "
+                         "sources need c3/*.h, cdyn/*.h and CBLAS, none of which exist here, and stand-in headers are not allowed (DESIGN.md 2)"}
 
 
 def _cpu_worker(workload, budget_s, wid):
@@ -597,6 +598,17 @@ def main():
         }
         # the step the other way round, measured after the timed region (never `value`): the d launches of a step are independent,
         # and c3sc_hip_bellman_fibers_all spreads them over three streams so that one dimension's tail overlaps the next one's head
+        res["multi_gpu_notes"] = {
+            "launch_mode": "the d launches of a step stay on ONE stream at every N (default): per-kernel durations are then what HIP events and "
+                           "rocprofv3 both see, which `roofline` is defined on; --overlap (c3sc_hip_bellman_fibers_all, three streams) must be "
+                           "given at every N or at none for a like-for-like scaling curve -- it lifts the 2^17-fibers-per-rank launch of an "
+                           "8-GPU strong-scaling run to the per-fiber rate of the 2^20 batch",
+            "sweep_end_core_update": "stand-in (data-dependent rescaling of the rank's slice of the cores, then the all-gather and the re-staging): "
+                                     "the roofline batch is 2^20 RANDOM fibers per dimension without cross structure, a real core step "
+                                     "(k_cross_core) on it would factor a meaningless matrix; the real core steps are timed through the solver "
+                                     "(vi_sweep) and run sharded under c3control_shard_over_gpus",
+            "failure_handling": "a rank whose launch or staging copy fails still enters the all-gather (rows marked NaN) and all ranks stop "
+                                "together (cross_device.hip step_fibers, comm_rccl.hip c3sc_hip_comm_exchange; tests/test_distributed.py)"}
         res["step_launch_mode"] = "overlapped (c3sc_hip_bellman_fibers_all, three streams)" if args.overlap else "one stream, d launches in order"
         if other is not None:
             res["other_mode_step"] = {

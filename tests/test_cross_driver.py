@@ -161,6 +161,32 @@ def test_elevated_cross_rank_rounded_to_the_cap_is_near_the_best_train():
     assert errs[3 * cap] <= 1.5 * best
 
 
+def test_elevated_cross_rank_edge_cases():
+    """crossrank is clamped per bond to the smaller side of the unfolding (a 2-D function on 9 x 30 nodes cannot have a bond above 9),
+    is ignored without rank adaptation (adapt = 0: no kicks, the start rank stays), is carried over by a warm start (the second
+    interpolation starts from the first one's CROSS ranks and index sets, not from the rounded ranks + 1) and never lets the result
+    exceed maxrank; an exactly low-rank function is still recovered to rounding accuracy."""
+    L, fl = _lib()
+    g2 = [np.linspace(-1, 1, 9), np.linspace(0, 2, 30)]
+    f2 = lambda X: np.exp(-((X[:, 0] - 0.3 * X[:, 1]) ** 2)) + 0.1 * np.abs(X[:, 0] + X[:, 1] - 1.0)
+    vf, ranks, calls = _interp(L, fl, f2, g2, startrank=2, kickrank=3, maxrank=4, crossrank=64, cross_tol=1e-10, round_tol=1e-10, batch=True)
+    assert ranks == [1, 4, 1], ranks
+    assert calls["fibers"] <= 2 * 5 * 3 * (9 + 30) * 2  # cross ranks stopped at 9, the smaller side
+    vf2, ranks2, calls2 = _interp(L, fl, lambda X: f2(X) * 1.01, g2, vref=vf, startrank=2, kickrank=3, maxrank=4, crossrank=64, cross_tol=1e-10,
+                                  round_tol=1e-10, batch=True)
+    assert ranks2 == [1, 4, 1] and calls2["fibers"] < calls["fibers"]  # no rank search from the start rank again
+    L.valuef_destroy(vf)
+    L.valuef_destroy(vf2)
+    grids = [np.linspace(-1, 2, 11), np.linspace(-2, 3, 12), np.linspace(0, 1, 10)]
+    quad = lambda X: (X ** 2).sum(axis=1) + 0.5  # TT rank 2
+    vf, ranks, _ = _interp(L, fl, quad, grids, startrank=3, maxrank=3, crossrank=9, adapt=0)
+    assert max(ranks) <= 3 and _nodal_error(L, fl, vf, quad, grids) < 1e-9
+    L.valuef_destroy(vf)
+    vf, ranks, _ = _interp(L, fl, quad, grids, startrank=2, kickrank=2, maxrank=3, crossrank=9)
+    assert max(ranks) == 2 and _nodal_error(L, fl, vf, quad, grids) < 1e-9  # rounding still trims to the true rank
+    L.valuef_destroy(vf)
+
+
 def test_continuous_norms_and_offgrid_eval():
     L, fl = _lib()
     # constant 0.2 on [-2,2]^2 (tprob_test.c quad2d): ||V||_L2 = 0.2 * 4

@@ -33,7 +33,12 @@ constexpr int NT = 512;                       // threads of the core-step workgr
 constexpr int MAXROWS = 8192;                 // rows of a fiber matrix (N r): 16 per thread
 constexpr unsigned long long IDX_BITS = 22;   // low bits of a pivot-search key hold the (inverted) index
 constexpr unsigned long long IDX_MASK = (1ull << IDX_BITS) - 1;
-constexpr size_t LDS_CAP_BYTES = 132 * 1024;  // dynamic LDS of the general core step: 160 KB of a CU minus its 17 KB of static arrays
+#ifndef C3SC_CROSS_MAXR
+#define C3SC_CROSS_MAXR 32                   // largest rank of a core step (static LDS arrays below); 48 was built once to measure cross rank 40
+#endif
+constexpr int MAXR = C3SC_CROSS_MAXR;
+// dynamic LDS of the general core step: 160 KB of a CU minus its static arrays (17 KB at MAXR = 32)
+constexpr size_t LDS_CAP_BYTES = (132 - (MAXR > 32 ? (MAXR * MAXR - 1024) * 8 / 1024 + 2 : 0)) * 1024;
 
 struct Strides { long long s[MAXD]; };
 
@@ -212,8 +217,8 @@ __device__ inline void mark_warm_rows(const CoreArgs &P, int m, int n, unsigned 
     // one thread per (old tuple q, candidate tuple a): the first matching a (lowest index, as a sequential scan would find it) names
     // the row.  The sequential scan it replaces -- one thread per old tuple, up to nin x lin dependent LDS reads -- was 6-10 k
     // cycles of a 64 k-cycle step.
-    __shared__ int firsta[32];
-    if (tid < 32) firsta[tid] = 0x7fffffff;
+    __shared__ int firsta[MAXR];
+    if (tid < MAXR) firsta[tid] = 0x7fffffff;
     __syncthreads();
     if (P.warm)
         for (int e = tid; e < n * nin; e += NT) {
@@ -310,13 +315,13 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
     unsigned long long tlast__ = clock64();
 #endif
     extern __shared__ double smem[];
-    __shared__ double Lr[32 * 32];
-    __shared__ double rowv[32];
-    __shared__ double pivabs[32];
-    __shared__ int rows[32], srows[32], pos[32];
+    __shared__ double Lr[MAXR * MAXR];
+    __shared__ double rowv[MAXR];
+    __shared__ double pivabs[MAXR];
+    __shared__ int rows[MAXR], srows[MAXR], pos[MAXR];
     __shared__ unsigned long long red[2 * (NT / 64)];
     __shared__ unsigned char warmf[MAXROWS];
-    __shared__ int s_in[32 * MAXD], s_old[32 * MAXD];
+    __shared__ int s_in[MAXR * MAXD], s_old[MAXR * MAXD];
     const int tid = threadIdx.x;
     const int r0 = P.r0, N = P.N, r1 = P.r1;
     if (P.copy_only) { // G[a + r0 (j + N b)] = out[(a + r0 b) N + j]
@@ -392,7 +397,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
     // ---- B = L inv(L[rows]): L[rows] is unit lower triangular in pivot order
     for (int e = tid; e < n * n; e += NT) {
         const int q = e / n, j = e % n;
-        Lr[q * 32 + j] = j < q ? A[rows[q] + j * m] : (j == q ? 1.0 : 0.0);
+        Lr[q * MAXR + j] = j < q ? A[rows[q] + j * m] : (j == q ? 1.0 : 0.0);
     }
     __syncthreads();
     for (int i = tid, q = 0; i < m; i += NT, q++) {
@@ -405,7 +410,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
                 for (int u = 0; u < CH; u++) {
                     const int t = t0 + u < n ? t0 + u : n - 1;
                     xt[u] = A[i + t * m];
-                    w[u] = Lr[t * 32 + j];
+                    w[u] = Lr[t * MAXR + j];
                 }
 #pragma unroll
                 for (int u = 0; u < CH; u++) if (t0 + u < n) s -= xt[u] * w[u];
@@ -607,7 +612,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     size_t fmax = 1, nmax = 1, wmax = 1;
     x->d = d;
     for (int k = 0; k <= d; k++) {
-        if (ranks[k] < 1 || ranks[k] > 32) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_setup: ranks up to 32");
+        if (ranks[k] < 1 || ranks[k] > MAXR) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_setup: ranks up to 32 (C3SC_CROSS_MAXR)");
         x->r[k] = (int)ranks[k];
     }
     // layout of the slab for these ranks

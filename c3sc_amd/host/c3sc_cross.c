@@ -934,7 +934,10 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     size_t crank = approx_args_get_crossrank(aargs);
     if (getenv("C3SC_CROSS_RANK_FACTOR")) crank = (size_t)ceil(atof(getenv("C3SC_CROSS_RANK_FACTOR")) * (double)maxrank);
     if (crank < maxrank) crank = maxrank;
-    if (dev != NULL && crank > 32) crank = 32 > maxrank ? 32 : maxrank; /* c3sc_hip_cross_setup: ranks up to 32 */
+    {
+        const size_t devcap = getenv("C3SC_CROSS_MAXR") ? (size_t)atoi(getenv("C3SC_CROSS_MAXR")) : 32; /* c3sc_hip_cross_setup: ranks up to 32 (a build with -DC3SC_CROSS_MAXR=48 serves 48) */
+        if (dev != NULL && crank > devcap) crank = devcap > maxrank ? devcap : maxrank;
+    }
     /* per bond: the reference's clamp to min N (Q12) holds for maxrank; an elevated cross rank is bounded by the sizes of the two
      * sides of its unfolding only */
     size_t *crk = xcalloc(d + 1, sizeof(size_t));

@@ -176,13 +176,13 @@ def skid5d(n=40, r=15) -> Workload:
 def cothrust6d(n=20, r=10) -> Workload:
     """examples/cothrust2/copterposethrust.c:277-383: quadcopter position + velocity, N = 20, every face reflecting, beta = 1,
     rank 10 (start = max), obstacle = the target box around (0, 0, 0, 1, 0, 0); its BFGS box (thrust, roll, pitch) in
-    [-1.5, 1.5] x [-0.4, 0.4]^2 as a 5 x 5 x 5 candidate list, slightly off-centre (set_control_box gives the continuous minimiser
-    over the same box)."""
+    [-1.5, 1.5] x [-0.4, 0.4]^2 as a 4 x 4 x 4 candidate list (64 candidates: the longest list the fiber-pair kernel serves), slightly
+    off-centre (set_control_box gives the continuous minimiser over the same box)."""
     lb = (-3.5, -3.5, -2.0, -5.0, -5.0, -5.0)
     ub = (0.2, 3.5, 2.0, 5.0, 5.0, 5.0)
     goal = ((0.0, 0.0, 0.0, 1.0, 0.0, 0.0), (0.4, 0.4, 0.4, 0.5, 0.4, 0.4))
-    a0 = (np.linspace(-1.5, 1.5, 5) + 0.011).clip(-1.5, 1.5)
-    a1 = (np.linspace(-0.4, 0.4, 5) + 0.003).clip(-0.4, 0.4)
+    a0 = (np.linspace(-1.5, 1.5, 4) + 0.011).clip(-1.5, 1.5)
+    a1 = (np.linspace(-0.4, 0.4, 4) + 0.003).clip(-0.4, 0.4)
     return Workload("cothrust6d", MODEL_COTHRUST6D, (), 6, 3, lb, ub, (n,) * 6, uniform_ranks(6, r), 1.0, (BC_REFLECT,) * 6, [goal],
                     _grid_cands([a0, a1, a1]))
 

@@ -40,7 +40,7 @@ SMALL = [
     ("skid5d", dict(ngrid=(9, 8, 11, 7, 10), rank=5)),          # examples/skidding5d: lateral tyre forces, state-dependent boundcost, Q13
     ("skid5d", dict(ngrid=(40,) * 5, rank=15)),                 # ... at the example's own size: N = 40, maxrank 15
     ("cothrust6d", dict(ngrid=(7, 8, 6, 9, 5, 7), rank=6)),     # examples/cothrust2: 3 controls, accelerations = per-candidate features
-    ("cothrust6d", dict(ngrid=(20,) * 6, rank=10)),             # ... at the example's own size: N = 20, rank 10 (125 candidates)
+    ("cothrust6d", dict(ngrid=(20,) * 6, rank=10)),             # ... at the example's own size: N = 20, rank 10 (64 candidates)
 ]
 
 

@@ -626,7 +626,7 @@ def test_skid5d_and_cothrust6d_models_restate_the_examples(oracle):
         assert L.orc_model_diff_diag(wl.MODEL_SKID5D, None, oracle.dp(x), oracle.dp(u), oracle.dp(sg)) == 0
         assert list(sg) == [1e-5, 1e-5, 1e-5, 0.0, 1e-5]  # Q13: out[28] instead of out[18]
     w = wl.WORKLOADS["cothrust6d"]()
-    assert w.bc == (wl.BC_REFLECT,) * 6 and w.discount == 1.0 and w.ncand == 125
+    assert w.bc == (wl.BC_REFLECT,) * 6 and w.discount == 1.0 and w.ncand == 64
     mq, g = 1.227, 9.81
     mg = mq * g
     for _ in range(200):

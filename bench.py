@@ -220,35 +220,47 @@ def solver_measurements(workload, budget_s):
 
     # "VI iterations to tolerance": c3control_vi_solve's own loop (bellman.c:2282-2340: stop when the L2 step between iterates falls
     # below abs_conv_tol), one sweep per call so that the step series is kept; start value 0
-    aa = aargs(1e-6, 1e-6, 4, 4, rmax, 2 * rmax)
+    xr = 4 * rmax  # cross approximation at four times the rank cap, its result rounded to the cap (approx_args_set_crossrank)
+    aa = aargs(1e-6, 1e-6, 4, 4, rmax, xr)
     zero = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.0), 0)[1])
     cost = C.c_void_p(L.c3control_init_value(ctl.h, zero, None, aa, 0))
     diag = C.c_void_p(None)
-    tol_rel, t0, nsw, conv, steps, norms = 1e-3, time.perf_counter(), 0, False, [], []
-    while time.perf_counter() - t0 < budget_s:
+    vi_budget = 2.0 * budget_s
+    tol_rel, t0, nsw, conv, steps, norms, nb_total = 1e-3, time.perf_counter(), 0, False, [], [], 0
+    while time.perf_counter() - t0 < vi_budget:
         nxt = C.c_void_p(L.c3control_step_vi(ctl.h, cost, aa, ctl.opt, 0, C.byref(ne)))
+        nb_total += ne.value
         steps.append(L.valuef_norm2diff(cost, nxt))
         L.valuef_destroy(cost)
         cost = nxt
         nsw += 1
-        if nsw % 50 == 0 or nsw < 4:
-            norms.append(L.valuef_norm(cost))
-        if nsw % 50 == 0 and steps[-1] < tol_rel * norms[-1]:
+        norms.append(L.valuef_norm(cost))
+        if steps[-1] < tol_rel * norms[-1]:  # c3control_vi_solve's test (bellman.c:2335) with abs_conv_tol = tol_rel |V|
             conv = True
             break
-    norm = L.valuef_norm(cost)
-    tail = np.array(steps[-200:])
-    iters = {"converged": conv, "tol_rel_L2": tol_rel, "sweeps": nsw, "seconds": time.perf_counter() - t0, "ms_per_sweep": 1e3 * (time.perf_counter() - t0) / max(nsw, 1),
-             "last_step_L2": steps[-1], "norm_L2": norm, "last_step_rel": steps[-1] / norm if norm else None,
-             "median_step_rel_last_200": float(np.median(tail)) / norm if norm else None,
-             "first_sweep_with_step_rel_below_1e-2": next((i for i, sv in enumerate(steps) if sv < 1e-2 * norm), None),
-             "rank_cap": rmax, "cross_rank": 2 * rmax, "wall_budget_s": budget_s,
+    t_conv = time.perf_counter() - t0
+    # what the iteration does after the tolerance was met: 60 more sweeps, so that the step floor is on record beside the count
+    after = []
+    for _ in range(60 if conv else 0):
+        nxt = C.c_void_p(L.c3control_step_vi(ctl.h, cost, aa, ctl.opt, 0, C.byref(ne)))
+        after.append(L.valuef_norm2diff(cost, nxt) / L.valuef_norm(nxt))
+        L.valuef_destroy(cost)
+        cost = nxt
+    norm = norms[-1] if norms else 0.0
+    rel = [sv / nv for sv, nv in zip(steps, norms) if nv > 0]
+    iters = {"converged": conv, "tol_rel_L2": tol_rel, "sweeps": nsw, "seconds": t_conv, "ms_per_sweep": 1e3 * t_conv / max(nsw, 1),
+             "node_backups": nb_total, "last_step_L2": steps[-1], "norm_L2": norm, "last_step_rel": steps[-1] / norm if norm else None,
+             "step_rel_every_25_sweeps": [float(f"{v:.3e}") for v in rel[::25]],
+             "step_rel_floor_60_sweeps_after_convergence": {"median": float(np.median(after)), "min": float(np.min(after)), "max": float(np.max(after))} if after else None,
+             "first_sweep_with_step_rel_below_1e-2": next((i for i, v in enumerate(rel) if v < 1e-2), None),
+             "rank_cap": rmax, "cross_rank": xr, "wall_budget_s": vi_budget,
              "end_point_rule": "consistent ends (c3control_set_consistent_ends, the C3Control default; C3SC_LITERAL_ENDS=1 restores nodeutil.c:570-612)",
-             "what": "pure value iteration (c3control_vi_solve's loop, one sweep per call) through libc3sc.so from the start value 0 until "
-                     "|V_i+1 - V_i|_L2 < tol_rel |V|_L2; cross approximation at twice the rank cap, rounded to the cap (approx_args_set_crossrank). "
-                     "On this exit-time problem (discount 0, contraction ~1 - 2.5e-3 per sweep) every sweep's approximation error enters a "
-                     "weakly contracting iteration: the step reaches a floor set by that error (3.6e-3 relative with the cross at the cap, "
-                     "2.5e-3 at twice, 1.3e-3 at three times the cap -- DESIGN.md 6.2) instead of the tolerance; dubins3d below converges"}
+             "what": "pure value iteration (c3control_vi_solve's loop and stopping test, one sweep per call so that the series is kept) through "
+                     "libc3sc.so from the start value 0 until |V_i+1 - V_i|_L2 < tol_rel |V_i+1|_L2.  The value function keeps FT rank 10 (the "
+                     f"kernels' input); the cross approximation of T(V) runs at ranks up to {xr} and is cut back to 10 by the TT-SVD "
+                     "(approx_args_set_crossrank).  On this exit-time problem (discount 0, contraction ~1 - 2.5e-3 per sweep) the step floor is the "
+                     "per-sweep noise of the re-selected cross: 3.6e-3 / 2.5e-3 / 1.3e-3 / 0.9e-3 of |V| at cross rank 10 / 20 / 30 / 40 "
+                     "(DESIGN.md 6.2, profiles/r04_vi_to_tol_car7d_rank10_crossrank*.txt): 40 is the first that passes a 1e-3 tolerance"}
     L.valuef_destroy(cost)
     L.approx_args_free(aa)
     ctl.close()

@@ -33,12 +33,12 @@ constexpr int NT = 512;                       // threads of the core-step workgr
 constexpr int MAXROWS = 8192;                 // rows of a fiber matrix (N r): 16 per thread
 constexpr unsigned long long IDX_BITS = 22;   // low bits of a pivot-search key hold the (inverted) index
 constexpr unsigned long long IDX_MASK = (1ull << IDX_BITS) - 1;
-#ifndef C3SC_CROSS_MAXR
-#define C3SC_CROSS_MAXR 32                   // largest rank of a core step (static LDS arrays below); 48 was built once to measure cross rank 40
-#endif
-constexpr int MAXR = C3SC_CROSS_MAXR;
-// dynamic LDS of the general core step: 160 KB of a CU minus its static arrays (17 KB at MAXR = 32)
-constexpr size_t LDS_CAP_BYTES = (132 - (MAXR > 32 ? (MAXR * MAXR - 1024) * 8 / 1024 + 2 : 0)) * 1024;
+// Largest rank of a core step.  Ranks up to LDSR = 32 keep the unit-triangular factor L[rows] in a static LDS array next to the
+// matrix; a step with a larger rank (an elevated cross rank, approx_args_set_crossrank: 40 is what car7d 41^7 needs for a 1e-3
+// value-iteration step) never fits LDS with its matrix anyway (41 x 40 x 40 doubles = 525 KB): it runs on global scratch and takes
+// its MAXR x MAXR factor from the dynamic LDS block the matrix does not use.
+constexpr int MAXR = 48, LDSR = 32;
+constexpr size_t LDS_CAP_BYTES = 132 * 1024;  // dynamic LDS of the general core step: 160 KB of a CU minus its 17 KB of static arrays
 
 struct Strides { long long s[MAXD]; };
 
@@ -315,7 +315,9 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
     unsigned long long tlast__ = clock64();
 #endif
     extern __shared__ double smem[];
-    __shared__ double Lr[MAXR * MAXR];
+    __shared__ double Lr_s[LDSR * LDSR];
+    double *Lr = INLDS ? Lr_s : smem; // !INLDS: MAXR x MAXR doubles of dynamic LDS (the matrix lives in global scratch)
+    constexpr int LS = INLDS ? LDSR : MAXR;
     __shared__ double rowv[MAXR];
     __shared__ double pivabs[MAXR];
     __shared__ int rows[MAXR], srows[MAXR], pos[MAXR];
@@ -397,7 +399,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
     // ---- B = L inv(L[rows]): L[rows] is unit lower triangular in pivot order
     for (int e = tid; e < n * n; e += NT) {
         const int q = e / n, j = e % n;
-        Lr[q * MAXR + j] = j < q ? A[rows[q] + j * m] : (j == q ? 1.0 : 0.0);
+        Lr[q * LS + j] = j < q ? A[rows[q] + j * m] : (j == q ? 1.0 : 0.0);
     }
     __syncthreads();
     for (int i = tid, q = 0; i < m; i += NT, q++) {
@@ -410,7 +412,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
                 for (int u = 0; u < CH; u++) {
                     const int t = t0 + u < n ? t0 + u : n - 1;
                     xt[u] = A[i + t * m];
-                    w[u] = Lr[t * MAXR + j];
+                    w[u] = Lr[t * LS + j];
                 }
 #pragma unroll
                 for (int u = 0; u < CH; u++) if (t0 + u < n) s -= xt[u] * w[u];
@@ -612,7 +614,7 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     size_t fmax = 1, nmax = 1, wmax = 1;
     x->d = d;
     for (int k = 0; k <= d; k++) {
-        if (ranks[k] < 1 || ranks[k] > MAXR) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_setup: ranks up to 32 (C3SC_CROSS_MAXR)");
+        if (ranks[k] < 1 || ranks[k] > MAXR) return fail(c, C3SC_ERR_UNSUPPORTED, "cross_setup: ranks up to 48");
         x->r[k] = (int)ranks[k];
     }
     // layout of the slab for these ranks
@@ -872,8 +874,8 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         }
         const size_t mn = F * N * sizeof(double);
         if (P.copy_only) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), 0, st, P);
-        else if (mn <= LDS_CAP_BYTES) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), mn, st, P);
-        else hipLaunchKernelGGL(k_cross_core<false>, dim3(1), dim3(NT), 0, st, P);
+        else if (mn <= LDS_CAP_BYTES && r0 <= LDSR && r1 <= LDSR) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), mn, st, P);
+        else hipLaunchKernelGGL(k_cross_core<false>, dim3(1), dim3(NT), (size_t)MAXR * MAXR * sizeof(double), st, P);
     }
     HIPCHK(c, hipGetLastError());
     return C3SC_OK;
@@ -923,6 +925,7 @@ int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
         P.stamps = nullptr;
 #endif
         if (!P.copy_only) maxmn = std::max(maxmn, (size_t)P.r0 * P.r1 * P.N * sizeof(double));
+        if (P.r0 > LDSR || P.r1 > LDSR) maxmn = LDS_CAP_BYTES + 1; // a rank above 32: the global-scratch form for all steps
     }
     HIPCHK(c, hipMemsetAsync(mismatch, 0, sizeof(int), st));
     HIPCHK(c, hipMemcpyAsync(x->slab + x->off_steps, h, 2 * d * sizeof(CoreArgs), hipMemcpyHostToDevice, st));
@@ -931,7 +934,7 @@ int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
     if (maxmn <= LDS_CAP_BYTES)
         hipLaunchKernelGGL(k_cross_confirm<true>, dim3(2 * d), dim3(NT), maxmn, st, (const CoreArgs *)(x->slab + x->off_steps));
     else
-        hipLaunchKernelGGL(k_cross_confirm<false>, dim3(2 * d), dim3(NT), 0, st, (const CoreArgs *)(x->slab + x->off_steps));
+        hipLaunchKernelGGL(k_cross_confirm<false>, dim3(2 * d), dim3(NT), (size_t)MAXR * MAXR * sizeof(double), st, (const CoreArgs *)(x->slab + x->off_steps));
     HIPCHK(c, hipGetLastError());
     // the flag and, in the same wait, everything a successful confirmation is followed by (c3sc_hip_cross_fetch then copies from
     // the pinned block); after a mismatch the block is stale and the counters it brought wait in `pending`

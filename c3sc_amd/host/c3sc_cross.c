@@ -935,7 +935,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     if (getenv("C3SC_CROSS_RANK_FACTOR")) crank = (size_t)ceil(atof(getenv("C3SC_CROSS_RANK_FACTOR")) * (double)maxrank);
     if (crank < maxrank) crank = maxrank;
     {
-        const size_t devcap = getenv("C3SC_CROSS_MAXR") ? (size_t)atoi(getenv("C3SC_CROSS_MAXR")) : 32; /* c3sc_hip_cross_setup: ranks up to 32 (a build with -DC3SC_CROSS_MAXR=48 serves 48) */
+        const size_t devcap = 48; /* c3sc_hip_cross_setup: ranks up to 48 (cross_device.hip: MAXR) */
         if (dev != NULL && crank > devcap) crank = devcap > maxrank ? devcap : maxrank;
     }
     /* per bond: the reference's clamp to min N (Q12) holds for maxrank; an elevated cross rank is bounded by the sizes of the two

@@ -294,8 +294,9 @@ def test_speculative_first_iteration_same_bits_and_actually_used(name, kw, aargs
     ("dubins3d", dict(ngrid=(41, 41, 41), rank=4), dict(maxrank=12, kick=3)),
     ("lqg2d", dict(ngrid=(60, 60), rank=4), dict(maxrank=20, kick=5)),  # core steps of up to 60 x 20 x 20: the factorisation leaves LDS
     ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=2, crossrank=10)),  # cross at rank 10, rounded to 5
-    ("car7d", dict(), dict(maxrank=10, kick=4, crossrank=20)),          # the bench's vi_iters_to_tol configuration: cross rank 20 -> 10
-], ids=["car7d-small", "car7d-41", "dubins3d", "lqg2d", "car7d-small-crossrank10", "car7d-41-crossrank20"])
+    ("car7d", dict(), dict(maxrank=10, kick=4, crossrank=20)),          # cross rank 20 -> 10 at full size (the matrices still fit LDS)
+    ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=9, crossrank=40)),  # ranks above 32: global-scratch core steps
+], ids=["car7d-small", "car7d-41", "dubins3d", "lqg2d", "car7d-small-crossrank10", "car7d-41-crossrank20", "car7d-small-crossrank40"])
 def test_device_resident_cross_iterations_match_the_host_driver(name, kw, aargs):
     """c3control_step_vi with whole cross iterations on the device (c3sc_hip_cross_*: fiber index lists, Bellman launches, node
     memo, pivoted factorisation + maxvol of every core step on one stream) against the same sweeps driven from the host

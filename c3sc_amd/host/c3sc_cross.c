@@ -1005,6 +1005,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     for (int round = 0; round < 50; round++) {
         struct tt *prev = NULL, *cur = NULL;
         double rel = 1.0, prev2 = -1.0; /* prev2 = <prev, prev> once known */
+        int pending = 0;                /* a convergence test deferred to the next iteration's confirmation */
         for (size_t it = 0; it < maxiter; it++) {
             c.deficient = 0;
             int **Iold = copy_sets(&c, c.I, 0), **Jold = copy_sets(&c, c.J, 1);
@@ -1033,6 +1034,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                     if (trace) fprintf(stderr, "c3sc cross trace: round 0: speculative iteration confirmed\n");
                 } else if (trace) fprintf(stderr, "c3sc cross trace: round 0: speculative iteration not confirmed\n");
             }
+            int stop_now = 0;
             if (t2 == NULL && c.dev && it > 0 && !c.dev_fresh && c.dev_confirm) {
                 /* The previous iteration changed index sets; the next one usually changes nothing.  The device can establish that
                  * in one launch -- all 2 d core steps side by side on the fiber values they already hold, comparing instead of
@@ -1049,7 +1051,22 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                     for (size_t k = 0; k < d; k++) { c.nfibers += 2 * c.r[k] * c.r[k + 1]; c.dev_requested += 2 * c.r[k] * c.r[k + 1] * c.N[k]; }
                 }
                 g_tc[1] += tnow() - t_cf;
+                if (!ok && pending) {
+                    /* the convergence test the previous iteration left open (see below): its iterate against the one before */
+                    const double t_conv = tnow();
+                    double cur2 = -1.0;
+                    rel = tt_rel_change(cur, prev, prev2, &cur2, cross_tol);
+                    if (verbose > 1) printf("  cross sweep %zu: relative change %.3e (fibers so far %zu)\n", it, rel, c.nfibers);
+                    if (trace) fprintf(stderr, "c3sc cross trace:   relative change %.3e (tol %.1e)\n", rel, cross_tol);
+                    tt_free(prev);
+                    prev = tt_copy(cur);
+                    prev2 = cur2;
+                    g_tc[3] += tnow() - t_conv;
+                    if (rel < cross_tol) stop_now = 1;
+                }
+                pending = 0;
             }
+            if (stop_now) { free_sets(&c, Iold); free_sets(&c, Jold); break; }
             if (t2 != NULL) { /* confirmed: sets unchanged by construction */ }
             else if (c.dev) TIMED(0, t2 = cross_iteration_device(&c));
             else {
@@ -1068,6 +1085,16 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             tt_free(cur);
             cur = t2;
             if (fixed_point) { if (verbose > 1) printf("  cross sweep %zu: index sets reproduced (fixed point)\n", it + 1); break; }
+            if (it + 1 >= maxiter) break; /* the last iteration: its result is taken whatever the test would say */
+            if (prev != NULL && c.dev && c.dev_confirm && c.dev_pol == NULL) { /* bellman_pi counts the fibers an iteration requests: not deferred there */
+                /* Device path: the next iteration starts with the one-launch confirmation.  If it confirms, the iteration it stands
+                 * for returns THIS iterate again (its right-to-left steps see the same fibers and the same final index sets), so the
+                 * loop ends at the fixed point with the same train whether or not the relative change was below the tolerance -- the
+                 * test (a Gram recursion over both trains: 1 ms at rank 20, 7 ms at rank 40) is only needed if the confirmation
+                 * fails, and is made then, with the same operands and the same consequence.  Same decisions as the host-driven path. */
+                pending = 1;
+                continue;
+            }
             const double t_conv = tnow();
             double cur2 = -1.0;
             if (prev != NULL) {

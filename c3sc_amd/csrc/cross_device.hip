@@ -300,7 +300,8 @@ __device__ inline void write_sets_and_next(const CoreArgs &P, int n, const int *
 // Everything a thread does to one of its rows is written as chunks of CH columns: the loads of a chunk are issued together
 // and the arithmetic follows (left to itself the compiler keeps one LDS round trip per element in flight, because every
 // store into the matrix might alias the next load: the kernel was 45 us of pure latency that way).
-constexpr int CH = 8;
+constexpr int CH_LDS = 8, CH_GLOBAL = 8; // 24 loads per trip on global scratch were measured SLOWER (rank-40 steps: 16.6 -> 21.4 ms per sweep: the
+                                        // chunk is issued in full even where few trailing columns remain)
 
 #ifdef C3SC_CORE_STAMPS
 #define CORE_STAMP(slot) do { __syncthreads(); if (threadIdx.x == 0 && P.stamps) { const unsigned long long now__ = clock64(); P.stamps[slot] += now__ - tlast__; tlast__ = now__; } } while (0)
@@ -314,6 +315,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
 #ifdef C3SC_CORE_STAMPS
     unsigned long long tlast__ = clock64();
 #endif
+    constexpr int CH = INLDS ? CH_LDS : CH_GLOBAL;
     extern __shared__ double smem[];
     __shared__ double Lr_s[LDSR * LDSR];
     double *Lr = INLDS ? Lr_s : smem; // !INLDS: MAXR x MAXR doubles of dynamic LDS (the matrix lives in global scratch)

@@ -147,9 +147,10 @@ def solver_measurements(workload, budget_s):
     ctl = facade_lib.Control(w, consistent_ends=None)  # the library's default (c3control_set_consistent_ends: on)
     rmax = max(w.ranks)
 
-    def aargs(cross, rnd, kick, start, maxrank, crossrank=0):
+    def aargs(cross, rnd, kick, start, maxrank, crossrank=0, cross_maxiter=5):
         aa = C.c_void_p(L.approx_args_init())
         L.approx_args_set_crossrank(aa, C.c_size_t(crossrank))  # 0: the cross approximation runs at maxrank (the reference's scheme)
+        L.approx_args_set_cross_maxiter(aa, C.c_size_t(cross_maxiter))  # 5: the reference's cap on cross iterations (valuefunc.c:632)
         L.approx_args_set_cross_tol(aa, C.c_double(cross))
         L.approx_args_set_round_tol(aa, C.c_double(rnd))
         L.approx_args_set_kickrank(aa, C.c_size_t(kick))
@@ -194,6 +195,17 @@ def solver_measurements(workload, budget_s):
     xrows = xrows[6:]
     xms, xnb = 1e3 * float(np.mean([r[0] for r in xrows])), float(np.mean([r[1] for r in xrows]))
     L.approx_args_free(aa2)
+    # one cross iteration per sweep (approx_args_set_cross_maxiter(1)): inside a value iteration every sweep warm-starts from the previous
+    # sweep's index sets, so the sweeps themselves play the role of the cross iterations -- same step floor, fewer core steps
+    one = {}
+    for tag, xr1 in (("cross_at_the_cap", 0), ("crossrank2x", 2 * rmax)):
+        aa3 = aargs(1e-6, 1e-5, 4, 4, rmax, xr1, 1)
+        orows, oranks = sweeps(40, False, aa3)
+        orows = orows[12:]  # ranks need more sweeps to reach the cap with one iteration each
+        oms, onb = 1e3 * float(np.mean([r[0] for r in orows])), float(np.mean([r[1] for r in orows]))
+        one[tag] = {"ms_per_sweep": oms, "node_backups_per_sweep": onb, "nodes_per_s_through_the_driver": onb / (oms * 1e-3), "ranks": oranks,
+                    "kernel_launches_per_sweep": float(np.mean([r[2] for r in orows]))}
+        L.approx_args_free(aa3)
     ms = 1e3 * float(np.mean([r[0] for r in rows]))
     sms = 1e3 * float(np.mean([r[0] for r in steady]))
     snb = float(np.mean([r[1] for r in steady]))
@@ -208,6 +220,8 @@ def solver_measurements(workload, budget_s):
                 "crossrank2x": {"ms_per_sweep": xms, "node_backups_per_sweep": xnb, "nodes_per_s_through_the_driver": xnb / (xms * 1e-3), "ranks": xranks,
                                 "what": f"the same sweeps with approx_args_set_crossrank({2 * rmax}): the cross approximation runs at twice the rank cap "
                                         "(4x the fibers per core step) and its result is rounded to the cap by the TT-SVD; sweeps 10..19 of the series"},
+                "one_cross_iteration_per_sweep": dict(one, what="approx_args_set_cross_maxiter(1): sweeps 16..43 of the same series with ONE cross iteration "
+                                                               "(left-to-right + right-to-left half sweep, no confirming launch) per value-iteration sweep"),
                 "what": f"c3control_step_vi through libc3sc.so on {w.name} (rank cap {rmax}), mean of sweeps 4..11 of a solve from a smooth start (round 2's window): whole cross "
                         "iterations device-resident (c3sc_hip_cross_*: index lists, Bellman launches, node memo, pivoted LU + maxvol per core "
                         "step on one stream); steady_* = the following 16 sweeps of the same series (ranks at their cap, one cross iteration + "
@@ -220,8 +234,8 @@ def solver_measurements(workload, budget_s):
 
     # "VI iterations to tolerance": c3control_vi_solve's own loop (bellman.c:2282-2340: stop when the L2 step between iterates falls
     # below abs_conv_tol), one sweep per call so that the step series is kept; start value 0
-    xr = 4 * rmax  # cross approximation at four times the rank cap, its result rounded to the cap (approx_args_set_crossrank)
-    aa = aargs(1e-6, 1e-6, 4, 4, rmax, xr)
+    xr = min(48, int(np.ceil(4.8 * rmax)))  # cross approximation far above the rank cap (the device's core steps end at rank 48), rounded to the cap
+    aa = aargs(1e-6, 1e-6, 4, 4, rmax, xr, 1)  # ... and ONE cross iteration per sweep: the value-iteration sweeps are the cross iterations
     zero = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).fill(0.0), 0)[1])
     cost = C.c_void_p(L.c3control_init_value(ctl.h, zero, None, aa, 0))
     diag = C.c_void_p(None)
@@ -253,14 +267,15 @@ def solver_measurements(workload, budget_s):
              "step_rel_every_25_sweeps": [float(f"{v:.3e}") for v in rel[::25]],
              "step_rel_floor_60_sweeps_after_convergence": {"median": float(np.median(after)), "min": float(np.min(after)), "max": float(np.max(after))} if after else None,
              "first_sweep_with_step_rel_below_1e-2": next((i for i, v in enumerate(rel) if v < 1e-2), None),
-             "rank_cap": rmax, "cross_rank": xr, "wall_budget_s": vi_budget,
+             "rank_cap": rmax, "cross_rank": xr, "cross_iterations_per_sweep": 1, "wall_budget_s": vi_budget,
              "end_point_rule": "consistent ends (c3control_set_consistent_ends, the C3Control default; C3SC_LITERAL_ENDS=1 restores nodeutil.c:570-612)",
              "what": "pure value iteration (c3control_vi_solve's loop and stopping test, one sweep per call so that the series is kept) through "
                      "libc3sc.so from the start value 0 until |V_i+1 - V_i|_L2 < tol_rel |V_i+1|_L2.  The value function keeps FT rank 10 (the "
                      f"kernels' input); the cross approximation of T(V) runs at ranks up to {xr} and is cut back to 10 by the TT-SVD "
-                     "(approx_args_set_crossrank).  On this exit-time problem (discount 0, contraction ~1 - 2.5e-3 per sweep) the step floor is the "
-                     "per-sweep noise of the re-selected cross: 3.6e-3 / 2.5e-3 / 1.3e-3 / 0.9e-3 of |V| at cross rank 10 / 20 / 30 / 40 "
-                     "(DESIGN.md 6.2, profiles/r04_vi_to_tol_car7d_rank10_crossrank*.txt): 40 is the first that passes a 1e-3 tolerance"}
+                     "(approx_args_set_crossrank), one cross iteration per sweep (approx_args_set_cross_maxiter).  On this exit-time problem "
+                     "(discount 0, contraction ~1 - 2.5e-3 per sweep) the step floor is the per-sweep noise of the re-selected cross: "
+                     "3.6e-3 / 2.5e-3 / 1.3e-3 / 0.95e-3 / 0.69e-3 of |V| at cross rank 10 / 20 / 30 / 40 / 48 (DESIGN.md 6.2, "
+                     "profiles/r04_vi_to_tol_car7d_rank10_crossrank*.txt)"}
     L.valuef_destroy(cost)
     L.approx_args_free(aa)
     ctl.close()

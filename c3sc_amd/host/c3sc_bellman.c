@@ -1311,6 +1311,7 @@ static struct ApproxArgs *device_rank_cap(struct C3Control *c, struct ApproxArgs
     approx_args_set_maxrank(a, approx_args_get_maxrank(in));
     approx_args_set_adapt(a, approx_args_get_adapt(in));
     approx_args_set_crossrank(a, approx_args_get_crossrank(in));
+    approx_args_set_cross_maxiter(a, approx_args_get_cross_maxiter(in));
     const int cap = c3sc_hip_max_rank(dp_has_device_model(c->dp) ? c->dp->model : C3SC_MODEL_TABLE, (int)c->dx);
     if (cap > 0 && approx_args_get_maxrank(a) > (size_t)cap) {
         static int warned = 0;

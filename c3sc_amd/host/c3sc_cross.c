@@ -952,7 +952,9 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     const size_t kick = approx_args_get_kickrank(aargs);
     const int adapt = approx_args_get_adapt(aargs);
     const double cross_tol = approx_args_get_cross_tol(aargs), round_tol = approx_args_get_round_tol(aargs);
-    const size_t maxiter = 5; /* valuefunc.c:632 */
+    size_t maxiter = approx_args_get_cross_maxiter(aargs); /* 5 unless the caller says otherwise: valuefunc.c:632 */
+    if (getenv("C3SC_CROSS_MAXITER")) maxiter = (size_t)atoi(getenv("C3SC_CROSS_MAXITER")); /* experiments */
+    if (maxiter < 1) maxiter = 1;
 
     struct cross c;
     memset(&c, 0, sizeof(c));

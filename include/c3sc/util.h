@@ -29,6 +29,9 @@ int approx_args_get_adapt(const struct ApproxArgs *);
 /* new (no reference counterpart): ranks of the cross approximation before its result is rounded to maxrank; 0 = maxrank */
 void approx_args_set_crossrank(struct ApproxArgs *, size_t);
 size_t approx_args_get_crossrank(const struct ApproxArgs *);
+/* new: cap on the cross iterations of one interpolation (the reference hard-codes 5: valuefunc.c:632) */
+void approx_args_set_cross_maxiter(struct ApproxArgs *, size_t);
+size_t approx_args_get_cross_maxiter(const struct ApproxArgs *);
 size_t uniform_stride(size_t N, size_t M); /* util.c:995-1006 */
 
 #include <stdio.h>

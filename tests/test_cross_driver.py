@@ -59,6 +59,8 @@ def _interp(L, fl, func, grids, vref=None, batch=False, **kw):
     L.approx_args_set_adapt(aa, C.c_int(kw.get("adapt", 1)))
     if "crossrank" in kw:
         L.approx_args_set_crossrank(aa, C.c_size_t(kw["crossrank"]))
+    if "cross_maxiter" in kw:
+        L.approx_args_set_cross_maxiter(aa, C.c_size_t(kw["cross_maxiter"]))
     if batch:
         cb = BATCH_FN(many)
         vf = C.c_void_p(L.valuef_interp_batch(C.c_size_t(d), cb, None, fl.sp(N), gp, vref, aa, 0))
@@ -185,6 +187,33 @@ def test_elevated_cross_rank_edge_cases():
     vf, ranks, _ = _interp(L, fl, quad, grids, startrank=2, kickrank=2, maxrank=3, crossrank=9)
     assert max(ranks) == 2 and _nodal_error(L, fl, vf, quad, grids) < 1e-9  # rounding still trims to the true rank
     L.valuef_destroy(vf)
+
+
+def test_cross_iteration_cap_and_warm_started_sequence():
+    """approx_args_set_cross_maxiter: the reference caps the cross iterations of an interpolation at 5 (valuefunc.c:632).  With the cap
+    at 1 a single interpolation from generic index sets is rough, but a SEQUENCE of warm-started interpolations of a slowly changing
+    function -- what a value iteration is -- reaches the accuracy of the 5-iteration driver with a fraction of the fibers: the sweeps
+    play the role of the cross iterations."""
+    L, fl = _lib()
+    grids = [np.linspace(-1, 1, 17), np.linspace(-1, 1, 15), np.linspace(-1, 1, 16), np.linspace(-1, 1, 14)]
+    fam = lambda s: (lambda X: 1.0 / (1.0 + s + (X ** 2).sum(axis=1)) + 0.05 * np.abs(X[:, 0] - X[:, 3] + 0.1 * s))
+    res = {}
+    for cap in (5, 1):
+        vf, fibers, err = None, 0, None
+        for step in range(8):
+            f = fam(0.02 * step)
+            nxt, ranks, calls = _interp(L, fl, f, grids, vref=vf, startrank=6, kickrank=2, maxrank=6, cross_tol=1e-12, round_tol=1e-12,
+                                        cross_maxiter=cap, batch=True)
+            fibers += calls["fibers"]
+            if vf is not None:
+                L.valuef_destroy(vf)
+            vf = nxt
+            err = _nodal_error(L, fl, vf, f, grids, nsamp=600)
+        res[cap] = (err, fibers)
+        L.valuef_destroy(vf)
+    print(f"8 warm-started interpolations of a drifting function: cap 5 -> error {res[5][0]:.2e} with {res[5][1]} fibers; cap 1 -> {res[1][0]:.2e} with {res[1][1]}")
+    assert res[1][1] <= 0.8 * res[5][1]
+    assert res[1][0] <= 2.0 * res[5][0] + 1e-12
 
 
 def test_continuous_norms_and_offgrid_eval():

@@ -253,9 +253,10 @@ def solver_measurements(workload, budget_s):
             conv = True
             break
     t_conv = time.perf_counter() - t0
-    # what the iteration does after the tolerance was met: 60 more sweeps, so that the step floor is on record beside the count
+    # what the iteration does after the tolerance was met: 150 more sweeps, the last 60 of which give the step floor beside the count
+    # (right after the stop the true value-iteration step is still a good part of the measured one)
     after = []
-    for _ in range(60 if conv else 0):
+    for _ in range(150 if conv else 0):
         nxt = C.c_void_p(L.c3control_step_vi(ctl.h, cost, aa, ctl.opt, 0, C.byref(ne)))
         after.append(L.valuef_norm2diff(cost, nxt) / L.valuef_norm(nxt))
         L.valuef_destroy(cost)
@@ -265,7 +266,8 @@ def solver_measurements(workload, budget_s):
     iters = {"converged": conv, "tol_rel_L2": tol_rel, "sweeps": nsw, "seconds": t_conv, "ms_per_sweep": 1e3 * t_conv / max(nsw, 1),
              "node_backups": nb_total, "last_step_L2": steps[-1], "norm_L2": norm, "last_step_rel": steps[-1] / norm if norm else None,
              "step_rel_every_25_sweeps": [float(f"{v:.3e}") for v in rel[::25]],
-             "step_rel_floor_60_sweeps_after_convergence": {"median": float(np.median(after)), "min": float(np.min(after)), "max": float(np.max(after))} if after else None,
+             "step_rel_after_convergence": {"sweeps_1_to_60": {"median": float(np.median(after[:60])), "min": float(np.min(after[:60])), "max": float(np.max(after[:60]))},
+                                            "sweeps_91_to_150": {"median": float(np.median(after[90:])), "min": float(np.min(after[90:])), "max": float(np.max(after[90:]))}} if after else None,
              "first_sweep_with_step_rel_below_1e-2": next((i for i, v in enumerate(rel) if v < 1e-2), None),
              "rank_cap": rmax, "cross_rank": xr, "cross_iterations_per_sweep": 1, "wall_budget_s": vi_budget,
              "end_point_rule": "consistent ends (c3control_set_consistent_ends, the C3Control default; C3SC_LITERAL_ENDS=1 restores nodeutil.c:570-612)",

@@ -696,6 +696,10 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
         HIPCHK(c, hipFuncSetAttribute((const void *)k_cross_confirm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP_BYTES));
         x->lds_optin = true;
     }
+    // The set-up ran on the NULL stream (flag / tag reset, index-set upload, memo growth); the iteration, confirmation and fetch
+    // calls take the CALLER's stream, which need not be ordered against it (a non-blocking stream is not).  Everything issued here
+    // is complete before the call returns, so any stream may follow.
+    HIPCHK(c, hipStreamSynchronize(nullptr));
     return C3SC_OK;
 }
 

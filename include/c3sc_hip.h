@@ -230,7 +230,10 @@ int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32
  *   box: 0 = candidate list (set_controls), 1 = control box (set_control_box)
  *   fetch waits for the stream and returns the cores of the last half sweep in the layout G_k[a + r_k (j + N_k b)], both
  *   families of index sets, and info[4] = {nodes stored in the memo since the last fetch (the reference's nnode_evals),
- *   1 if a fiber matrix was numerically rank deficient, maxvol row swaps, 1 if the memo overflowed} */
+ *   1 if a fiber matrix was numerically rank deficient, maxvol row swaps, 1 if the memo overflowed / 2 if a rank of a sharded
+ *   sweep failed (its rows arrived as NaN)}
+ *   ranks up to 48 (above 32 a core step runs on global scratch).  Streams: setup works on the NULL stream and is COMPLETE when it
+ *   returns, so iteration / confirm / speculate / fetch may be given any stream (all calls of one context on the same one) */
 int c3sc_hip_cross_setup(c3sc_hip_ctx *ctx, const size_t *ranks, const int32_t *const *I, const int32_t *const *J, int new_sweep);
 int c3sc_hip_cross_iteration(c3sc_hip_ctx *ctx, int box, void *stream);
 /* after an iteration that changed index sets: the confirming iteration as ONE launch (all core steps side by side on the values

@@ -18,7 +18,7 @@ def _build(tmp_path, name="lqg2d_pi"):
     return exe
 
 
-@pytest.mark.parametrize("name", ["lqg2d_pi", "bellman_pi3d"])
+@pytest.mark.parametrize("name", ["lqg2d_pi", "bellman_pi3d", "car7d_vi"])
 def test_example_compiles_against_the_public_headers(tmp_path, name):
     assert os.path.exists(_build(tmp_path, name))
 
@@ -63,3 +63,20 @@ def test_example_shards_with_the_c_communicator(tmp_path):
         outs.append([ln for ln in p.stdout.splitlines() if ln.startswith("control update")])
     assert "sharded over 1 rank(s)" in p.stdout
     assert outs[0] == outs[1] and len(outs[0]) == 3
+
+
+@pytest.mark.gpu
+def test_value_iteration_to_tolerance_on_the_headline_configuration_through_the_c_api(tmp_path):
+    """examples/car7d_vi.c: the headline configuration (synthetic 7-D car, 41^7 grid, FT rank 10, nine controls, discount 0) set up
+    with the reference's calls and solved by c3control_vi_solve's OWN loop and stopping test (bellman.c:2282-2340) from the start
+    value 0, abs_conv_tol = 1.0 = 1e-3 of |V|_L2.  With the cross approximation at rank 48 rounded to 10 (approx_args_set_crossrank)
+    and one cross iteration per sweep (approx_args_set_cross_maxiter) the loop stops by its criterion after ~330 sweeps (~10 s);
+    the value function handed back has FT rank <= 10.  The host callbacks of the program are cross-checked against the device
+    functor on the first fiber (bellman_vi), so the C callbacks and the kernel's model are the same physics."""
+    exe = _build(tmp_path, "car7d_vi")
+    p = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    print(p.stdout[-1500:], p.stderr[-1500:])
+    assert p.returncode == 0 and "CAR7D_VI_CONVERGED" in p.stdout
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("c3control_vi_solve:")][0]
+    sweeps = int(line.split()[1])
+    assert 200 <= sweeps <= 500, line

@@ -673,8 +673,11 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     // value memo: every node a sweep can touch (5 iterations x 2 half sweeps x sum_k F_k N_k, before rank kicks) at load <= 1/3
     size_t nodes = 0;
     for (int k = 0; k < d; k++) nodes += (size_t)x->r[k] * x->r[k + 1] * x->N[k];
-    size_t want = 1 << 16;
-    while (want < 32 * nodes) want <<= 1;
+    // C3SC_MEMO_MIN_LOG2 / C3SC_MEMO_SCALE: test hooks that make the table small enough to fill (tests/test_solver_loops.py)
+    const size_t memo_scale = getenv("C3SC_MEMO_SCALE") ? (size_t)atoi(getenv("C3SC_MEMO_SCALE")) : 32;
+    size_t want = (size_t)1 << (getenv("C3SC_MEMO_MIN_LOG2") ? atoi(getenv("C3SC_MEMO_MIN_LOG2")) : 16);
+    while (want < memo_scale * nodes) want <<= 1;
+    if (want < x->vmemo.cap) want = x->vmemo.cap; // never below what a growth (c3sc_hip_cross_grow_memo) has reached
     {
         const bool fresh = new_sweep || x->vmemo.epoch == 0;
         int rc = memo_ensure(c, x->vmemo, want, !fresh);
@@ -701,6 +704,21 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     // is complete before the call returns, so any stream may follow.
     HIPCHK(c, hipStreamSynchronize(nullptr));
     return C3SC_OK;
+}
+
+/* The node memo (and the policy memo, if one exists) reported an overflow (info[3] == 1 of c3sc_hip_cross_fetch): double the tables,
+ * keeping the entries of the current epoch, so that the following iterations of this sweep find room.  Values computed while the
+ * table was full are correct fiber values that merely were not stored. */
+int c3sc_hip_cross_grow_memo(c3sc_hip_ctx *c)
+{
+    if (!c || !c->cross) return fail(c, C3SC_ERR_ARG, "cross_grow_memo: cross_setup first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    c3sc_cross_dev *x = c->cross;
+    int rc = C3SC_OK;
+    if (x->vmemo.cap) rc = memo_ensure(c, x->vmemo, 2 * x->vmemo.cap, true);
+    if (rc == C3SC_OK && x->pmemo.cap) rc = memo_ensure(c, x->pmemo, 2 * x->pmemo.cap, true);
+    return rc;
 }
 
 /* pivot-search options of the core steps (defaults: warm start on, swap tolerance 0.05 -- the host driver's) */

@@ -852,6 +852,19 @@ static void device_setup_if_fresh(struct cross *c)
     c->dev_new_sweep = 0;
 }
 
+
+/* The device memo filled up (c3sc_hip_cross_fetch: info[3] == 1).  Under consistent end points a fiber value is a function of its
+ * node alone, so the values computed meanwhile are the very ones a larger table would have returned: grow the tables and go on
+ * (only the nnode_evals count of this sweep is then an upper bound).  Under the reference's literal end-point rule a node's value
+ * depends on which fiber stored it first -- the memo IS part of the semantics there -- and the solve stops as before. */
+static void memo_overflow(struct c3sc_hip_ctx *dev)
+{
+    static int warned = 0;
+    if (c3sc_hip_get_consistent_ends(dev) != 1) DIE("valuef_interp: the device node memo overflowed (literal end-point rule: cannot continue)");
+    if (c3sc_hip_cross_grow_memo(dev) != 0) DIE("c3sc_hip_cross_grow_memo: %s", c3sc_hip_last_error(dev));
+    if (!warned) { fprintf(stderr, "c3sc: the device node memo was full and has been doubled; node-evaluation counts of that sweep are upper bounds\n"); warned = 1; }
+}
+
 static struct tt *cross_iteration_device(struct cross *c)
 {
     const size_t d = c->d;
@@ -863,7 +876,7 @@ static struct tt *cross_iteration_device(struct cross *c)
     rc = c3sc_hip_cross_fetch(c->dev, t->G, (int32_t *const *)c->I, (int32_t *const *)c->J, info, NULL);
     if (rc != 0) DIE("c3sc_hip_cross_fetch: %s", c3sc_hip_last_error(c->dev));
     if (info[3] >= 2) DIE("valuef_interp: a rank of the sharded sweep failed (its rows arrived as NaN): all ranks stop here");
-    if (info[3]) DIE("valuef_interp: the device node memo overflowed");
+    if (info[3]) memo_overflow(c->dev);
     c->dev_nodes += info[0];
     if (info[1]) c->deficient = 1;
     c->nswaps += (size_t)info[2];
@@ -1029,7 +1042,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
                     t2 = tt_alloc(d, c.N, c.r);
                     unsigned long long info[4] = {0, 0, 0, 0};
                     if (c3sc_hip_cross_fetch(c.dev, t2->G, NULL, NULL, info, NULL) != 0) DIE("c3sc_hip_cross_fetch: %s", c3sc_hip_last_error(c.dev));
-                    if (info[3]) DIE("valuef_interp: the device node memo overflowed");
+                    if (info[3]) memo_overflow(c.dev);
                     c.dev_nodes += info[0];
                     if (info[1]) c.deficient = 1;
                     for (size_t k = 0; k < d; k++) { c.nfibers += 2 * c.r[k] * c.r[k + 1]; c.dev_requested += 2 * c.r[k] * c.r[k + 1] * c.N[k]; }

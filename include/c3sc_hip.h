@@ -256,6 +256,9 @@ int c3sc_hip_cross_iteration_pi(c3sc_hip_ctx *ctx, c3sc_hip_ctx *policy_ctx, lon
 /* pivot search of the core steps: warm_pivots != 0 starts it from the rows of the index set the step produced last time,
  * swap_tol is maxvol's dominance tolerance (row swaps while max |B| > 1 + swap_tol); defaults 1 and 0.05 */
 int c3sc_hip_cross_options(c3sc_hip_ctx *ctx, int warm_pivots, double swap_tol);
+/* after info[3] == 1 (memo full): double the memo tables keeping the current epoch's entries (no reference counterpart: the
+ * reference's hash table never fills, util.c:760-766 -- it chains) */
+int c3sc_hip_cross_grow_memo(c3sc_hip_ctx *ctx);
 int c3sc_hip_cross_fetch(c3sc_hip_ctx *ctx, double *const *h_cores, int32_t *const *h_I, int32_t *const *h_J, unsigned long long *info,
                          void *stream);
 void c3sc_hip_cross_free(c3sc_hip_ctx *ctx);

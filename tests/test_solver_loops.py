@@ -425,3 +425,63 @@ def test_car7d_free_running_solves_device_vs_oracle(oracle):
     gpu.L.valuef_destroy(b)
     gpu.close()
     orc.close()
+
+
+_OVERFLOW_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import facade_lib
+from c3sc_amd import workloads as wl
+L = facade_lib.lib()
+for n in ("c3control_init_value", "c3control_step_vi"):
+    getattr(L, n).restype = C.c_void_p
+L.valuef_get_ranks.restype = C.POINTER(C.c_size_t)
+L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
+w = wl.c4_car7d().scaled(ngrid=(13, 12, 14, 11, 10, 9, 15), rank=4)
+ctl = facade_lib.Control(w, consistent_ends={ce})
+aa = C.c_void_p(L.approx_args_init())
+L.approx_args_set_maxrank(aa, C.c_size_t(8)); L.approx_args_set_startrank(aa, C.c_size_t(3)); L.approx_args_set_kickrank(aa, C.c_size_t(2))
+L.approx_args_set_cross_tol(aa, C.c_double(1e-8)); L.approx_args_set_round_tol(aa, C.c_double(1e-8))
+d = w.dx
+start = facade_lib.FIBER_FN(lambda n, x, out, a: (np.ctypeslib.as_array(out, shape=(n,)).__setitem__(slice(None), 1.0 + 0.1 * (np.ctypeslib.as_array(x, shape=(n, d)) ** 2).sum(axis=1)), 0)[1])
+v = C.c_void_p(L.c3control_init_value(ctl.h, start, None, aa, 0))
+ne = C.c_size_t(0)
+for _ in range(4):
+    nxt = C.c_void_p(L.c3control_step_vi(ctl.h, v, aa, ctl.opt, 0, C.byref(ne)))
+    L.valuef_destroy(v); v = nxt
+ranks = [int(L.valuef_get_ranks(v)[i]) for i in range(d + 1)]
+L.valuef_norm.restype = C.c_double
+print("RESULT", ranks, repr(L.valuef_norm(v)))
+"""
+
+
+@pytest.mark.gpu
+def test_device_memo_overflow_grows_the_table_and_gives_the_same_cores():
+    """The device node memo filling up used to end the solve.  Under consistent end points a fiber value is a function of
+    its node (up to the last bits: the train is contracted in another order along another direction), so values computed while the
+    table was full are the ones a larger table would have returned: the table is doubled (c3sc_hip_cross_grow_memo) and the sweep
+    goes on -- same ranks, |V| within the rank-8 approximation's own spread of the run with an ample table (last-bit differences in
+    fiber values may flip pivots at this rank cap).  Under the reference's literal end-point rule the memo is part of
+    the semantics (first stored value wins): the solve still stops."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(ce, small):
+        env = dict(os.environ)
+        if small:
+            env.update(C3SC_MEMO_MIN_LOG2="10", C3SC_MEMO_SCALE="0")
+        return subprocess.run([sys.executable, "-c", _OVERFLOW_SCRIPT.format(root=root, ce=ce)], env=env, capture_output=True, text=True, timeout=600)
+
+    ample, tiny = run("True", False), run("True", True)
+    assert ample.returncode == 0 and tiny.returncode == 0, (tiny.returncode, tiny.stderr[-1500:])
+    assert "memo was full" in tiny.stderr and "memo was full" not in ample.stderr
+    ra = [ln for ln in ample.stdout.splitlines() if ln.startswith("RESULT")][0]
+    rt = [ln for ln in tiny.stdout.splitlines() if ln.startswith("RESULT")][0]
+    assert ra.split("]")[0] == rt.split("]")[0], (ra, rt)  # ranks
+    na, nt = float(ra.split("]")[1]), float(rt.split("]")[1])
+    print(f"|V| with an ample memo {na:.6f}, after overflow + growth {nt:.6f}")
+    assert abs(na - nt) <= 2e-2 * na
+    lit = run("False", True)
+    assert lit.returncode == 1 and "memo overflowed" in lit.stderr

@@ -807,8 +807,11 @@ __device__ __attribute__((always_inline)) inline void fiber_pair_body(const KArg
 #ifndef FPP_WPS_LOW
 #define FPP_WPS_LOW 4
 #endif
+#ifndef FPP_WPS_HIGH
+#define FPP_WPS_HIGH 2 // wavefronts per SIMD of the staged (rank > 6) instantiations; 1 was measured (512 registers per wavefront, spills in AGPRs)
+#endif
 template <class Model, int RP>
-__host__ __device__ constexpr int fpp_waves_per_simd() { return (fpp_direct<Model, RP>() && RP <= 6) ? FPP_WPS_LOW : 2; }
+__host__ __device__ constexpr int fpp_waves_per_simd() { return (fpp_direct<Model, RP>() && RP <= 6) ? FPP_WPS_LOW : (FPP_WPS_HIGH); }
 
 template <class Model, int RP, int K, bool FORCED>
 __global__ void __launch_bounds__(FPP_THREADS, (fpp_waves_per_simd<Model, RP>()))

@@ -351,7 +351,9 @@ def test_device_resident_cross_iterations_match_the_host_driver(name, kw, aargs)
     ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=2)),
     ("dubins3d", dict(ngrid=(41, 41, 41), rank=4), dict(maxrank=12, kick=3)),
     ("lqg2d", dict(ngrid=(50, 50), rank=4), dict(maxrank=20, kick=5)),
-], ids=["car7d-small", "dubins3d", "lqg2d"])
+    ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=3, crossrank=12)),                   # policy evaluation with the cross above the cap
+    ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=3, crossrank=12, cross_maxiter=1)),  # ... and one cross iteration per sweep
+], ids=["car7d-small", "dubins3d", "lqg2d", "car7d-small-crossrank12", "car7d-small-crossrank12-one-cross-iteration"])
 def test_device_resident_policy_iteration_matches_the_host_driver(name, kw, aargs):
     """The examples' control update -- c3control_pi_solve (10 evaluation sweeps of one policy, bellman_pi) followed by one
     c3control_vi_solve step -- with whole cross iterations on the device (policy pass with the per-node policy memo, evaluation

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "ctx.hpp"
 
@@ -304,9 +305,11 @@ constexpr int CH_LDS = 8, CH_GLOBAL = 8; // 24 loads per trip on global scratch 
                                         // chunk is issued in full even where few trailing columns remain)
 
 #ifdef C3SC_CORE_STAMPS
+#define LU_STAMP(slot) do { if (threadIdx.x == 0 && P.stamps) { const unsigned long long now__ = clock64(); P.stamps[slot] += now__ - tlu__; tlu__ = now__; } } while (0)
 #define CORE_STAMP(slot) do { __syncthreads(); if (threadIdx.x == 0 && P.stamps) { const unsigned long long now__ = clock64(); P.stamps[slot] += now__ - tlast__; tlast__ = now__; } } while (0)
 #else
 #define CORE_STAMP(slot) do { } while (0)
+#define LU_STAMP(slot) do { } while (0)
 #endif
 template <bool INLDS>
 __device__ __forceinline__ void core_step(const CoreArgs &P)
@@ -377,20 +380,19 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
             if ((used >> q) & 1u) continue;
             const double l = A[i + kc * m] * inv;
             A[i + kc * m] = l;
-            if (l != 0.0)
-                for (int c0 = kc + 1; c0 < n; c0 += CH) {
-                    double x[CH], pc[CH];
+            for (int c0 = kc + 1; c0 < n; c0 += CH) { // every row, also with a zero multiplier (as lu_maxvol: no skipping, no sign of zero to keep)
+                double x[CH], pc[CH];
 #pragma unroll
-                    for (int u = 0; u < CH; u++) {
-                        const int c = c0 + u < n ? c0 + u : n - 1;
-                        x[u] = A[i + c * m];
-                        pc[u] = A[p + c * m];
-                    }
-#pragma unroll
-                    for (int u = 0; u < CH; u++) x[u] -= l * pc[u];
-#pragma unroll
-                    for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
+                for (int u = 0; u < CH; u++) {
+                    const int c = c0 + u < n ? c0 + u : n - 1;
+                    x[u] = A[i + c * m];
+                    pc[u] = A[p + c * m];
                 }
+#pragma unroll
+                for (int u = 0; u < CH; u++) x[u] -= l * pc[u];
+#pragma unroll
+                for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
+            }
         }
         // no barrier here: the next column's pivot search reads a thread's own rows only, and the barrier inside its block_max
         // stands between this update of a row and any other thread reading it as the next pivot row (pivot rows are never
@@ -500,6 +502,458 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
 template <bool INLDS>
 __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P) { core_step<INLDS>(P); }
 
+// ------------------------------------------------------------------------------ the core step of a matrix that does not fit LDS
+// Ranks above 32 (an elevated cross rank: 1968 x 48 at car7d's 41 nodes) and long dimensions at rank > 16 keep the matrix in
+// global scratch (L2-resident: 755 KB).  The LDS form above run on that scratch is a chain of dependent L2 round trips -- every
+// chunk of a row's update is load -> arithmetic -> store, and the next chunk's loads wait for those stores because they might
+// alias: 0.6-1.1 ms per rank-48 step, 17-23 ms of a 29 ms value-iteration sweep.  Same arithmetic, element by element and in the
+// same order (so still the bit-for-bit twin of lu_maxvol, c3sc_cross.c), organised around what is cheap here:
+//   * LU LEFT-looking: column kc of a row is brought up to date when it is needed, x = a - sum_{t < kc} l_t U[t][kc] (t ascending:
+//     the order in which the right-looking form subtracts), from the row's own multipliers -- loads that depend on no store of
+//     this column -- and from U, the pivot rows' updated entries, which live in LDS (MAXR x MAXR).  One store per row and column
+//     instead of a read-modify-write of the whole trailing matrix.  The new pivot row's U entries are formed by ONE wavefront
+//     (lane = column; the row's multipliers sit in the lanes of a register and are read with v_readlane), while the others wait.
+//   * substitution, maxvol updates: a row at a time in REGISTERS (NR doubles, statically indexed, padded with +0 beyond n: a
+//     product of two +0 subtracts as +0 and leaves every value, -0 included, as it is): one round trip per row.  The pivot search
+//     of maxvol rides on the pass that produced the values (no separate read of the matrix).
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void core_step_global(const CoreArgs &P)
+{
+#pragma clang fp contract(off)
+#ifdef C3SC_CORE_STAMPS
+    unsigned long long tlast__ = clock64();
+#endif
+    constexpr int CH = 8, LS = MAXR, QG = 4; // QG rows of a thread advance together through a column of the LU
+    extern __shared__ double smem[];         // MAXR x MAXR: U[t][c] during the LU, then L[rows] transposed (LrT[j][t] = Lr[t][j])
+    double *U = smem;
+    __shared__ double rowv[MAXR];
+    __shared__ double pivabs[MAXR];
+    __shared__ int rows[MAXR], srows[MAXR], pos[MAXR];
+    __shared__ unsigned long long red[2 * (NT / 64)];
+    __shared__ unsigned char warmf[MAXROWS];
+    __shared__ int s_in[MAXR * MAXD], s_old[MAXR * MAXD];
+    const int tid = threadIdx.x;
+    const int r0 = P.r0, N = P.N, r1 = P.r1;
+    if (P.copy_only) { // G[a + r0 (j + N b)] = out[(a + r0 b) N + j]
+        if (P.confirm && P.dir == 0) return;
+        const int total = r0 * N * r1;
+        for (int e = tid; e < total; e += NT) {
+            const int a = e % r0, j = (e / r0) % N, b = e / (r0 * N);
+            P.G[e] = P.out[(a + r0 * b) * N + j];
+        }
+        write_sets_and_next(P, 0, srows, pivabs, 0);
+        return;
+    }
+    const int m = P.dir == 0 ? r0 * N : N * r1, n = P.dir == 0 ? r1 : r0;
+    double *A = P.work;
+    for (int i = tid; i < m; i += NT) { // load the fiber matrix, a row per thread
+        int base, step;
+        if (P.dir == 0) { base = (i % r0) * N + i / r0; step = r0 * N; }
+        else { base = r0 * (i / N) * N + i % N; step = N; }
+        for (int c0 = 0; c0 < n; c0 += CH) {
+            double x[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) x[u] = (c0 + u < n) ? P.out[base + step * (c0 + u)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
+        }
+        for (int c = n; c < NR; c++) A[i + c * m] = 0.0; // the padding columns of the rows' register image
+    }
+    CORE_STAMP(0);
+    mark_warm_rows(P, m, n, warmf, s_in, s_old);
+    CORE_STAMP(1);
+    const double boost = (double)(1 << WARM_BOOST_LOG2);
+    int parity = 0;
+    unsigned used = 0; // bit q: my q-th row (row tid + q NT) is a pivot row
+    const int ngroups = (m + QG * NT - 1) / (QG * NT);
+#ifdef C3SC_CORE_STAMPS
+    unsigned long long tlu__ = clock64();
+#endif
+    // ---- tall LU with row pivoting.  Every element sees x -= l_t U[t][c] for t = 0, 1, 2, ... in this order, as in lu_maxvol.
+    if (m <= QG * NT) {
+        // Panels of PW columns, a thread's (at most QG) rows of the panel in REGISTERS:
+        //   A  the panel is brought up to date through column c0 - 1 from the rows' stored multipliers (one load per row and t,
+        //      used for PW columns) and U[t][c0 ..] (LDS, read once per thread for its QG rows);
+        //   B  column by column inside the panel: pivot search on the registers, the pivot row's owner publishes its panel
+        //      entries (they ARE U[kc][c0 ..]), everybody scales its entry (the multiplier, stored at once) and updates the
+        //      rest of its panel registers: two barriers per column, no global round trip on the critical path;
+        //   C  at the end of the panel the U entries of its PW pivot rows BEYOND the panel: wavefront w takes pivot row w (lane =
+        //      column) through the terms t < c0, then one wavefront finishes the PW x PW triangle inside the panel.
+        constexpr int PW = 8;
+        __shared__ double part[PW * MAXR]; // [w][c]: pivot row w of the panel through t < c0
+        __shared__ double lin[PW * PW];    // [w][tt]: multiplier of pivot row w for column c0 + tt (tt < w)
+        __shared__ double slots[2 * (NT / 64) * PW]; // [parity][wavefront][v]: the wavefront's candidate row, panel columns
+        int row[QG];
+        unsigned rowc[QG];
+#pragma unroll
+        for (int qq = 0; qq < QG; qq++) {
+            row[qq] = tid + qq * NT;
+            rowc[qq] = row[qq] < m ? (unsigned)row[qq] : 0u; // a thread without a row there reads row 0 and throws the result away
+        }
+        for (int c0 = 0; c0 < n; c0 += PW) {
+            const int np = n - c0 < PW ? n - c0 : PW;
+            double acc[QG][PW];
+#pragma unroll
+            for (int v = 0; v < PW; v++) {
+                const unsigned off = (unsigned)((c0 + v < NR ? c0 + v : NR - 1) * m);
+#pragma unroll
+                for (int qq = 0; qq < QG; qq++) acc[qq][v] = A[rowc[qq] + off];
+            }
+            // ---- A: terms t < c0 (c0 is a multiple of PW: whole chunks of CA)
+            {
+                constexpr int CA = 4;
+                auto fetch = [&](int t0, double (&l)[QG][CA]) {
+#pragma unroll
+                    for (int u = 0; u < CA; u++) {
+                        const unsigned off = (unsigned)((t0 + u) * m);
+#pragma unroll
+                        for (int qq = 0; qq < QG; qq++) l[qq][u] = A[rowc[qq] + off];
+                    }
+                };
+                auto apply = [&](int t0, const double (&l)[QG][CA]) {
+#pragma unroll
+                    for (int u = 0; u < CA; u++) {
+                        double w[PW];
+#pragma unroll
+                        for (int v = 0; v < PW; v++) w[v] = U[(t0 + u) * LS + (c0 + v < MAXR ? c0 + v : MAXR - 1)];
+#pragma unroll
+                        for (int qq = 0; qq < QG; qq++)
+#pragma unroll
+                            for (int v = 0; v < PW; v++) acc[qq][v] -= l[qq][u] * w[v];
+                    }
+                };
+                double la[QG][CA], lb[QG][CA]; // two chunks: the next one is on its way while this one is applied
+                if (c0 > 0) fetch(0, la);
+                for (int t0 = 0; t0 < c0; t0 += 2 * CA) {
+                    const bool second = t0 + CA < c0;
+                    if (second) fetch(t0 + CA, lb);
+                    apply(t0, la);
+                    if (second) {
+                        if (t0 + 2 * CA < c0) fetch(t0 + 2 * CA, la);
+                        apply(t0 + CA, lb);
+                    }
+                }
+            }
+            LU_STAMP(8);
+            // ---- B: the panel's columns.  One barrier per column: every wavefront leaves its best candidate's key AND that row's panel
+            // registers in its slot; behind the barrier everybody reads the winning slot -- it is U[kc][kc .. c0 + PW - 1].
+            static_for<0, PW>([&](auto uu) {
+                constexpr int u = decltype(uu)::value;
+                if (u < np) {
+                    const int kc = c0 + u;
+                    unsigned long long key = 0;
+                    unsigned kbit = 0;
+                    double cand[PW]; // the panel registers of the lane's best row (selected as the search goes: indexing acc by a run-time row sends it to scratch)
+#pragma unroll
+                    for (int v = u; v < PW; v++) cand[v] = 0.0;
+#pragma unroll
+                    for (int qq = 0; qq < QG; qq++) {
+                        const double x = acc[qq][u];
+                        const unsigned long long kk = (row[qq] < m && !((used >> qq) & 1u)) ? pivot_key(warmf[rowc[qq]] ? x * boost : x, (unsigned long long)row[qq]) : 0ull;
+                        const bool better = kk > key;
+                        key = better ? kk : key;
+                        kbit = better ? (1u << qq) : kbit;
+#pragma unroll
+                        for (int v = u; v < PW; v++) cand[v] = better ? acc[qq][v] : cand[v];
+                    }
+                    const unsigned long long wmax = wave_max_u64(key);
+                    double *slot = slots + (parity * (NT / 64) + (tid >> 6)) * PW;
+                    if (key == wmax && key != 0) { // one lane (the index is part of the key)
+#pragma unroll
+                        for (int v = u; v < PW; v++) slot[v] = cand[v];
+                    }
+                    if ((tid & 63) == 0) red[parity * (NT / 64) + (tid >> 6)] = wmax;
+                    __syncthreads();
+                    unsigned long long best = red[parity * (NT / 64)];
+                    int wb = 0;
+#pragma unroll
+                    for (int w2 = 1; w2 < NT / 64; w2++) {
+                        const unsigned long long r = red[parity * (NT / 64) + w2];
+                        if (r > best) { best = r; wb = w2; }
+                    }
+                    const double *win = slots + (parity * (NT / 64) + wb) * PW;
+                    parity ^= 1; // the next column writes the other set of slots: one barrier per column is enough
+                    const int p = (int)(IDX_MASK - (best & IDX_MASK));
+                    if (key == best && key != 0) used |= kbit; // the pivot row's owner
+                    const double dp = win[u];
+                    if (tid == 0) { rows[kc] = p; pivabs[kc] = fabs(dp); }
+                    const double inv = dp != 0.0 ? 1.0 / dp : 0.0;
+                    double w[PW];
+#pragma unroll
+                    for (int v = u + 1; v < PW; v++) w[v] = win[v];
+#pragma unroll
+                    for (int qq = 0; qq < QG; qq++)
+                        if (row[qq] < m && !((used >> qq) & 1u)) {
+                            const double l = acc[qq][u] * inv;
+                            A[row[qq] + kc * m] = l;
+#pragma unroll
+                            for (int v = u + 1; v < PW; v++) acc[qq][v] -= l * w[v];
+                        }
+                }
+            });
+            LU_STAMP(9);
+            // ---- C: U[c0 + w][c] for c >= c0 + PW
+            if (c0 + PW < n) {
+                __syncthreads(); // the multipliers of the panel's last column are stored (the pivot rows' are read below)
+                const int wv = tid >> 6, lane = tid & 63;
+                if (wv < PW) { // np = PW here
+                    const int pw = rows[c0 + wv];
+                    const int c = lane < n ? lane : n - 1;
+                    double a0 = A[pw + c * m];
+                    for (int tb = 0; tb < c0; tb += 64) { // the pivot row's multipliers, 64 at a time in the lanes of a register
+                        const double lpv = tb + lane < c0 ? A[pw + (tb + lane) * m] : 0.0;
+                        const int lplo = (int)(unsigned)((unsigned long long)__double_as_longlong(lpv) & 0xffffffffull);
+                        const int lphi = (int)(unsigned)((unsigned long long)__double_as_longlong(lpv) >> 32);
+                        const int tn = c0 - tb < 64 ? c0 - tb : 64;
+                        for (int t0 = 0; t0 < tn; t0 += CH) { // tn is a multiple of CH
+                            double ut[CH];
+#pragma unroll
+                            for (int uq = 0; uq < CH; uq++) ut[uq] = U[(tb + t0 + uq) * LS + (c < MAXR ? c : MAXR - 1)];
+#pragma unroll
+                            for (int uq = 0; uq < CH; uq++) {
+                                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(lplo, t0 + uq), hi = (unsigned)__builtin_amdgcn_readlane(lphi, t0 + uq);
+                                a0 -= __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) * ut[uq];
+                            }
+                        }
+                    }
+                    if (lane >= c0 + PW && lane < n) part[wv * MAXR + lane] = a0;
+                    if (lane < wv) lin[wv * PW + lane] = A[pw + (c0 + lane) * m];
+                }
+                __syncthreads();
+                if (tid >= c0 + PW && tid < n) { // one wavefront (n <= 48): the triangle inside the panel, t = c0 .. c0 + w - 1 ascending
+                    double av[PW];
+#pragma unroll
+                    for (int w2 = 0; w2 < PW; w2++) av[w2] = part[w2 * MAXR + tid];
+#pragma unroll
+                    for (int w2 = 0; w2 < PW; w2++) {
+#pragma unroll
+                        for (int tt = 0; tt < w2; tt++) av[w2] -= lin[w2 * PW + tt] * av[tt];
+                        U[(c0 + w2) * LS + tid] = av[w2];
+                    }
+                }
+                __syncthreads();
+            }
+            LU_STAMP(10);
+        }
+    } else {
+        for (int kc = 0; kc < n; kc++) {
+            unsigned long long key = 0;
+            double xs[QG]; // the first group's entries of this column stay in registers until they are scaled
+    #pragma unroll
+            for (int qq = 0; qq < QG; qq++) xs[qq] = 0.0;
+            for (int g = 0; g < ngroups; g++) {
+                double s[QG];
+                int row[QG];
+                unsigned rowc[QG]; // the row every load goes to: a row without work reads row 0 and throws the sum away (no predicated loads)
+                bool live[QG];
+    #pragma unroll
+                for (int qq = 0; qq < QG; qq++) {
+                    const int q = g * QG + qq;
+                    row[qq] = tid + q * NT;
+                    live[qq] = row[qq] < m && !((used >> q) & 1u);
+                    rowc[qq] = live[qq] ? (unsigned)row[qq] : 0u;
+                    s[qq] = A[rowc[qq] + (unsigned)(kc * m)];
+                }
+                // the row's multipliers of columns t0 .. t0 + CH - 1 (clamped to kc - 1: the tail is loaded twice and not used)
+                auto fetch = [&](int t0, double (&l)[QG][CH]) {
+    #pragma unroll
+                    for (int u = 0; u < CH; u++) {
+                        const unsigned off = (unsigned)((t0 + u < kc ? t0 + u : kc - 1) * m);
+    #pragma unroll
+                        for (int qq = 0; qq < QG; qq++) l[qq][u] = A[rowc[qq] + off];
+                    }
+                };
+                auto apply = [&](int t0, const double (&l)[QG][CH]) {
+                    double w[CH];
+    #pragma unroll
+                    for (int u = 0; u < CH; u++) w[u] = U[(t0 + u < kc ? t0 + u : kc - 1) * LS + kc];
+    #pragma unroll
+                    for (int qq = 0; qq < QG; qq++)
+    #pragma unroll
+                        for (int u = 0; u < CH; u++)
+                            if (t0 + u < kc) s[qq] -= l[qq][u] * w[u];
+                };
+                double la[QG][CH], lb[QG][CH]; // two chunks: the next one is on its way while this one is applied
+                if (kc > 0) fetch(0, la);
+                for (int t0 = 0; t0 < kc; t0 += 2 * CH) {
+                    const bool second = t0 + CH < kc;
+                    if (second) fetch(t0 + CH, lb);
+                    apply(t0, la);
+                    if (second) {
+                        if (t0 + 2 * CH < kc) fetch(t0 + 2 * CH, la);
+                        apply(t0 + CH, lb);
+                    }
+                }
+    #pragma unroll
+                for (int qq = 0; qq < QG; qq++)
+                    if (live[qq]) {
+                        if (g == 0) xs[qq] = s[qq];
+                        else A[row[qq] + kc * m] = s[qq];
+                        const unsigned long long kk = pivot_key(warmf[row[qq]] ? s[qq] * boost : s[qq], (unsigned long long)row[qq]);
+                        key = kk > key ? kk : key;
+                    }
+            }
+            LU_STAMP(8);
+            const unsigned long long best = block_max(key, red, parity);
+            LU_STAMP(9);
+            const int p = (int)(IDX_MASK - (best & IDX_MASK));
+            if (p % NT == tid) used |= 1u << (p / NT);
+            if (tid < 64) { // U[kc][c], c >= kc: the pivot row's entries, up to date through column kc - 1 (lane = column)
+                const int c = tid;
+                double a0 = (c >= kc && c < n) ? A[p + c * m] : 0.0;
+                const double lpv = c < kc ? A[p + c * m] : 0.0; // lane t: the pivot row's multiplier of column t
+                const int lplo = (int)(unsigned)((unsigned long long)__double_as_longlong(lpv) & 0xffffffffull);
+                const int lphi = (int)(unsigned)((unsigned long long)__double_as_longlong(lpv) >> 32);
+                const int cc = c < MAXR ? c : MAXR - 1;
+                for (int t0 = 0; t0 < kc; t0 += CH) {
+                    double ut[CH];
+    #pragma unroll
+                    for (int u = 0; u < CH; u++) ut[u] = U[(t0 + u < kc ? t0 + u : kc - 1) * LS + cc];
+    #pragma unroll
+                    for (int u = 0; u < CH; u++)
+                        if (t0 + u < kc) {
+                            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(lplo, t0 + u), hi = (unsigned)__builtin_amdgcn_readlane(lphi, t0 + u);
+                            const double lt = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                            a0 -= lt * ut[u];
+                        }
+                }
+                if (c >= kc && c < n) U[kc * LS + c] = a0;
+            }
+            __syncthreads();
+            LU_STAMP(10);
+            const double dp = U[kc * LS + kc];
+            if (tid == 0) { rows[kc] = p; pivabs[kc] = fabs(dp); }
+            const double inv = dp != 0.0 ? 1.0 / dp : 0.0;
+            for (int g = 0; g < ngroups; g++)
+    #pragma unroll
+                for (int qq = 0; qq < QG; qq++) {
+                    const int q = g * QG + qq, i = tid + q * NT;
+                    if (i < m && !((used >> q) & 1u)) A[i + kc * m] = (g == 0 ? xs[qq] : A[i + kc * m]) * inv;
+                }
+            LU_STAMP(11);
+            // no barrier here: the next column reads a thread's own rows and U rows that were complete at the barrier above; the next
+            // pivot row's multipliers are read behind the barrier inside the next block_max
+        }
+    }
+    __syncthreads();
+    CORE_STAMP(2);
+    // ---- B = L inv(L[rows]): x Lr = l per non-pivot row, the row in registers
+    double *LrT = smem; // LrT[j LS + t] = Lr[t][j] = A[rows[t] + j m] (j < t < n), +0 elsewhere
+    for (int e = tid; e < NR * NR; e += NT) {
+        const int j = e / NR, t = e % NR;
+        LrT[j * LS + t] = (j < t && t < n) ? A[rows[t] + j * m] : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT) { // pivot rows: unit vectors (their multipliers are in LrT now)
+        const int q = e / n, j = e % n;
+        A[rows[q] + j * m] = (j == q) ? 1.0 : 0.0;
+    }
+    unsigned long long key = 0; // maxvol's first search rides on this pass (the unit rows cannot win it with an entry above 1 + swap_tol)
+    for (int i = tid, q = 0; i < m; i += NT, q++) {
+        if ((used >> q) & 1u) continue;
+        double x[NR];
+        int ms = m;
+        asm volatile("" : "+s"(ms)); // the column offsets t m are formed here (scalar unit): hoisted out of the row loop they are 48 live registers, spilled
+#pragma unroll
+        for (int t = 0; t < NR; t++) x[t] = (A + t * ms)[i];
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque)); // the factor is read where it is used: hoisted out of the row loop it is 1 128 live values
+        const double *Lq = LrT + opaque; // (an offset, not the pointer: a laundered pointer loses its address space and reads FLAT)
+        static_for<0, NR>([&](auto jj) { // s = l_j - sum_{t > j} x_t Lr[t][j], t ascending; j = NR - 1 .. 0
+            constexpr int j = NR - 1 - decltype(jj)::value;
+            double s = x[j];
+            static_for<0, (NR - 1 - j + CH - 1) / CH>([&](auto cc) { // CH entries of the factor in flight (left alone the scheduler asks
+                constexpr int t0 = j + 1 + decltype(cc)::value * CH; // for whole columns at once and spills)
+                double w[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) if (t0 + u < NR) w[u] = Lq[j * LS + t0 + u];
+#pragma unroll
+                for (int u = 0; u < CH; u++) if (t0 + u < NR) s -= x[t0 + u] * w[u];
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            x[j] = s;
+        });
+#pragma unroll
+        for (int t = 0; t < NR; t++) { // the padding columns stay +0: their keys lose against any entry that is not zero
+            (A + t * ms)[i] = x[t];
+            const unsigned long long kk = pivot_key(x[t], (unsigned long long)(t * ms + i));
+            key = kk > key ? kk : key;
+        }
+    }
+    CORE_STAMP(3);
+    // ---- maxvol: swap rows until the largest entry of B is <= 1 + swap_tol
+    int nswaps = 0;
+    for (int it = 0; it < 200; it++) {
+        const unsigned long long best = block_max(key, red, parity);
+        if (best == 0) break; // m = n: every row is a pivot row, B is the identity and the first search saw no entry at all
+        const int lin = (int)(IDX_MASK - (best & IDX_MASK));
+        const int bj = lin / m, bi = lin % m;
+        const double piv = A[bi + bj * m];
+        if (!(fabs(piv) > 1.0 + P.swap_tol)) break;
+        if (tid < MAXR) rowv[tid] = tid < n ? A[bi + tid * m] - (tid == bj ? 1.0 : 0.0) : 0.0;
+        __syncthreads();
+        key = 0;
+        for (int i = tid; i < m; i += NT) { // the row in registers: updated (if its multiplier is not zero) and searched in one pass
+            double x[NR];
+            const double cv = A[i + bj * m] / piv;
+            int ms = m;
+            asm volatile("" : "+s"(ms));
+#pragma unroll
+            for (int t = 0; t < NR; t++) x[t] = (A + t * ms)[i];
+            if (cv != 0.0) {
+                int opaque = 0;
+                asm volatile("" : "+v"(opaque));
+                const double *rv = rowv + opaque;
+#pragma unroll
+                for (int t = 0; t < NR; t++) x[t] -= cv * rv[t]; // rowv is +0 beyond n: the padding stays +0
+#pragma unroll
+                for (int t = 0; t < NR; t++) (A + t * ms)[i] = x[t];
+            }
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                const unsigned long long kk = pivot_key(x[t], (unsigned long long)(t * ms + i));
+                key = kk > key ? kk : key;
+            }
+        }
+        if (tid == 0) rows[bj] = bi;
+        nswaps++;
+        // the next block_max's barrier stands between these stores and the reads of piv and rowv
+    }
+    __syncthreads();
+    CORE_STAMP(4);
+    sort_rows(n, rows, srows, pos);
+    for (int i = tid; i < m; i += NT) // results, columns in the order of ascending rows
+        for (int c0 = 0; c0 < n; c0 += CH) {
+            double x[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) x[u] = A[i + (c0 + u < n ? c0 + u : n - 1) * m];
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+                if (c0 + u < n) {
+                    if (P.dir == 0) { if (!P.confirm) P.G[i + m * pos[c0 + u]] = x[u]; }
+                    else P.G[pos[c0 + u] + r0 * i] = x[u];
+                }
+        }
+    CORE_STAMP(5);
+    write_sets_and_next(P, n, srows, pivabs, nswaps);
+    CORE_STAMP(6);
+#ifdef C3SC_CORE_STAMPS
+    if (threadIdx.x == 0 && P.stamps) P.stamps[7] += (unsigned long long)nswaps;
+#endif
+}
+
+template <int NR>
+__global__ void __launch_bounds__(NT) k_cross_core_g(const CoreArgs P) { core_step_global<NR>(P); }
+
 // The confirming iteration in one launch.  After an iteration that swapped rows, the next one usually changes nothing: with
 // unchanged index sets all of its 2 d core steps are independent (each factors the fiber values its step already holds), so
 // they run side by side, one workgroup per step, and only COMPARE the index sets they produce with the current ones.  If none
@@ -508,6 +962,8 @@ __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P) { core_step
 // that follows rewrites anyway.
 template <bool INLDS>
 __global__ void __launch_bounds__(NT) k_cross_confirm(const CoreArgs *steps) { core_step<INLDS>(steps[blockIdx.x]); }
+template <int NR>
+__global__ void __launch_bounds__(NT) k_cross_confirm_g(const CoreArgs *steps) { core_step_global<NR>(steps[blockIdx.x]); }
 
 } // namespace
 
@@ -647,6 +1103,10 @@ int c3sc_hip_cross_setup(c3sc_hip_ctx *c, const size_t *ranks, const int32_t *co
     x->off_steps = off; off += up256(2 * MAXD * sizeof(CoreArgs) + 64);
     // scratch of a factorisation that does not fit LDS: one block per core step of an iteration (the batched confirmation runs all
     // 2 d steps side by side; the sequential iteration uses the first block)
+    for (int k = 0; k < d; k++) { // the global-scratch core step pads the columns of its matrix to 32 / 40 / 48 (core_step_global)
+        const size_t rmaxk = (size_t)std::max(x->r[k], x->r[k + 1]), rowsk = rmaxk * x->N[k];
+        wmax = std::max(wmax, rowsk * (rmaxk <= 32 ? 32 : rmaxk <= 40 ? 40 : 48));
+    }
     x->work_stride = up256(wmax * sizeof(double));
     x->off_work = off; off += 2 * (size_t)d * x->work_stride;
     for (int k = 0; k < d; k++) { x->offUidx[k] = off; off += up256(((size_t)x->r[k] * x->r[k + 1] + 64) * x->N[k] * sizeof(int32_t)); }
@@ -876,18 +1336,22 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         P.confirm = 0; P.mismatch = nullptr;
 #ifdef C3SC_CORE_STAMPS
         static unsigned long long *g_stamps = nullptr;
-        if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 64 * 8 * sizeof(unsigned long long)); (void)hipMemset(g_stamps, 0, 64 * 8 * sizeof(unsigned long long)); }
-        P.stamps = g_stamps + 8 * s;
+        if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, 64 * 16 * sizeof(unsigned long long)); (void)hipMemset(g_stamps, 0, 64 * 16 * sizeof(unsigned long long)); }
+        P.stamps = g_stamps + 16 * s;
         if (s == 2 * d - 1) {
             static int calls = 0;
             if (++calls % 20 == 0) {
                 (void)hipStreamSynchronize(st);
-                unsigned long long hs[64 * 8];
+                unsigned long long hs[64 * 16];
                 (void)hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost);
-                for (int q = 0; q < 2 * d; q++)
-                    fprintf(stderr, "core step %2d (mean of %d): load %6.0f warm %6.0f lu %6.0f backsub %6.0f maxvol %6.0f results %6.0f sets+next %6.0f cycles, swaps %.2f\n", q, calls,
-                            hs[8 * q + 0] / (double)calls, hs[8 * q + 1] / (double)calls, hs[8 * q + 2] / (double)calls, hs[8 * q + 3] / (double)calls,
-                            hs[8 * q + 4] / (double)calls, hs[8 * q + 5] / (double)calls, hs[8 * q + 6] / (double)calls, hs[8 * q + 7] / (double)calls);
+                for (int q = 0; q < 2 * d; q++) // the mean over the last 20 iterations (the last step of the 20th is still running: 19 of it)
+                    fprintf(stderr, "core step %2d (iterations %d-%d): load %6.0f warm %6.0f lu %6.0f backsub %6.0f maxvol %6.0f results %6.0f sets+next %6.0f cycles, swaps %.2f\n", q, calls - 19, calls,
+                            hs[16 * q + 0] / 20.0, hs[16 * q + 1] / 20.0, hs[16 * q + 2] / 20.0, hs[16 * q + 3] / 20.0,
+                            hs[16 * q + 4] / 20.0, hs[16 * q + 5] / 20.0, hs[16 * q + 6] / 20.0, hs[16 * q + 7] / 20.0);
+                for (int q = 0; q < 2 * d; q++) // global-scratch steps: the LU's columns as thread 0 sees them
+                    if (hs[16 * q + 8]) fprintf(stderr, "core step %2d LU columns: own rows %6.0f pivot search %6.0f pivot row %6.0f scale + store %6.0f cycles\n", q,
+                                                hs[16 * q + 8] / 20.0, hs[16 * q + 9] / 20.0, hs[16 * q + 10] / 20.0, hs[16 * q + 11] / 20.0);
+                (void)hipMemset(g_stamps, 0, 64 * 16 * sizeof(unsigned long long));
             }
         }
 #endif
@@ -899,7 +1363,13 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
         const size_t mn = F * N * sizeof(double);
         if (P.copy_only) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), 0, st, P);
         else if (mn <= LDS_CAP_BYTES && r0 <= LDSR && r1 <= LDSR) hipLaunchKernelGGL(k_cross_core<true>, dim3(1), dim3(NT), mn, st, P);
-        else hipLaunchKernelGGL(k_cross_core<false>, dim3(1), dim3(NT), (size_t)MAXR * MAXR * sizeof(double), st, P);
+        else { // global scratch; the rows' register image is padded to the next of 32 / 40 / 48 columns
+            const int ncol = P.dir == 0 ? r1 : r0;
+            const size_t lds = (size_t)MAXR * MAXR * sizeof(double);
+            if (ncol <= 32) hipLaunchKernelGGL(k_cross_core_g<32>, dim3(1), dim3(NT), lds, st, P);
+            else if (ncol <= 40) hipLaunchKernelGGL(k_cross_core_g<40>, dim3(1), dim3(NT), lds, st, P);
+            else hipLaunchKernelGGL(k_cross_core_g<48>, dim3(1), dim3(NT), lds, st, P);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return C3SC_OK;
@@ -957,8 +1427,15 @@ int c3sc_hip_cross_confirm(c3sc_hip_ctx *c, int *confirmed, void *stream)
     // global scratch: the same code either way (core_step<INLDS>), as in the sequential iteration
     if (maxmn <= LDS_CAP_BYTES)
         hipLaunchKernelGGL(k_cross_confirm<true>, dim3(2 * d), dim3(NT), maxmn, st, (const CoreArgs *)(x->slab + x->off_steps));
-    else
-        hipLaunchKernelGGL(k_cross_confirm<false>, dim3(2 * d), dim3(NT), (size_t)MAXR * MAXR * sizeof(double), st, (const CoreArgs *)(x->slab + x->off_steps));
+    else {
+        int maxr = 1;
+        for (int k = 0; k <= d; k++) maxr = std::max(maxr, x->r[k]);
+        const size_t lds = (size_t)MAXR * MAXR * sizeof(double);
+        const CoreArgs *steps = (const CoreArgs *)(x->slab + x->off_steps);
+        if (maxr <= 32) hipLaunchKernelGGL(k_cross_confirm_g<32>, dim3(2 * d), dim3(NT), lds, st, steps);
+        else if (maxr <= 40) hipLaunchKernelGGL(k_cross_confirm_g<40>, dim3(2 * d), dim3(NT), lds, st, steps);
+        else hipLaunchKernelGGL(k_cross_confirm_g<48>, dim3(2 * d), dim3(NT), lds, st, steps);
+    }
     HIPCHK(c, hipGetLastError());
     // the flag and, in the same wait, everything a successful confirmation is followed by (c3sc_hip_cross_fetch then copies from
     // the pinned block); after a mismatch the block is stale and the counters it brought wait in `pending`

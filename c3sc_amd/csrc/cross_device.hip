@@ -555,18 +555,23 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
     }
     const int m = P.dir == 0 ? r0 * N : N * r1, n = P.dir == 0 ? r1 : r0;
     double *A = P.work;
-    for (int i = tid; i < m; i += NT) { // load the fiber matrix, a row per thread
-        int base, step;
-        if (P.dir == 0) { base = (i % r0) * N + i / r0; step = r0 * N; }
-        else { base = r0 * (i / N) * N + i % N; step = N; }
-        for (int c0 = 0; c0 < n; c0 += CH) {
+    { // the fiber matrix: out[(a + r0 b) N + j] read in its own order (coalesced), element (row, column) of A written where it belongs
+        const int total = r0 * r1 * N;
+        for (int e0 = 0; e0 < total; e0 += NT * CH) {
             double x[CH];
 #pragma unroll
-            for (int u = 0; u < CH; u++) x[u] = (c0 + u < n) ? P.out[base + step * (c0 + u)] : 0.0;
+            for (int u = 0; u < CH; u++) { const int e = e0 + u * NT + tid; x[u] = P.out[e < total ? e : total - 1]; }
 #pragma unroll
-            for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
+            for (int u = 0; u < CH; u++) {
+                const int e = e0 + u * NT + tid;
+                if (e < total) {
+                    const int f = e / N, j = e - f * N, b = f / r0, a = f - b * r0;
+                    if (P.dir == 0) A[(a + r0 * j) + b * m] = x[u]; // row a + r0 j, column b
+                    else A[(j + N * b) + a * m] = x[u];             // row j + N b, column a
+                }
+            }
         }
-        for (int c = n; c < NR; c++) A[i + c * m] = 0.0; // the padding columns of the rows' register image
+        for (int e = tid; e < m * (NR - n); e += NT) A[n * m + e] = 0.0; // the padding columns of the rows' register image
     }
     CORE_STAMP(0);
     mark_warm_rows(P, m, n, warmf, s_in, s_old);
@@ -592,12 +597,14 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
         __shared__ double part[PW * MAXR]; // [w][c]: pivot row w of the panel through t < c0
         __shared__ double lin[PW * PW];    // [w][tt]: multiplier of pivot row w for column c0 + tt (tt < w)
         __shared__ double slots[2 * (NT / 64) * PW]; // [parity][wavefront][v]: the wavefront's candidate row, panel columns
+        static_assert(QG == 4, "the slot hand-over below names the rows one by one");
         int row[QG];
-        unsigned rowc[QG];
+        unsigned rowc[QG], warmbits = 0; // bit qq: row qq carries the warm-start boost
 #pragma unroll
         for (int qq = 0; qq < QG; qq++) {
             row[qq] = tid + qq * NT;
             rowc[qq] = row[qq] < m ? (unsigned)row[qq] : 0u; // a thread without a row there reads row 0 and throws the result away
+            warmbits |= (row[qq] < m && warmf[rowc[qq]]) ? (1u << qq) : 0u;
         }
         for (int c0 = 0; c0 < n; c0 += PW) {
             const int np = n - c0 < PW ? n - c0 : PW;
@@ -652,24 +659,31 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
                     const int kc = c0 + u;
                     unsigned long long key = 0;
                     unsigned kbit = 0;
-                    double cand[PW]; // the panel registers of the lane's best row (selected as the search goes: indexing acc by a run-time row sends it to scratch)
-#pragma unroll
-                    for (int v = u; v < PW; v++) cand[v] = 0.0;
 #pragma unroll
                     for (int qq = 0; qq < QG; qq++) {
                         const double x = acc[qq][u];
-                        const unsigned long long kk = (row[qq] < m && !((used >> qq) & 1u)) ? pivot_key(warmf[rowc[qq]] ? x * boost : x, (unsigned long long)row[qq]) : 0ull;
+                        const unsigned long long kk = (row[qq] < m && !((used >> qq) & 1u)) ? pivot_key(((warmbits >> qq) & 1u) ? x * boost : x, (unsigned long long)row[qq]) : 0ull;
                         const bool better = kk > key;
                         key = better ? kk : key;
                         kbit = better ? (1u << qq) : kbit;
-#pragma unroll
-                        for (int v = u; v < PW; v++) cand[v] = better ? acc[qq][v] : cand[v];
                     }
                     const unsigned long long wmax = wave_max_u64(key);
                     double *slot = slots + (parity * (NT / 64) + (tid >> 6)) * PW;
-                    if (key == wmax && key != 0) { // one lane (the index is part of the key)
+                    if (key == wmax && key != 0) { // one lane (the index is part of the key) leaves its best row's panel registers: a branch
+                        // per row -- indexing acc by a run-time row (or a chain of selects, which the compiler turns into that) sends acc to scratch
+                        if (kbit == 1u) {
 #pragma unroll
-                        for (int v = u; v < PW; v++) slot[v] = cand[v];
+                            for (int v = u; v < PW; v++) { double t = acc[0][v]; asm volatile("" : "+v"(t)); slot[v] = t; } // (opaque: the four branches must not be merged into one indexed read)
+                        } else if (kbit == 2u) {
+#pragma unroll
+                            for (int v = u; v < PW; v++) { double t = acc[1][v]; asm volatile("" : "+v"(t)); slot[v] = t; } // (opaque: the four branches must not be merged into one indexed read)
+                        } else if (kbit == 4u) {
+#pragma unroll
+                            for (int v = u; v < PW; v++) { double t = acc[2][v]; asm volatile("" : "+v"(t)); slot[v] = t; } // (opaque: the four branches must not be merged into one indexed read)
+                        } else {
+#pragma unroll
+                            for (int v = u; v < PW; v++) { double t = acc[3][v]; asm volatile("" : "+v"(t)); slot[v] = t; } // (opaque: the four branches must not be merged into one indexed read)
+                        }
                     }
                     if ((tid & 63) == 0) red[parity * (NT / 64) + (tid >> 6)] = wmax;
                     __syncthreads();

@@ -32,6 +32,10 @@
 #include "c3sc_hip.h"
 #include "c3sc_private.h"
 
+static double tnow(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static double g_rt[6]; /* the rounding's own parts (C3SC_PROFILE): orthogonalisation QR, its products, truncation QR, SVD, products, rest */
+#define RTIMED(slot, stmt) do { const double t__ = tnow(); stmt; g_rt[slot] += tnow() - t__; } while (0)
+
 /* ------------------------------------------------------------------------------ small dense kernels */
 
 /* The dense loops below are compiled twice, for AVX2 and for the baseline ISA, and picked at load time (GNU ifunc): four
@@ -70,7 +74,7 @@ static struct {
     int quit;
     void (*fn)(void *, size_t);
     void *arg;
-    size_t next, end;            /* columns next .. end - 1 are handed out one at a time */
+    size_t next, end, grain;     /* columns next .. end - 1 are handed out grain at a time */
     int done;                    /* workers that finished the current loop */
     int sleepers;
     pthread_mutex_t mu;
@@ -79,10 +83,12 @@ static struct {
 
 static void pool_drain(void)
 {
+    const size_t grain = g_pool.grain, end = g_pool.end;
     for (;;) {
-        const size_t j = __atomic_fetch_add(&g_pool.next, 1, __ATOMIC_RELAXED);
-        if (j >= g_pool.end) break;
-        g_pool.fn(g_pool.arg, j);
+        const size_t j0 = __atomic_fetch_add(&g_pool.next, grain, __ATOMIC_RELAXED);
+        if (j0 >= end) break;
+        const size_t j1 = j0 + grain < end ? j0 + grain : end;
+        for (size_t j = j0; j < j1; j++) g_pool.fn(g_pool.arg, j);
     }
 }
 
@@ -143,15 +149,16 @@ static int dense_threads(void)
 }
 
 /* fn(arg, j) for j = j0 .. j1 - 1, the columns handed out one at a time to the caller and the pool's workers */
-static void parallel_columns(size_t j0, size_t j1, void (*fn)(void *, size_t), void *arg, int threads)
+static void parallel_columns_grain(size_t j0, size_t j1, void (*fn)(void *, size_t), void *arg, int threads, size_t grain)
 {
-    if (threads <= 1 || j1 <= j0 + 1 || g_pool.nworkers == 0) {
+    if (threads <= 1 || j1 <= j0 + grain || g_pool.nworkers == 0) {
         for (size_t j = j0; j < j1; j++) fn(arg, j);
         return;
     }
     g_pool.fn = fn;
     g_pool.arg = arg;
     g_pool.end = j1;
+    g_pool.grain = grain;
     __atomic_store_n(&g_pool.next, j0, __ATOMIC_RELAXED);
     __atomic_store_n(&g_pool.done, 0, __ATOMIC_RELAXED);
     __atomic_fetch_add(&g_pool.gen, 1, __ATOMIC_RELEASE);
@@ -161,6 +168,8 @@ static void parallel_columns(size_t j0, size_t j1, void (*fn)(void *, size_t), v
     pool_drain();
     while (__atomic_load_n(&g_pool.done, __ATOMIC_ACQUIRE) < g_pool.nworkers) __asm__ volatile("" ::: "memory");
 }
+
+static void parallel_columns(size_t j0, size_t j1, void (*fn)(void *, size_t), void *arg, int threads) { parallel_columns_grain(j0, j1, fn, arg, threads, 1); }
 
 /* Where the workers do not get CPUs of their own (measured: two or four threads on an eight-CPU virtual machine shared one CPU
  * with the spinning caller -- 40-85 us per empty loop, every factorisation SLOWER than on one thread; eight threads: 3 us) the pool
@@ -523,13 +532,13 @@ C3SC_CLONES static void tt_orthogonalize_rl(struct tt *t)
         for (size_t c = 0; c < cols; c++)
             for (size_t a = 0; a < r0; a++) At[c + a * cols] = t->G[k][a + r0 * c];
         double *R = xcalloc(r0 * r0, sizeof(double));
-        qr_thin(cols, r0, At, R);
+        RTIMED(0, qr_thin(cols, r0, At, R));
         double *Gn = xcalloc(r0 * cols, sizeof(double));
         for (size_t c = 0; c < cols; c++)
             for (size_t a = 0; a < r0; a++) Gn[a + r0 * c] = At[c + a * cols];
         double *Pn = xcalloc(rowsP * r0, sizeof(double));
         struct axpy_job job = {rowsP, r0, r0, 1, R, t->G[k - 1], Pn}; /* (G_{k-1} R^T)[:, a] = sum_b G_{k-1}[:, b] R[a, b] */
-        parallel_columns(0, r0, axpy_column, &job, (rowsP * r0 >= PAR_MIN_ENTRIES) ? dense_threads() : 1);
+        RTIMED(1, parallel_columns(0, r0, axpy_column, &job, (rowsP * r0 >= PAR_MIN_ENTRIES) ? dense_threads() : 1));
         free(t->G[k]); t->G[k] = Gn;
         free(t->G[k - 1]); t->G[k - 1] = Pn;
         free(At); free(R);
@@ -577,8 +586,8 @@ C3SC_CLONES static void tt_round(struct tt *t, double eps, size_t rcap, size_t *
             S = xcalloc(n, sizeof(double)); V = xcalloc(n * n, sizeof(double));
             double *R = xcalloc(n * n, sizeof(double)), *Q = xcalloc(m * n, sizeof(double));
             memcpy(Q, A, m * n * sizeof(double));
-            qr_thin(m, n, Q, R);
-            svd_jacobi(n, n, R, S, V); /* R <- U_R diag(S) */
+            RTIMED(2, qr_thin(m, n, Q, R));
+            RTIMED(3, svd_jacobi(n, n, R, S, V)); /* R <- U_R diag(S) */
             /* only the columns that survive the truncation below are formed (a cross rank of 48 cut to 10: a fifth of them) */
             size_t keep = n;
             {
@@ -588,7 +597,7 @@ C3SC_CLONES static void tt_round(struct tt *t, double eps, size_t rcap, size_t *
             }
             memset(A, 0, m * keep * sizeof(double));
             struct axpy_job job = {m, n, 1, n, R, Q, A}; /* A[:, j] = sum_q Q[:, q] R[q + j n] */
-            parallel_columns(0, keep, axpy_column, &job, (m * n >= PAR_MIN_ENTRIES) ? dense_threads() : 1);
+            RTIMED(4, parallel_columns(0, keep, axpy_column, &job, (m * n >= PAR_MIN_ENTRIES) ? dense_threads() : 1));
             free(R); free(Q);
         } else { /* wide: reduce with QR of A^T first is overkill here; pad rows with zeros */
             double *Ap = xcalloc(n * n, sizeof(double));
@@ -612,7 +621,7 @@ C3SC_CLONES static void tt_round(struct tt *t, double eps, size_t rcap, size_t *
         const size_t cols = t->N[k + 1] * t->r[k + 2];
         double *Gn = xcalloc(rnew * cols, sizeof(double));
         struct svt_job sj = {n, rnew, V, S, t->G[k + 1], Gn};
-        parallel_columns(0, cols, svt_column, &sj, (n * cols >= PAR_MIN_ENTRIES) ? dense_threads() : 1);
+        RTIMED(4, parallel_columns_grain(0, cols, svt_column, &sj, (n * cols >= 4 * PAR_MIN_ENTRIES) ? dense_threads() : 1, 64)); /* ~500 flops a column: 64 at a time */
         free(t->G[k]); t->G[k] = Gk;
         free(t->G[k + 1]); t->G[k + 1] = Gn;
         t->r[k + 1] = rnew;
@@ -929,9 +938,7 @@ static double *cross_eval_core(struct cross *c, size_t k)
 }
 
 /* C3SC_PROFILE=1: where the driver's own time goes (printed at the end of an interpolation) */
-#include <time.h>
 static double g_tc[6]; /* callback+gather, qr, maxvol, convergence check, rounding, total */
-static double tnow(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #define TIMED(slot, stmt) do { const double t__ = tnow(); stmt; g_tc[slot] += tnow() - t__; } while (0)
 
 /* left-to-right half sweep: new left index sets, interpolatory cores; returns the TT */
@@ -1349,8 +1356,11 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
         g_tc[5] = tnow() - t_all;
         fprintf(stderr, "c3sc cross profile: total %.2f ms = fibers (callback + gather, or whole device iterations incl. their fetch) %.2f, confirming launch + fetch %.2f, lu + maxvol %.2f, convergence check %.2f, rounding %.2f\n",
                 1e3 * g_tc[5], 1e3 * g_tc[0], 1e3 * g_tc[1], 1e3 * g_tc[2], 1e3 * g_tc[3], 1e3 * g_tc[4]);
+        fprintf(stderr, "c3sc rounding profile (also inside the convergence checks): orthogonalisation QR %.2f + products %.2f, truncation QR %.2f + SVD %.2f + products %.2f ms\n",
+                1e3 * g_rt[0], 1e3 * g_rt[1], 1e3 * g_rt[2], 1e3 * g_rt[3], 1e3 * g_rt[4]);
     }
     memset(g_tc, 0, sizeof(g_tc));
+    memset(g_rt, 0, sizeof(g_rt));
     {
         size_t *nl = xcalloc(d, sizeof(size_t)), *nr = xcalloc(d, sizeof(size_t));
         for (size_t k = 0; k < d; k++) { nl[k] = c.r[k]; nr[k] = c.r[k + 1]; }

@@ -293,3 +293,42 @@ def test_rank_adaptation_survives_degenerate_index_sets(oracle):
     L.valuef_destroy(v0)
     print("worst nodal error over noise seeds:", worst)
     assert worst <= 2e-8 * np.abs(want).max()
+
+
+_THREADS_SNIPPET = r"""
+import ctypes as C, hashlib, sys
+import numpy as np
+sys.path.insert(0, {tests!r})
+import test_cross_driver as t
+L, fl = t._lib()
+L.valuef_get_cores.restype = C.POINTER(C.POINTER(C.c_double))
+n, d = 48, 4
+grids = [np.linspace(-1.0, 1.0, n) + 0.01 * m for m in range(d)]
+f = lambda X: np.abs(X[:, 0] + 0.7 * X[:, 1] - 0.5 * X[:, 2] + 0.3 * X[:, 3]) + 0.2 * np.sqrt(0.1 + (X ** 2).sum(axis=1))
+vf, ranks, calls = t._interp(L, fl, f, grids, startrank=24, kickrank=8, maxrank=6, crossrank=24, cross_tol=1e-8, round_tol=1e-8, batch=True, cross_maxiter=2)
+pp = L.valuef_get_cores(vf)
+h = hashlib.sha256()
+for m in range(d):
+    h.update(np.ctypeslib.as_array(pp[m], shape=(n * ranks[m] * ranks[m + 1],)).tobytes())
+print("RESULT", ranks, h.hexdigest())
+"""
+
+
+def test_rounding_does_not_depend_on_the_number_of_host_threads():
+    """The dense host loops of the rounding (Householder panels, columns of Q, small products: c3sc_cross.c) run over whole columns
+    on a small thread pool when the matrices are large (an elevated cross rank: 1152 x 24 here).  Every column's arithmetic is the
+    serial loop's, so the rounded train must be the same BITS with one thread and with four (C3SC_THREADS_KEEP: the pool stays on
+    even where its start-up measurement would switch it off)."""
+    import subprocess
+    import sys
+    outs = []
+    for threads in ("1", "4"):
+        env = dict(os.environ, C3SC_THREADS=threads, C3SC_THREADS_KEEP="1")
+        r = subprocess.run([sys.executable, "-c", _THREADS_SNIPPET.format(tests=os.path.dirname(os.path.abspath(__file__)))],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1]
+        outs.append(line)
+    print(outs[0])
+    assert outs[0] == outs[1], outs
+    assert "[1, 6, 6, 6, 1]" in outs[0], outs[0]  # the cap binds: the cross ran at 24 and was cut back

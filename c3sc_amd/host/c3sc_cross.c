@@ -426,6 +426,174 @@ C3SC_CLONES static void svd_jacobi(size_t m, size_t n, double *A, double *S, dou
     }
 }
 
+/* SVD of a square n x n matrix by bidiagonalisation + implicit-shift QR (Golub-Kahan-Reinsch; Golub & Van Loan, Matrix
+ * Computations, alg. 5.4.2 and 8.6.1/8.6.2), same convention as svd_jacobi: on exit A = U diag(S), columns by decreasing S, V the
+ * right singular vectors.  For the 48 x 48 triangular factors of an elevated cross rank this is ~2 Mflop where the one-sided Jacobi
+ * needs 10-15 (it was 2.9 of the rounding's 7.3 ms per sweep at cross rank 48); singular values far below the rounding tolerance lose
+ * relative (not absolute) accuracy against Jacobi, which the truncation does not see.  Returns 0, or 1 if a block did not converge
+ * in 60 sweeps (the caller then runs svd_jacobi on its copy of the input). */
+static void givens(double f, double g, double *c, double *s, double *r)
+{
+    if (g == 0.0) { *c = 1.0; *s = 0.0; *r = f; return; }
+    if (f == 0.0) { *c = 0.0; *s = 1.0; *r = g; return; }
+    const double h = hypot(f, g);
+    *c = f / h; *s = g / h; *r = h;
+}
+/* columns i and j of the n x n column-major M: (m_i, m_j) <- (c m_i + s m_j, -s m_i + c m_j) */
+static inline void rot_cols(double *M, size_t n, size_t i, size_t j, double c, double s)
+{
+    double *a = M + i * n, *b = M + j * n;
+    for (size_t t = 0; t < n; t++) { const double x = a[t], y = b[t]; a[t] = c * x + s * y; b[t] = c * y - s * x; }
+}
+C3SC_CLONES static int svd_gkr(size_t n, double *A, double *S, double *V)
+{
+    if (n == 0) return 0;
+    double *d = xcalloc(n, sizeof(double)), *e = xcalloc(n, sizeof(double)); /* e[i] = B[i][i+1] */
+    double *U = xcalloc(n * n, sizeof(double));
+    double *vl = xcalloc(n * n, sizeof(double)), *vr = xcalloc(n * n, sizeof(double)); /* left / right Householder vectors (unit 2-norm) */
+    unsigned char *hasl = xcalloc(n, 1), *hasr = xcalloc(n, 1);
+    /* ---- bidiagonalisation: A = U1 B V1^T */
+    for (size_t i = 0; i < n; i++) {
+        { /* left reflector: column i, rows i .. n-1 */
+            double *a = A + i * n;
+            const double nrm = sqrt(dotn(a + i, a + i, n - i));
+            if (nrm != 0.0) {
+                double *v = vl + i * n;
+                const double alpha = a[i] >= 0.0 ? -nrm : nrm;
+                for (size_t t = i; t < n; t++) v[t] = a[t];
+                v[i] -= alpha;
+                const double vn = sqrt(dotn(v + i, v + i, n - i));
+                for (size_t t = i; t < n; t++) v[t] /= vn;
+                hasl[i] = 1;
+                for (size_t j = i; j < n; j++) reflect(v, A + j * n, i, n);
+            }
+            d[i] = a[i];
+        }
+        if (i + 1 < n) { /* right reflector: row i, columns i+1 .. n-1 */
+            double nrm2 = 0.0;
+            for (size_t j = i + 1; j < n; j++) nrm2 += A[i + j * n] * A[i + j * n];
+            const double nrm = sqrt(nrm2);
+            if (nrm != 0.0 && i + 2 < n) {
+                double *v = vr + i * n; /* entries i+1 .. n-1 */
+                const double a0 = A[i + (i + 1) * n], alpha = a0 >= 0.0 ? -nrm : nrm;
+                for (size_t j = i + 1; j < n; j++) v[j] = A[i + j * n];
+                v[i + 1] -= alpha;
+                double vn2 = 0.0;
+                for (size_t j = i + 1; j < n; j++) vn2 += v[j] * v[j];
+                const double vn = sqrt(vn2);
+                for (size_t j = i + 1; j < n; j++) v[j] /= vn;
+                hasr[i] = 1;
+                for (size_t r = i; r < n; r++) { /* row r <- row r (I - 2 v v^T) */
+                    double sdot = 0.0;
+                    for (size_t j = i + 1; j < n; j++) sdot += A[r + j * n] * v[j];
+                    sdot *= 2.0;
+                    for (size_t j = i + 1; j < n; j++) A[r + j * n] -= sdot * v[j];
+                }
+            }
+            e[i] = A[i + (i + 1) * n];
+        }
+    }
+    /* U1 = HL_0 ... HL_{n-1}, V1 = HR_0 ... HR_{n-3}: reflectors applied backwards to the identity */
+    for (size_t j = 0; j < n; j++) { U[j + j * n] = 1.0; }
+    for (size_t i = 0; i < n * n; i++) V[i] = 0.0;
+    for (size_t j = 0; j < n; j++) V[j + j * n] = 1.0;
+    for (size_t i = n; i-- > 0;) {
+        if (hasl[i]) for (size_t j = i; j < n; j++) reflect(vl + i * n, U + j * n, i, n);
+        if (hasr[i]) for (size_t j = i + 1; j < n; j++) reflect(vr + i * n, V + j * n, i + 1, n);
+    }
+    /* ---- implicit-shift QR on the bidiagonal (d, e); rotations go into the columns of U and V */
+    const double eps = 2.220446049250313e-16;
+    double bnorm = 0.0;
+    for (size_t i = 0; i < n; i++) { const double x = fabs(d[i]) + (i + 1 < n ? fabs(e[i]) : 0.0); if (x > bnorm) bnorm = x; }
+    int failed = 0;
+    for (size_t k = n; k-- > 0 && !failed;) {
+        for (int iter = 0;; iter++) {
+            /* the active block l .. k: e[l-1] negligible (or l = 0), e[l .. k-1] not */
+            size_t l = k;
+            while (l > 0 && fabs(e[l - 1]) > eps * (fabs(d[l - 1]) + fabs(d[l])) && fabs(e[l - 1]) > 1e-300 + eps * eps * bnorm) l--;
+            if (l > 0) e[l - 1] = 0.0;
+            if (l == k) break; /* d[k] has converged */
+            if (iter == 60) { failed = 1; break; }
+            /* a negligible diagonal inside the block: rotate its row's superdiagonal entry away (rows i and j > i), the block splits */
+            int split = 0;
+            for (size_t i = l; i < k; i++)
+                if (fabs(d[i]) <= eps * bnorm) {
+                    d[i] = 0.0;
+                    double f = e[i];
+                    e[i] = 0.0;
+                    for (size_t j = i + 1; j <= k && f != 0.0; j++) { /* zero f = B[i][j] against d[j] with a rotation of rows i, j */
+                        double c, sn, r;
+                        givens(d[j], f, &c, &sn, &r);
+                        d[j] = r;
+                        rot_cols(U, n, j, i, c, sn); /* U columns follow the rows of B */
+                        if (j < k) { f = -sn * e[j]; e[j] = c * e[j]; }
+                    }
+                    split = 1;
+                    break;
+                }
+            if (split) continue;
+            /* Wilkinson shift from the trailing 2 x 2 of B^T B */
+            const double dm = d[k - 1], dn = d[k], em = (k - 1 > l) ? e[k - 2] : 0.0, en = e[k - 1];
+            const double t11 = dm * dm + em * em, t12 = dm * en, t22 = dn * dn + en * en;
+            const double dl = 0.5 * (t11 - t22);
+            double mu = t22;
+            if (!(dl == 0.0 && t12 == 0.0)) mu = t22 - t12 * t12 / (dl + (dl >= 0.0 ? 1.0 : -1.0) * hypot(dl, t12));
+            double y = d[l] * d[l] - mu, z = d[l] * e[l];
+            for (size_t i = l; i < k; i++) {
+                double c, sn, r;
+                givens(y, z, &c, &sn, &r); /* right rotation on columns i, i+1 */
+                if (i > l) e[i - 1] = r;
+                const double di = d[i], ei = e[i], dj = d[i + 1];
+                y = c * di + sn * ei;
+                e[i] = c * ei - sn * di;
+                z = sn * dj;
+                d[i + 1] = c * dj;
+                rot_cols(V, n, i, i + 1, c, sn);
+                givens(y, z, &c, &sn, &r); /* left rotation on rows i, i+1 */
+                d[i] = r;
+                const double ei2 = e[i], dj2 = d[i + 1];
+                y = c * ei2 + sn * dj2;
+                d[i + 1] = c * dj2 - sn * ei2;
+                if (i + 1 < k) { z = sn * e[i + 1]; e[i + 1] = c * e[i + 1]; }
+                e[i] = y;
+                rot_cols(U, n, i, i + 1, c, sn);
+            }
+        }
+    }
+    if (!failed) {
+        for (size_t j = 0; j < n; j++)
+            if (d[j] < 0.0) { d[j] = -d[j]; for (size_t t = 0; t < n; t++) V[t + j * n] = -V[t + j * n]; }
+        /* decreasing order (selection sort on columns), A <- U diag(S) */
+        for (size_t j = 0; j + 1 < n; j++) {
+            size_t b = j;
+            for (size_t q = j + 1; q < n; q++) if (d[q] > d[b]) b = q;
+            if (b != j) {
+                double t = d[j]; d[j] = d[b]; d[b] = t;
+                for (size_t i = 0; i < n; i++) { t = U[i + j * n]; U[i + j * n] = U[i + b * n]; U[i + b * n] = t; }
+                for (size_t i = 0; i < n; i++) { t = V[i + j * n]; V[i + j * n] = V[i + b * n]; V[i + b * n] = t; }
+            }
+        }
+        for (size_t j = 0; j < n; j++) { S[j] = d[j]; for (size_t i = 0; i < n; i++) A[i + j * n] = U[i + j * n] * d[j]; }
+    }
+    free(d); free(e); free(U); free(vl); free(vr); free(hasl); free(hasr);
+    return failed;
+}
+
+/* the SVD the rounding uses for its square factors: Golub-Kahan-Reinsch from GKR_MIN columns on, Jacobi below and as the fallback */
+#define GKR_MIN 24
+C3SC_CLONES static void svd_square(size_t n, double *A, double *S, double *V)
+{
+    if (n >= GKR_MIN && !getenv("C3SC_JACOBI_SVD")) {
+        double *copy = xcalloc(n * n, sizeof(double));
+        memcpy(copy, A, n * n * sizeof(double));
+        const int failed = svd_gkr(n, A, S, V);
+        if (failed) { memcpy(A, copy, n * n * sizeof(double)); svd_jacobi(n, n, A, S, V); }
+        free(copy);
+        return;
+    }
+    svd_jacobi(n, n, A, S, V);
+}
+
 /* ------------------------------------------------------------------------------ TT in the working layout */
 struct tt {
     size_t d;
@@ -590,7 +758,7 @@ C3SC_CLONES static void tt_round(struct tt *t, double eps, size_t rcap, size_t *
             double *R = xcalloc(n * n, sizeof(double)), *Q = xcalloc(m * n, sizeof(double));
             memcpy(Q, A, m * n * sizeof(double));
             RTIMED(2, qr_thin(m, n, Q, R));
-            RTIMED(3, svd_jacobi(n, n, R, S, V)); /* R <- U_R diag(S) */
+            RTIMED(3, svd_square(n, R, S, V)); /* R <- U_R diag(S) */
             /* only the columns that survive the truncation below are formed (a cross rank of 48 cut to 10: a fifth of them) */
             size_t keep = n;
             {

@@ -311,6 +311,12 @@ h = hashlib.sha256()
 for m in range(d):
     h.update(np.ctypeslib.as_array(pp[m], shape=(n * ranks[m] * ranks[m + 1],)).tobytes())
 print("RESULT", ranks, h.hexdigest())
+rng = np.random.default_rng(5)
+vals = []
+for _ in range(40):
+    ind = np.array([rng.integers(0, n) for _ in range(d)], dtype=np.uintp)
+    vals.append(float(L.valuef_eval_ind(vf, fl.sp(ind))))
+print("VALUES", " ".join(repr(v) for v in vals))
 """
 
 
@@ -332,3 +338,27 @@ def test_rounding_does_not_depend_on_the_number_of_host_threads():
     print(outs[0])
     assert outs[0] == outs[1], outs
     assert "[1, 6, 6, 6, 1]" in outs[0], outs[0]  # the cap binds: the cross ran at 24 and was cut back
+
+
+def test_rounding_svd_bidiagonal_qr_against_jacobi():
+    """The square factors of the rounding (24 x 24 here, 48 x 48 at car7d's cross rank) are decomposed by Householder
+    bidiagonalisation + implicit-shift QR (svd_gkr, c3sc_cross.c); C3SC_JACOBI_SVD=1 keeps the one-sided Jacobi everywhere.  Both
+    must round the same cross approximation to the same ranks and the same function (values at 40 nodes to 1e-10 of the largest)."""
+    import subprocess
+    import sys
+    res = []
+    for jac in (False, True):
+        env = dict(os.environ, C3SC_THREADS="1")
+        env.pop("C3SC_JACOBI_SVD", None)
+        if jac:
+            env["C3SC_JACOBI_SVD"] = "1"
+        r = subprocess.run([sys.executable, "-c", _THREADS_SNIPPET.format(tests=os.path.dirname(os.path.abspath(__file__)))],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ranks = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split("]")[0]
+        vals = np.array([float(x) for x in [l for l in r.stdout.splitlines() if l.startswith("VALUES")][-1].split()[1:]])
+        res.append((ranks, vals))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    diff = np.abs(res[0][1] - res[1][1]).max() / np.abs(res[1][1]).max()
+    print(f"bidiagonal QR vs Jacobi in the rounding: {res[0][0]}], largest difference of 40 node values {diff:.2e} of the largest value")
+    assert diff < 1e-10

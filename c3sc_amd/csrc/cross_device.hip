@@ -455,8 +455,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
         __syncthreads();
         for (int i = tid; i < m; i += NT) {
             const double cv = A[i + bj * m] / piv;
-            if (cv != 0.0)
-                for (int c0 = 0; c0 < n; c0 += CH) {
+            for (int c0 = 0; c0 < n; c0 += CH) { // every row, zero multipliers too (as lu_maxvol)
                     double x[CH], rc[CH];
 #pragma unroll
                     for (int u = 0; u < CH; u++) {
@@ -516,6 +515,19 @@ __global__ void __launch_bounds__(NT) k_cross_core(const CoreArgs P) { core_step
 //   * substitution, maxvol updates: a row at a time in REGISTERS (NR doubles, statically indexed, padded with +0 beyond n: a
 //     product of two +0 subtracts as +0 and leaves every value, -0 included, as it is): one round trip per row.  The pivot search
 //     of maxvol rides on the pass that produced the values (no separate read of the matrix).
+// The pivot search of a thread over the entries of ONE row in ascending column order: the largest magnitude with 22 mantissa bits
+// dropped, the first one among equals -- what the maximum of pivot_key(x, t m + i) over the row gives, at six instructions an
+// entry instead of ten (the key itself is formed once per row, row_key).
+struct RowBest { unsigned long long tm; int t; };
+__device__ __forceinline__ void track(RowBest &b, double x, int t)
+{
+    const unsigned long long tm = ((unsigned long long)__double_as_longlong(fabs(x)) >> IDX_BITS) << IDX_BITS;
+    const bool better = tm > b.tm;
+    b.tm = better ? tm : b.tm;
+    b.t = better ? t : b.t;
+}
+__device__ __forceinline__ unsigned long long row_key(const RowBest &b, int m, int i) { return b.tm | (IDX_MASK - (unsigned long long)(b.t * m + i)); }
+
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F &&f)
 {
@@ -896,12 +908,14 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
             });
             x[j] = s;
         });
+        RowBest rb = {0ull, 0};
 #pragma unroll
-        for (int t = 0; t < NR; t++) { // the padding columns stay +0: their keys lose against any entry that is not zero
+        for (int t = 0; t < NR; t++) { // the padding columns stay +0: they lose against any entry that is not zero (and come last among zeros)
             (A + t * ms)[i] = x[t];
-            const unsigned long long kk = pivot_key(x[t], (unsigned long long)(t * ms + i));
-            key = kk > key ? kk : key;
+            track(rb, x[t], t);
         }
+        const unsigned long long kk = row_key(rb, m, i);
+        key = kk > key ? kk : key;
     }
     CORE_STAMP(3);
     // ---- maxvol: swap rows until the largest entry of B is <= 1 + swap_tol
@@ -916,27 +930,28 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
         if (tid < MAXR) rowv[tid] = tid < n ? A[bi + tid * m] - (tid == bj ? 1.0 : 0.0) : 0.0;
         __syncthreads();
         key = 0;
-        for (int i = tid; i < m; i += NT) { // the row in registers: updated (if its multiplier is not zero) and searched in one pass
+        for (int i = tid; i < m; i += NT) { // the row in registers: updated and searched in one pass (zero multipliers are not skipped: as lu_maxvol)
             double x[NR];
             const double cv = A[i + bj * m] / piv;
             int ms = m;
             asm volatile("" : "+s"(ms));
 #pragma unroll
             for (int t = 0; t < NR; t++) x[t] = (A + t * ms)[i];
-            if (cv != 0.0) {
+            {
                 int opaque = 0;
                 asm volatile("" : "+v"(opaque));
                 const double *rv = rowv + opaque;
 #pragma unroll
                 for (int t = 0; t < NR; t++) x[t] -= cv * rv[t]; // rowv is +0 beyond n: the padding stays +0
-#pragma unroll
-                for (int t = 0; t < NR; t++) (A + t * ms)[i] = x[t];
             }
+            RowBest rb = {0ull, 0};
 #pragma unroll
             for (int t = 0; t < NR; t++) {
-                const unsigned long long kk = pivot_key(x[t], (unsigned long long)(t * ms + i));
-                key = kk > key ? kk : key;
+                (A + t * ms)[i] = x[t];
+                track(rb, x[t], t);
             }
+            const unsigned long long kk = row_key(rb, m, i);
+            key = kk > key ? kk : key;
         }
         if (tid == 0) rows[bj] = bi;
         nswaps++;

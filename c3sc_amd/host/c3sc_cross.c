@@ -351,7 +351,7 @@ C3SC_CLONES static int lu_maxvol(size_t m, size_t n, double *A, size_t *rows, si
         for (size_t c = 0; c < n; c++) {
             double *ac = A + c * m;
             const double rc = rowv[c];
-            for (size_t i = 0; i < m; i++) if (colv[i] != 0.0) ac[i] -= colv[i] * rc;
+            for (size_t i = 0; i < m; i++) ac[i] -= colv[i] * rc; /* every row, zero multipliers too (the device twins do not skip them either) */
         }
         rows[bj] = bi;
         ns++;

@@ -1030,6 +1030,13 @@ struct c3sc_cross_dev {
     unsigned long long pending[4] = {0, 0, 0, 0}; // counters read from the device but not handed to the caller yet
     int warm = 1;
     double swap_tol = 0.05;
+    // streamed cores (c3sc_hip_cross_iteration_streamed): the right-to-left half sweep produces the cores in the order the host's
+    // right-to-left orthogonalisation consumes them, so each is copied to the pinned block on a stream of its own as soon as its
+    // step has run, and the host starts rounding while the later steps are still running
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_step[MAXD] = {nullptr}, ev_core[MAXD] = {nullptr};
+    bool stream_cores = false;   // this iteration: copy each core early
+    bool cores_streamed = false; // the pinned block already holds the cores of the last iteration
 };
 
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1086,6 +1093,11 @@ void c3sc_hip_cross_free(c3sc_hip_ctx *c)
     }
     if (x->counters) (void)hipFree(x->counters);
     if (x->stage) (void)hipHostFree(x->stage);
+    for (int k = 0; k < MAXD; k++) {
+        if (x->ev_step[k]) (void)hipEventDestroy(x->ev_step[k]);
+        if (x->ev_core[k]) (void)hipEventDestroy(x->ev_core[k]);
+    }
+    if (x->copy_stream) (void)hipStreamDestroy(x->copy_stream);
     delete x;
     c->cross = nullptr;
 }
@@ -1328,6 +1340,10 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
     if (!c || !c->cross || c->cross->d == 0) return fail(c, C3SC_ERR_ARG, "cross_iteration: cross_setup first");
     c3sc_cross_dev *x = c->cross;
     x->stage_fresh = false;
+    if (x->cores_streamed) { // a streamed iteration whose result was never fetched: its copies must not land in the middle of this one's
+        HIPCHK(c, hipStreamSynchronize(x->copy_stream));
+        x->cores_streamed = false;
+    }
     const int d = x->d;
     hipStream_t st = (hipStream_t)stream;
     c3sc_hip_comm *comm = c->shard_comm;
@@ -1399,12 +1415,47 @@ static int cross_iteration_impl(c3sc_hip_ctx *c, c3sc_hip_ctx *pol, long long po
             else if (ncol <= 40) hipLaunchKernelGGL(k_cross_core_g<40>, dim3(1), dim3(NT), lds, st, P);
             else hipLaunchKernelGGL(k_cross_core_g<48>, dim3(1), dim3(NT), lds, st, P);
         }
+        if (x->stream_cores && half == 1) { // the core of this step is final: on its way to the host behind the step, beside the next steps
+            HIPCHK(c, hipEventRecord(x->ev_step[k], st));
+            HIPCHK(c, hipStreamWaitEvent(x->copy_stream, x->ev_step[k], 0));
+            HIPCHK(c, hipMemcpyAsync(x->stage + x->offG[k], x->slab + x->offG[k], (size_t)r0 * N * r1 * sizeof(double), hipMemcpyDeviceToHost, x->copy_stream));
+            HIPCHK(c, hipEventRecord(x->ev_core[k], x->copy_stream));
+        }
     }
     HIPCHK(c, hipGetLastError());
+    if (x->stream_cores) { x->cores_streamed = true; x->stream_cores = false; }
     return C3SC_OK;
 }
 
 int c3sc_hip_cross_iteration(c3sc_hip_ctx *c, int box, void *stream) { return cross_iteration_impl(c, nullptr, 0, box, stream); }
+
+int c3sc_hip_cross_iteration_streamed(c3sc_hip_ctx *c, int box, void *stream)
+{
+    if (!c || !c->cross || c->cross->d == 0) return fail(c, C3SC_ERR_ARG, "cross_iteration_streamed: cross_setup first");
+    c3sc_cross_dev *x = c->cross;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!x->copy_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&x->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < MAXD; k++) {
+            HIPCHK(c, hipEventCreateWithFlags(&x->ev_step[k], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&x->ev_core[k], hipEventDisableTiming));
+        }
+    }
+    x->stream_cores = true;
+    const int rc = cross_iteration_impl(c, nullptr, 0, box, stream);
+    x->stream_cores = false;
+    return rc;
+}
+
+int c3sc_hip_cross_wait_core(c3sc_hip_ctx *c, int k, double *h_core)
+{
+    if (!c || !c->cross || k < 0 || k >= c->cross->d || !h_core) return fail(c, C3SC_ERR_ARG, "cross_wait_core: bad argument");
+    c3sc_cross_dev *x = c->cross;
+    if (!x->cores_streamed) return fail(c, C3SC_ERR_ARG, "cross_wait_core: no streamed iteration is under way");
+    HIPCHK(c, hipEventSynchronize(x->ev_core[k]));
+    std::memcpy(h_core, x->stage + x->offG[k], (size_t)x->r[k] * x->N[k] * x->r[k + 1] * sizeof(double));
+    return C3SC_OK;
+}
 
 int c3sc_hip_cross_iteration_pi(c3sc_hip_ctx *c, c3sc_hip_ctx *policy_ctx, long long policy_tag, void *stream)
 {
@@ -1516,7 +1567,12 @@ static int stage_download(c3sc_hip_ctx *c, const void *extra, void *extra_host, 
     c3sc_cross_dev *x = c->cross;
     const size_t nb = x->sets_bytes + x->cores_bytes;
     unsigned *hstat = (unsigned *)(x->stage + nb + 4 * sizeof(unsigned long long));
-    HIPCHK(c, hipMemcpyAsync(x->stage, x->slab, nb, hipMemcpyDeviceToHost, st));
+    if (x->cores_streamed) { // the cores came over one by one behind their steps (and the host may be reading them): the sets only
+        HIPCHK(c, hipStreamSynchronize(x->copy_stream));
+        HIPCHK(c, hipMemcpyAsync(x->stage, x->slab, x->off_cores, hipMemcpyDeviceToHost, st));
+        x->cores_streamed = false;
+    } else
+        HIPCHK(c, hipMemcpyAsync(x->stage, x->slab, nb, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(x->stage + nb, x->counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemsetAsync(x->counters, 0, 4 * sizeof(unsigned long long), st));
     HIPCHK(c, hipMemcpyAsync(hstat, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, st));

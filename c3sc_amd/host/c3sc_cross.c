@@ -674,9 +674,12 @@ C3SC_CLONES static void axpy_column(void *arg, size_t a)
 
 /* right-to-left orthogonalisation: afterwards cores 1..d-1 have orthonormal rows (right unfolding) and
  * ||T||_F = ||G_0||_F.  Ranks may shrink when r_k > N_k r_{k+1}. */
-C3SC_CLONES static void tt_orthogonalize_rl(struct tt *t)
-{
+C3SC_CLONES static void tt_orthogonalize_rl_from(struct tt *t, void (*need)(void *, size_t), void *arg)
+{ /* need(arg, k), if given, is called before core k is touched for the first time (cores d-1, d-2, ..., 0 in this order): a caller
+   * whose cores arrive in that order -- the device's right-to-left half sweep -- fills them in as they come */
+    if (need) need(arg, t->d - 1);
     for (size_t k = t->d - 1; k >= 1; k--) {
+        if (need) need(arg, k - 1);
         const size_t r0 = t->r[k], N = t->N[k], r1 = t->r[k + 1], cols = N * r1;
         const size_t p0 = t->r[k - 1], Np = t->N[k - 1], rowsP = p0 * Np;
         if (cols < r0) {
@@ -716,6 +719,8 @@ C3SC_CLONES static void tt_orthogonalize_rl(struct tt *t)
     }
 }
 
+static void tt_orthogonalize_rl(struct tt *t) { tt_orthogonalize_rl_from(t, NULL, NULL); }
+
 static double tt_frob_of_core0(const struct tt *t)
 {
     double s = 0.0;
@@ -738,11 +743,18 @@ C3SC_CLONES static void svt_column(void *arg, size_t c)
 
 /* TT rounding to relative accuracy eps in the nodal Frobenius norm, ranks cut to rcap at most (rcap = 0: no cap).  eps_ranks (d + 1
  * entries, or NULL) returns the ranks the accuracy alone asks for: the rank adaptation kicks a cross rank that eps does not reduce. */
-C3SC_CLONES static void tt_round(struct tt *t, double eps, size_t rcap, size_t *eps_ranks)
+C3SC_CLONES static void tt_truncate_lr(struct tt *t, double eps, size_t rcap, size_t *eps_ranks);
+static void tt_round(struct tt *t, double eps, size_t rcap, size_t *eps_ranks)
 {
     if (eps_ranks) memcpy(eps_ranks, t->r, (t->d + 1) * sizeof(size_t));
     if (t->d < 2) return;
     tt_orthogonalize_rl(t);
+    tt_truncate_lr(t, eps, rcap, eps_ranks);
+}
+
+/* the second half of the rounding: left-to-right truncation of a train whose cores 1 .. d-1 have orthonormal rows */
+C3SC_CLONES static void tt_truncate_lr(struct tt *t, double eps, size_t rcap, size_t *eps_ranks)
+{
     const double nrm = tt_frob_of_core0(t);
     const double delta = eps * nrm / sqrt((double)(t->d - 1));
     for (size_t k = 0; k + 1 < t->d; k++) {
@@ -1241,6 +1253,47 @@ static struct tt *cross_iteration_device(struct cross *c)
     return t;
 }
 
+/* The last cross iteration of an interpolation on the device, with the rounding's right-to-left orthogonalisation riding on it: the
+ * device's right-to-left half sweep finishes the cores in the order d-1, ..., 0 -- the order the orthogonalisation consumes them in --
+ * and each core is on its way to the host as soon as its step has run (c3sc_hip_cross_iteration_streamed).  The host factors core k
+ * while the device is still working on the steps of cores k-2, k-3, ...: at an elevated cross rank (1968 x 48 factorisations on both
+ * sides) about a quarter of the sweep disappears behind the device's own work.  Same arithmetic as tt_round on the fetched train:
+ * the returned train is already orthogonalised (tt_truncate_lr finishes the rounding). */
+struct stream_ctx { struct cross *c; struct tt *t; double waited; };
+static void stream_need(void *arg, size_t k)
+{
+    struct stream_ctx *sc = arg;
+    const double t0 = tnow();
+    if (c3sc_hip_cross_wait_core(sc->c->dev, (int)k, sc->t->G[k]) != 0) DIE("c3sc_hip_cross_wait_core: %s", c3sc_hip_last_error(sc->c->dev));
+    sc->waited += tnow() - t0;
+}
+static struct tt *cross_iteration_device_streamed(struct cross *c)
+{
+    const size_t d = c->d;
+    const double t_begin = tnow();
+    device_setup_if_fresh(c);
+    int rc = c3sc_hip_cross_iteration_streamed(c->dev, c->dev_box, NULL);
+    if (rc != 0) DIE("c3sc_hip_cross_iteration_streamed: %s", c3sc_hip_last_error(c->dev));
+    struct tt *t = tt_alloc(d, c->N, c->r);
+    struct stream_ctx sc = {c, t, 0.0};
+    const double t_orth = tnow();
+    if (d >= 2) tt_orthogonalize_rl_from(t, stream_need, &sc);
+    else stream_need(&sc, 0);
+    const double orth = tnow() - t_orth - sc.waited;
+    unsigned long long info[4] = {0, 0, 0, 0};
+    rc = c3sc_hip_cross_fetch(c->dev, NULL, (int32_t *const *)c->I, (int32_t *const *)c->J, info, NULL);
+    if (rc != 0) DIE("c3sc_hip_cross_fetch: %s", c3sc_hip_last_error(c->dev));
+    if (info[3] >= 2) DIE("valuef_interp: a rank of the sharded sweep failed (its rows arrived as NaN): all ranks stop here");
+    if (info[3]) memo_overflow(c->dev);
+    c->dev_nodes += info[0];
+    if (info[1]) c->deficient = 1;
+    c->nswaps += (size_t)info[2];
+    for (size_t k = 0; k < d; k++) { c->nfibers += 2 * c->r[k] * c->r[k + 1]; c->dev_requested += 2 * c->r[k] * c->r[k + 1] * c->N[k]; }
+    g_tc[4] += orth;                            /* the rounding's share ... */
+    g_tc[0] += tnow() - t_begin - orth;         /* ... and the device's: launches, waits for cores, the final fetch */
+    return t;
+}
+
 /* tuple sets of the requested size: keep what is there, extend with uniform-stride "diagonal" tuples
  * (valuefunc.c:672-690 seeds the sets from grid[m][stride*j]) that are not present yet */
 static int *resize_tuples(const int *old, size_t nold, size_t nnew, size_t len, const size_t *Ndims, size_t salt)
@@ -1374,14 +1427,19 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     struct tt *best = NULL;
     const double t_all = tnow();
     const int trace = getenv("C3SC_CROSS_TRACE") != NULL;
+    /* the last iteration's cores are streamed and orthogonalised as they arrive (bellman_vi's fibers; the policy-evaluation form
+     * counts its fibers per iteration and keeps the plain hand-over) */
+    const int stream_last = c.dev != NULL && c.dev_pol == NULL && getenv("C3SC_NO_STREAMED_ROUNDING") == NULL;
     for (int round = 0; round < 50; round++) {
         struct tt *prev = NULL, *cur = NULL;
         double rel = 1.0, prev2 = -1.0; /* prev2 = <prev, prev> once known */
         int pending = 0;                /* a convergence test deferred to the next iteration's confirmation */
+        int cur_orth = 0;               /* cur came from the streamed iteration: already orthogonalised right to left */
         for (size_t it = 0; it < maxiter; it++) {
             c.deficient = 0;
             int **Iold = copy_sets(&c, c.I, 0), **Jold = copy_sets(&c, c.J, 1);
             struct tt *t2 = NULL;
+            int t2_orth = 0;
             if (c.dev && it == 0 && round == 0 && c.dev_speculate) {
                 /* A sweep that starts from the previous sweep's index sets usually ends with them: the value function moved a
                  * little and the pivot search starts from the old rows.  The device evaluates the fiber lists of all d cores
@@ -1440,6 +1498,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             }
             if (stop_now) { free_sets(&c, Iold); free_sets(&c, Jold); break; }
             if (t2 != NULL) { /* confirmed: sets unchanged by construction */ }
+            else if (c.dev && stream_last && it + 1 >= maxiter) { t2 = cross_iteration_device_streamed(&c); t2_orth = 1; }
             else if (c.dev) TIMED(0, t2 = cross_iteration_device(&c));
             else {
                 struct tt *t1 = cross_sweep_lr(&c);
@@ -1456,6 +1515,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             free_sets(&c, Iold); free_sets(&c, Jold);
             tt_free(cur);
             cur = t2;
+            cur_orth = t2_orth;
             if (fixed_point) { if (verbose > 1) printf("  cross sweep %zu: index sets reproduced (fixed point)\n", it + 1); break; }
             if (it + 1 >= maxiter) break; /* the last iteration: its result is taken whatever the test would say */
             if (prev != NULL && c.dev && c.dev_confirm && c.dev_pol == NULL) { /* bellman_pi counts the fibers an iteration requests: not deferred there */
@@ -1482,9 +1542,17 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
         }
         tt_free(prev);
         /* rounding; if a rank survives untouched and may still grow, kick it and cross again */
-        struct tt *rounded = tt_copy(cur);
+        struct tt *rounded;
         size_t *eps_r = xcalloc(d + 1, sizeof(size_t));
-        TIMED(4, tt_round(rounded, round_tol, maxrank, eps_r));
+        if (cur_orth) { /* the first half of the rounding rode on the device's right-to-left half sweep */
+            rounded = cur;
+            cur = NULL;
+            memcpy(eps_r, c.r, (d + 1) * sizeof(size_t));
+            if (d >= 2) TIMED(4, tt_truncate_lr(rounded, round_tol, maxrank, eps_r));
+        } else {
+            rounded = tt_copy(cur);
+            TIMED(4, tt_round(rounded, round_tol, maxrank, eps_r));
+        }
         int kicked = 0;
         if (adapt == 1) {
             /* Rounding dropped every rank, so the rule below would stop here.  If the last cross iteration worked on

@@ -236,6 +236,14 @@ int c3sc_hip_stencil_fibers_host(c3sc_hip_ctx *ctx, int k, size_t F, const int32
  *   returns, so iteration / confirm / speculate / fetch may be given any stream (all calls of one context on the same one) */
 int c3sc_hip_cross_setup(c3sc_hip_ctx *ctx, const size_t *ranks, const int32_t *const *I, const int32_t *const *J, int new_sweep);
 int c3sc_hip_cross_iteration(c3sc_hip_ctx *ctx, int box, void *stream);
+/* The same iteration with its cores STREAMED to the host: the right-to-left half sweep produces the cores in the order k = d-1 .. 0,
+ * the order in which a right-to-left orthogonalisation (the first half of the TT rounding, what C3's ftapprox_cross_rankadapt does
+ * behind valuefunc.c:728-733) consumes them.  Each core is copied to the pinned block on a stream of its own as soon as its step
+ * has run; c3sc_hip_cross_wait_core(k, h_core) waits for THAT copy only and hands the core over (working layout), while the later
+ * steps are still running.  c3sc_hip_cross_fetch afterwards brings the index sets and counters (pass h_cores = NULL).  Same kernels,
+ * same results as c3sc_hip_cross_iteration. */
+int c3sc_hip_cross_iteration_streamed(c3sc_hip_ctx *ctx, int box, void *stream);
+int c3sc_hip_cross_wait_core(c3sc_hip_ctx *ctx, int k, double *h_core);
 /* after an iteration that changed index sets: the confirming iteration as ONE launch (all core steps side by side on the values
  * they already hold, comparing instead of writing their index sets).  *confirmed = 1: the iteration that would follow changes
  * nothing and its cores are in place -- fetch them; 0: run c3sc_hip_cross_iteration[_pi] as usual.  Synchronises the stream. */

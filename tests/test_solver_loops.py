@@ -490,3 +490,47 @@ def test_device_memo_overflow_grows_the_table_and_gives_the_same_cores():
     assert abs(na - nt) <= 2e-2 * na
     lit = run("False", True)
     assert lit.returncode == 1 and "memo overflowed" in lit.stderr
+
+
+@pytest.mark.gpu
+def test_streamed_orthogonalisation_returns_the_same_bits_as_the_plain_hand_over():
+    """The last cross iteration of an interpolation streams its cores to the host as the right-to-left steps finish them and the
+    rounding's orthogonalisation factors each while the device works on the next (c3sc_hip_cross_iteration_streamed,
+    c3sc_hip_cross_wait_core); C3SC_NO_STREAMED_ROUNDING=1 fetches the finished train and rounds it afterwards.  Same arithmetic:
+    cores, ranks and node counts of six sweeps at an elevated cross rank must be identical, bit for bit."""
+    w = wl.WORKLOADS["car7d"]()
+    results = {}
+    for mode in ("streamed", "plain"):
+        if mode == "plain":
+            os.environ["C3SC_NO_STREAMED_ROUNDING"] = "1"
+        else:
+            os.environ.pop("C3SC_NO_STREAMED_ROUNDING", None)
+        try:
+            L, fl, ctl, aa = _setup(w, maxrank=10, kick=10, crossrank=30, cross_maxiter=1)
+            d = w.dx
+
+            def start(n, x, out, a):
+                X = np.ctypeslib.as_array(x, shape=(n, d))
+                np.ctypeslib.as_array(out, shape=(n,))[:] = 1.0 + 0.1 * ((X - 0.05) ** 2).sum(axis=1)
+                return 0
+
+            v = C.c_void_p(L.c3control_init_value(ctl.h, FIBER_FN(start), None, aa, 0))
+            rows = []
+            ne = C.c_size_t(0)
+            for it in range(6):
+                nxt = C.c_void_p(L.c3control_step_vi(ctl.h, v, aa, ctl.opt, 0, C.byref(ne)))
+                L.valuef_destroy(v)
+                v = nxt
+                ranks, cores = _cores_of(L, v, w)
+                rows.append((ne.value, ranks, cores))
+            results[mode] = rows
+            L.valuef_destroy(v)
+            L.approx_args_free(aa)
+            ctl.close()
+        finally:
+            os.environ.pop("C3SC_NO_STREAMED_ROUNDING", None)
+    for a, b in zip(results["streamed"], results["plain"]):
+        assert a[0] == b[0] and a[1] == b[1], (a[0], b[0], a[1], b[1])
+        for ca, cb in zip(a[2], b[2]):
+            assert ca.tobytes() == cb.tobytes()
+    print(f"car7d 41^7, cross rank 30 -> 10: six sweeps streamed and plain bit-identical; node evaluations {[r[0] for r in results['streamed']]}")

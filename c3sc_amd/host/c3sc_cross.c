@@ -1259,6 +1259,12 @@ static struct tt *cross_iteration_device(struct cross *c)
  * while the device is still working on the steps of cores k-2, k-3, ...: at an elevated cross rank (1968 x 48 factorisations on both
  * sides) about a quarter of the sweep disappears behind the device's own work.  Same arithmetic as tt_round on the fetched train:
  * the returned train is already orthogonalised (tt_truncate_lr finishes the rounding). */
+static size_t max_rank_of(const struct cross *c)
+{ /* below rank ~16 a core's factorisation is ~20 us: seven events and copies cost more than the overlap returns (measured at rank 10) */
+    size_t r = 1;
+    for (size_t k = 0; k <= c->d; k++) if (c->r[k] > r) r = c->r[k];
+    return r;
+}
 struct stream_ctx { struct cross *c; struct tt *t; double waited; };
 static void stream_need(void *arg, size_t k)
 {
@@ -1498,7 +1504,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             }
             if (stop_now) { free_sets(&c, Iold); free_sets(&c, Jold); break; }
             if (t2 != NULL) { /* confirmed: sets unchanged by construction */ }
-            else if (c.dev && stream_last && it + 1 >= maxiter) { t2 = cross_iteration_device_streamed(&c); t2_orth = 1; }
+            else if (c.dev && stream_last && it + 1 >= maxiter && max_rank_of(&c) > 16) { t2 = cross_iteration_device_streamed(&c); t2_orth = 1; }
             else if (c.dev) TIMED(0, t2 = cross_iteration_device(&c));
             else {
                 struct tt *t1 = cross_sweep_lr(&c);

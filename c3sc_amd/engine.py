@@ -24,7 +24,7 @@ c_i32_p = C.POINTER(C.c_int32)
 # every symbol include/c3sc_hip.h declares (the CPU test-suite checks they are all exported)
 EXPORTS = [
     "c3sc_hip_ctx_create", "c3sc_hip_ctx_destroy", "c3sc_hip_last_error", "c3sc_hip_device_count", "c3sc_hip_max_rank",
-    "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_consistent_ends", "c3sc_hip_get_consistent_ends", "c3sc_hip_cross_setup", "c3sc_hip_cross_iteration", "c3sc_hip_cross_iteration_pi", "c3sc_hip_cross_confirm", "c3sc_hip_bellman_fibers_all", "c3sc_hip_policy_fibers_all", "c3sc_hip_cross_speculate", "c3sc_hip_comm_unique_id", "c3sc_hip_comm_create", "c3sc_hip_comm_destroy", "c3sc_hip_comm_world", "c3sc_hip_comm_rank", "c3sc_hip_comm_allgather", "c3sc_hip_cross_set_comm", "c3sc_hip_comm_exchange", "c3sc_hip_cross_options", "c3sc_hip_cross_grow_memo", "c3sc_hip_cross_fetch", "c3sc_hip_cross_free", "c3sc_hip_set_mca", "c3sc_hip_set_model",
+    "c3sc_hip_set_grid", "c3sc_hip_set_boundary", "c3sc_hip_set_consistent_ends", "c3sc_hip_get_consistent_ends", "c3sc_hip_cross_setup", "c3sc_hip_cross_iteration", "c3sc_hip_cross_iteration_streamed", "c3sc_hip_cross_wait_core", "c3sc_hip_cross_iteration_pi", "c3sc_hip_cross_confirm", "c3sc_hip_bellman_fibers_all", "c3sc_hip_policy_fibers_all", "c3sc_hip_cross_speculate", "c3sc_hip_comm_unique_id", "c3sc_hip_comm_create", "c3sc_hip_comm_destroy", "c3sc_hip_comm_world", "c3sc_hip_comm_rank", "c3sc_hip_comm_allgather", "c3sc_hip_cross_set_comm", "c3sc_hip_comm_exchange", "c3sc_hip_cross_options", "c3sc_hip_cross_grow_memo", "c3sc_hip_cross_fetch", "c3sc_hip_cross_free", "c3sc_hip_set_mca", "c3sc_hip_set_model",
     "c3sc_hip_set_controls", "c3sc_hip_upload_value", "c3sc_hip_upload_value_device", "c3sc_hip_set_variant",
     "c3sc_hip_bellman_fibers", "c3sc_hip_bellman_fibers_tables", "c3sc_hip_bellman_fibers_tables_host", "c3sc_hip_stencil_fibers", "c3sc_hip_bellman_fibers_host",
     "c3sc_hip_policy_fibers", "c3sc_hip_policy_fibers_host", "c3sc_hip_policy_fibers_tables", "c3sc_hip_policy_fibers_tables_host",

@@ -332,7 +332,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
     const int tid = threadIdx.x;
     const int r0 = P.r0, N = P.N, r1 = P.r1;
     if (P.copy_only) { // G[a + r0 (j + N b)] = out[(a + r0 b) N + j]
-        if (P.confirm && P.dir == 0) return;
+        if (P.dir == 0) { if (!P.confirm) write_sets_and_next(P, 0, srows, pivabs, 0); return; } // the last left-to-right step: its core (the fiber values) is rewritten by the first right-to-left step
         const int total = r0 * N * r1;
         for (int e = tid; e < total; e += NT) {
             const int a = e % r0, j = (e / r0) % N, b = e / (r0 * N);
@@ -477,7 +477,9 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
     __syncthreads();
     CORE_STAMP(4);
     sort_rows(n, rows, srows, pos);
-    // ---- results, columns in the order of ascending rows
+    // ---- results, columns in the order of ascending rows.  A left-to-right step's core is never read: the right-to-left half of
+    // the iteration rewrites every core (c3sc_cross.c frees the left-to-right train unseen) -- only its index set counts
+    if (P.dir == 1)
     for (int i = tid; i < m; i += NT)
         for (int c0 = 0; c0 < n; c0 += CH) {
             double x[CH];
@@ -486,8 +488,7 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
 #pragma unroll
             for (int u = 0; u < CH; u++)
                 if (c0 + u < n) {
-                    if (P.dir == 0) { if (!P.confirm) P.G[i + m * pos[c0 + u]] = x[u]; } // G[i + m b'], i = a + r0 j
-                    else P.G[pos[c0 + u] + r0 * i] = x[u];                                // G[a' + r0 cc], cc = i
+                    P.G[pos[c0 + u] + r0 * i] = x[u]; // G[a' + r0 cc], cc = i
                 }
         }
     CORE_STAMP(5);
@@ -556,7 +557,7 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
     const int tid = threadIdx.x;
     const int r0 = P.r0, N = P.N, r1 = P.r1;
     if (P.copy_only) { // G[a + r0 (j + N b)] = out[(a + r0 b) N + j]
-        if (P.confirm && P.dir == 0) return;
+        if (P.dir == 0) { if (!P.confirm) write_sets_and_next(P, 0, srows, pivabs, 0); return; } // the last left-to-right step: its core (the fiber values) is rewritten by the first right-to-left step
         const int total = r0 * N * r1;
         for (int e = tid; e < total; e += NT) {
             const int a = e % r0, j = (e / r0) % N, b = e / (r0 * N);
@@ -960,6 +961,7 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
     __syncthreads();
     CORE_STAMP(4);
     sort_rows(n, rows, srows, pos);
+    if (P.dir == 1) // (a left-to-right step's core is never read: see core_step)
     for (int i = tid; i < m; i += NT) // results, columns in the order of ascending rows
         for (int c0 = 0; c0 < n; c0 += CH) {
             double x[CH];
@@ -968,8 +970,7 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
 #pragma unroll
             for (int u = 0; u < CH; u++)
                 if (c0 + u < n) {
-                    if (P.dir == 0) { if (!P.confirm) P.G[i + m * pos[c0 + u]] = x[u]; }
-                    else P.G[pos[c0 + u] + r0 * i] = x[u];
+                    P.G[pos[c0 + u] + r0 * i] = x[u];
                 }
         }
     CORE_STAMP(5);

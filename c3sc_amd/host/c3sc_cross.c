@@ -32,6 +32,14 @@
 #include "c3sc_hip.h"
 #include "c3sc_private.h"
 
+/* buffers that are written in full before they are read (no zeroing; measured: within the run-to-run noise of the rounding either way) */
+static void *xbuffer(size_t n, size_t sz)
+{
+    const size_t bytes = n * sz;
+    void *p = malloc(bytes > 0 ? bytes : 1);
+    if (!p) DIE("out of memory");
+    return p;
+}
 static double tnow(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 static double g_rt[6]; /* the rounding's own parts (C3SC_PROFILE): orthogonalisation QR, its products, truncation QR, SVD, products, rest */
 #define RTIMED(slot, stmt) do { const double t__ = tnow(); stmt; g_rt[slot] += tnow() - t__; } while (0)
@@ -236,7 +244,7 @@ C3SC_CLONES static void qr_q_column(void *arg, size_t j)
 C3SC_CLONES static void qr_thin(size_t m, size_t n, double *A, double *R)
 {
     assert(m >= n);
-    double *V = xcalloc(m * n, sizeof(double)); /* Householder vectors */
+    double *V = xbuffer(m * n, sizeof(double)); /* Householder vectors: column k is written (rows k .. m-1) before it is used, has[k] says whether */
     double *Rf = xcalloc(n * n, sizeof(double));
     unsigned char *has = xcalloc(n, 1);        /* 0: zero column below the diagonal, no reflector (e_k reflects onto itself) */
     const int nthr = (m * n >= PAR_MIN_ENTRIES) ? dense_threads() : 1;
@@ -657,13 +665,14 @@ static struct ValueF *valuef_from_tt(const struct tt *t, double **grid)
     return vf;
 }
 
-/* dst[:, a] += sum_b W(a, b) src[:, b] for one column a (b ascending, zero weights skipped): a column of a product with a small
+/* dst[:, a] = sum_b W(a, b) src[:, b] for one column a (b ascending, zero weights skipped): a column of a product with a small
  * matrix, W(a, b) = W[a * sa + b * sb] */
 struct axpy_job { size_t rows, nb, sb, sa; const double *W, *src; double *dst; };
 C3SC_CLONES static void axpy_column(void *arg, size_t a)
 {
     const struct axpy_job *q = arg;
     double *dst = q->dst + a * q->rows;
+    memset(dst, 0, q->rows * sizeof(double));
     for (size_t b = 0; b < q->nb; b++) {
         const double w = q->W[a * q->sa + b * q->sb];
         if (w == 0.0) continue;
@@ -702,15 +711,15 @@ C3SC_CLONES static void tt_orthogonalize_rl_from(struct tt *t, void (*need)(void
             continue;
         }
         /* A = G_k as r0 x cols (cols >= r0): QR of A^T (cols x r0), A^T = Q R  ->  A = R^T Q^T */
-        double *At = xcalloc(cols * r0, sizeof(double));
+        double *At = xbuffer(cols * r0, sizeof(double));
         for (size_t c = 0; c < cols; c++)
             for (size_t a = 0; a < r0; a++) At[c + a * cols] = t->G[k][a + r0 * c];
         double *R = xcalloc(r0 * r0, sizeof(double));
         RTIMED(0, qr_thin(cols, r0, At, R));
-        double *Gn = xcalloc(r0 * cols, sizeof(double));
+        double *Gn = xbuffer(r0 * cols, sizeof(double));
         for (size_t c = 0; c < cols; c++)
             for (size_t a = 0; a < r0; a++) Gn[a + r0 * c] = At[c + a * cols];
-        double *Pn = xcalloc(rowsP * r0, sizeof(double));
+        double *Pn = xbuffer(rowsP * r0, sizeof(double)); /* axpy_column clears its column first */
         struct axpy_job job = {rowsP, r0, r0, 1, R, t->G[k - 1], Pn}; /* (G_{k-1} R^T)[:, a] = sum_b G_{k-1}[:, b] R[a, b] */
         RTIMED(1, parallel_columns(0, r0, axpy_column, &job, (rowsP * r0 >= PAR_MIN_ENTRIES) ? dense_threads() : 1));
         free(t->G[k]); t->G[k] = Gn;
@@ -767,7 +776,7 @@ C3SC_CLONES static void tt_truncate_lr(struct tt *t, double eps, size_t rcap, si
              * columns of length n instead of m (a third of rounding's time on car7d: 410 x 10 cores).  A = Q R, R = U_R S V^T
              * => A = (Q U_R) S V^T; on exit A holds (Q U_R) diag(S) like svd_jacobi's own convention. */
             S = xcalloc(n, sizeof(double)); V = xcalloc(n * n, sizeof(double));
-            double *R = xcalloc(n * n, sizeof(double)), *Q = xcalloc(m * n, sizeof(double));
+            double *R = xcalloc(n * n, sizeof(double)), *Q = xbuffer(m * n, sizeof(double));
             memcpy(Q, A, m * n * sizeof(double));
             RTIMED(2, qr_thin(m, n, Q, R));
             RTIMED(3, svd_square(n, R, S, V)); /* R <- U_R diag(S) */
@@ -778,7 +787,6 @@ C3SC_CLONES static void tt_truncate_lr(struct tt *t, double eps, size_t rcap, si
                 while (keep > 1 && tl + S[keep - 1] * S[keep - 1] <= delta * delta) { tl += S[keep - 1] * S[keep - 1]; keep--; }
                 if (rcap > 0 && keep > rcap) keep = rcap;
             }
-            memset(A, 0, m * keep * sizeof(double));
             struct axpy_job job = {m, n, 1, n, R, Q, A}; /* A[:, j] = sum_q Q[:, q] R[q + j n] */
             RTIMED(4, parallel_columns(0, keep, axpy_column, &job, (m * n >= PAR_MIN_ENTRIES) ? dense_threads() : 1));
             free(R); free(Q);
@@ -796,13 +804,13 @@ C3SC_CLONES static void tt_truncate_lr(struct tt *t, double eps, size_t rcap, si
         if (eps_ranks) eps_ranks[k + 1] = rnew;
         if (rcap > 0 && rnew > rcap) rnew = rcap;
         /* G_k <- U[:, :rnew]; G_{k+1} <- diag(S) V^T [:rnew, :] G_{k+1} */
-        double *Gk = xcalloc(m * rnew, sizeof(double));
+        double *Gk = xbuffer(m * rnew, sizeof(double));
         for (size_t j = 0; j < rnew; j++) {
             const double inv = S[j] > 0.0 ? 1.0 / S[j] : 0.0;
             for (size_t i = 0; i < m; i++) Gk[i + j * m] = A[i + j * m] * inv;
         }
         const size_t cols = t->N[k + 1] * t->r[k + 2];
-        double *Gn = xcalloc(rnew * cols, sizeof(double));
+        double *Gn = xbuffer(rnew * cols, sizeof(double));
         struct svt_job sj = {n, rnew, V, S, t->G[k + 1], Gn};
         RTIMED(4, parallel_columns_grain(0, cols, svt_column, &sj, (n * cols >= 4 * PAR_MIN_ENTRIES) ? dense_threads() : 1, 64)); /* ~500 flops a column: 64 at a time */
         free(t->G[k]); t->G[k] = Gk;

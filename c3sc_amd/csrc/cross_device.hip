@@ -568,23 +568,22 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
     }
     const int m = P.dir == 0 ? r0 * N : N * r1, n = P.dir == 0 ? r1 : r0;
     double *A = P.work;
-    { // the fiber matrix: out[(a + r0 b) N + j] read in its own order (coalesced), element (row, column) of A written where it belongs
-        const int total = r0 * r1 * N;
-        for (int e0 = 0; e0 < total; e0 += NT * CH) {
+    // the fiber matrix, a row per thread: gathered loads (stride N or r0 N doubles, every line of `out` is used by neighbouring
+    // rows and stays in the caches) and coalesced stores.  Measured the other way round -- out read in its own order, elements
+    // scattered into A -- the scattered 8-byte stores cost twice as much (84 k -> 150-220 k cycles for 1968 x 48), with or
+    // without the index divisions.
+    for (int i = tid; i < m; i += NT) {
+        int base, step;
+        if (P.dir == 0) { base = (i % r0) * N + i / r0; step = r0 * N; } // out[(a + r0 c) N + j], i = a + r0 j
+        else { base = r0 * (i / N) * N + i % N; step = N; }              // out[(c + r0 b) N + j], i = j + N b
+        for (int c0 = 0; c0 < n; c0 += CH) {
             double x[CH];
 #pragma unroll
-            for (int u = 0; u < CH; u++) { const int e = e0 + u * NT + tid; x[u] = P.out[e < total ? e : total - 1]; }
+            for (int u = 0; u < CH; u++) x[u] = (c0 + u < n) ? P.out[base + step * (c0 + u)] : 0.0;
 #pragma unroll
-            for (int u = 0; u < CH; u++) {
-                const int e = e0 + u * NT + tid;
-                if (e < total) {
-                    const int f = e / N, j = e - f * N, b = f / r0, a = f - b * r0;
-                    if (P.dir == 0) A[(a + r0 * j) + b * m] = x[u]; // row a + r0 j, column b
-                    else A[(j + N * b) + a * m] = x[u];             // row j + N b, column a
-                }
-            }
+            for (int u = 0; u < CH; u++) if (c0 + u < n) A[i + (c0 + u) * m] = x[u];
         }
-        for (int e = tid; e < m * (NR - n); e += NT) A[n * m + e] = 0.0; // the padding columns of the rows' register image
+        for (int c = n; c < NR; c++) A[i + c * m] = 0.0; // the padding columns of the rows' register image
     }
     CORE_STAMP(0);
     mark_warm_rows(P, m, n, warmf, s_in, s_old);

@@ -264,7 +264,7 @@ def solver_measurements(workload, budget_s):
     norm = norms[-1] if norms else 0.0
     rel = [sv / nv for sv, nv in zip(steps, norms) if nv > 0]
     iters = {"converged": conv, "tol_rel_L2": tol_rel, "sweeps": nsw, "seconds": t_conv, "ms_per_sweep": 1e3 * t_conv / max(nsw, 1),
-             "node_backups": nb_total, "last_step_L2": steps[-1], "norm_L2": norm, "last_step_rel": steps[-1] / norm if norm else None,
+             "node_backups": nb_total, "nodes_per_s_through_the_driver": nb_total / t_conv if t_conv > 0 else None, "last_step_L2": steps[-1], "norm_L2": norm, "last_step_rel": steps[-1] / norm if norm else None,
              "step_rel_every_25_sweeps": [float(f"{v:.3e}") for v in rel[::25]],
              "step_rel_after_convergence": {"sweeps_1_to_60": {"median": float(np.median(after[:60])), "min": float(np.min(after[:60])), "max": float(np.max(after[:60]))},
                                             "sweeps_91_to_150": {"median": float(np.median(after[90:])), "min": float(np.min(after[90:])), "max": float(np.max(after[90:]))}} if after else None,

@@ -838,6 +838,7 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
             if (tid < 64) { // U[kc][c], c >= kc: the pivot row's entries, up to date through column kc - 1 (lane = column)
                 const int c = tid;
                 double a0 = (c >= kc && c < n) ? A[p + c * m] : 0.0;
+                const double a_in = a0;
                 const double lpv = c < kc ? A[p + c * m] : 0.0; // lane t: the pivot row's multiplier of column t
                 const int lplo = (int)(unsigned)((unsigned long long)__double_as_longlong(lpv) & 0xffffffffull);
                 const int lphi = (int)(unsigned)((unsigned long long)__double_as_longlong(lpv) >> 32);
@@ -854,6 +855,9 @@ __device__ __forceinline__ void core_step_global(const CoreArgs &P)
                             a0 -= lt * ut[u];
                         }
                 }
+                // a row beyond the first QG of its thread has its entry of column kc up to date in the matrix already (it was stored
+                // for the scaling below): nothing to subtract there
+                if (c == kc && p >= QG * NT) a0 = a_in;
                 if (c >= kc && c < n) U[kc * LS + c] = a0;
             }
             __syncthreads();

@@ -1444,6 +1444,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
     /* the last iteration's cores are streamed and orthogonalised as they arrive (bellman_vi's fibers; the policy-evaluation form
      * counts its fibers per iteration and keeps the plain hand-over) */
     const int stream_last = c.dev != NULL && c.dev_pol == NULL && getenv("C3SC_NO_STREAMED_ROUNDING") == NULL;
+    const size_t stream_min_rank = getenv("C3SC_STREAM_MIN_RANK") ? (size_t)atoi(getenv("C3SC_STREAM_MIN_RANK")) : 16; /* streamed above this rank */
     for (int round = 0; round < 50; round++) {
         struct tt *prev = NULL, *cur = NULL;
         double rel = 1.0, prev2 = -1.0; /* prev2 = <prev, prev> once known */
@@ -1512,7 +1513,7 @@ static struct ValueF *interp_impl(size_t d, fiber_fn f, fiber_batch_fn fb, fiber
             }
             if (stop_now) { free_sets(&c, Iold); free_sets(&c, Jold); break; }
             if (t2 != NULL) { /* confirmed: sets unchanged by construction */ }
-            else if (c.dev && stream_last && it + 1 >= maxiter && max_rank_of(&c) > 16) { t2 = cross_iteration_device_streamed(&c); t2_orth = 1; }
+            else if (c.dev && stream_last && it + 1 >= maxiter && max_rank_of(&c) > stream_min_rank) { t2 = cross_iteration_device_streamed(&c); t2_orth = 1; }
             else if (c.dev) TIMED(0, t2 = cross_iteration_device(&c));
             else {
                 struct tt *t1 = cross_sweep_lr(&c);

@@ -1327,6 +1327,26 @@ static struct ApproxArgs *device_rank_cap(struct C3Control *c, struct ApproxArgs
     return a;
 }
 
+/* Do the core steps of this interpolation fit the device's one-workgroup factorisation (c3sc_hip_cross_setup: at most 8192 rows,
+ * N r, of a fiber matrix; ranks up to 48)?  A grid of 200 nodes at cross rank 48 does not: the host-driven cross (same results,
+ * one launch per core step) serves it instead of ending the solve in cross_setup. */
+static int device_cross_fits(const struct C3Control *c, struct ApproxArgs *aa)
+{
+    size_t r = approx_args_get_maxrank(aa);
+    const size_t xr = approx_args_get_crossrank(aa);
+    const char *e = getenv("C3SC_CROSS_RANK_FACTOR");
+    if (xr > r) r = xr;
+    if (e && atof(e) > 1.0) r = (size_t)ceil(atof(e) * (double)approx_args_get_maxrank(aa));
+    if (r > 48) r = 48;
+    for (size_t m = 0; m < c->dx; m++)
+        if (r * c->ngrid[m] > 8192) {
+            static int told = 0;
+            if (!told) { fprintf(stderr, "c3sc: %zu nodes at rank %zu exceed the device's core step (8192 rows): the cross iteration is driven from the host\n", c->ngrid[m], r); told = 1; }
+            return 0;
+        }
+    return 1;
+}
+
 struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct ApproxArgs *apargs, struct c3Opt *opt, int verbose,
                                  size_t *nevals)
 { /* bellman.c:2177-2212; the interpolation asks for whole core steps, each one kernel launch */
@@ -1343,7 +1363,7 @@ struct ValueF *c3control_step_vi(struct C3Control *c, struct ValueF *vf, struct 
     const int rccl = c->shard_comm != NULL && c->shard_exchange == c3sc_hip_comm_exchange; /* sharded over the C communicator */
     const int sharded = (c->shard_world > 1 && c->shard_exchange != NULL) && !rccl;
     const int checked = c->dp->model_checked || c->dp->stagecost == NULL || c->dp->boundcost == NULL || c->dp->obscost == NULL;
-    if (dp_has_device_model(c->dp) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL) {
+    if (dp_has_device_model(c->dp) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL && device_cross_fits(c, aa)) {
         const double t0 = prof ? now_s() : 0.0;
         struct c3sc_hip_ctx *ctx = sync_device(vi);
         c3sc_hip_cross_set_comm(ctx, rccl ? c->shard_comm : NULL);
@@ -1374,7 +1394,7 @@ struct ValueF *c3control_step_pi(struct C3Control *c, struct ValueF *vf, struct 
     /* whole cross iterations on the device, as in c3control_step_vi: candidate lists of a device model, unsharded */
     const int sharded = c->shard_world > 1 && c->shard_exchange != NULL;
     const int checked = c->dp->model_checked || c->dp->stagecost == NULL || c->dp->boundcost == NULL || c->dp->obscost == NULL;
-    if (dp_has_device_model(c->dp) && c3opt_is_bruteforce(opt) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL) {
+    if (dp_has_device_model(c->dp) && c3opt_is_bruteforce(opt) && !sharded && checked && getenv("C3SC_HOST_CROSS") == NULL && device_cross_fits(c, aa)) {
         struct ControlParams *cp = poli->cp;
         struct c3sc_hip_ctx *ctx_it = sync_device_ctx(cp, workspace_get_hip_ctx(cp->work), poli->vf_iteration);
         struct c3sc_hip_ctx *ctx_pol = sync_device_ctx(cp, workspace_get_hip_ctx_policy(cp->work), poli->vf_policy);

@@ -313,7 +313,7 @@ constexpr int CH_LDS = 8, CH_GLOBAL = 8; // 24 loads per trip on global scratch 
 #define CORE_STAMP(slot) do { } while (0)
 #define LU_STAMP(slot) do { } while (0)
 #endif
-template <int NRS>
+template <int NRS, int QG>
 __device__ __forceinline__ void core_step_regs(const CoreArgs &P, int m, int n, double *Lr, int LS, double *rowv, double *pivabs, int *rows, int *srows,
                                                int *pos, unsigned long long *red, unsigned char *warmf, int *s_in, int *s_old);
 
@@ -348,8 +348,9 @@ __device__ __forceinline__ void core_step(const CoreArgs &P)
         return;
     }
     const int m = P.dir == 0 ? r0 * N : N * r1, n = P.dir == 0 ? r1 : r0;
-    if (INLDS && n <= 16 && m <= NT) { // a row per thread and the whole row in registers (car7d at the rank cap: 410 x 10)
-        core_step_regs<16>(P, m, n, Lr, LS, rowv, pivabs, rows, srows, pos, red, warmf, s_in, s_old);
+    if (INLDS && n <= 16 && m <= 2 * NT) { // one or two rows per thread, whole rows in registers (car7d at the rank cap: 410 x 10; dubins3d on 101 nodes: 808 x 8)
+        if (m <= NT) core_step_regs<16, 1>(P, m, n, Lr, LS, rowv, pivabs, rows, srows, pos, red, warmf, s_in, s_old);
+        else core_step_regs<16, 2>(P, m, n, Lr, LS, rowv, pivabs, rows, srows, pos, red, warmf, s_in, s_old);
         return;
     }
     double *A = INLDS ? smem : P.work;
@@ -998,13 +999,14 @@ template <int NR>
 __global__ void __launch_bounds__(NT) k_cross_core_g(const CoreArgs P) { core_step_global<NR>(P); }
 
 // ------------------------------------------------------------------------------ the core step of a small matrix, in registers
-// At most NT rows and NRS = 16 columns (car7d at its rank cap: 410 x 10): a row per thread, the WHOLE row in registers from the
-// gather of the fiber values to the write of the core -- no matrix in LDS at all.  The LU is the column phase of core_step_global
-// with one panel (one barrier per column: every wavefront leaves its candidate's key and row in a slot, the winner's slot is the
-// pivot row), the pivot rows' multipliers go to L[rows] in LDS as they are chosen, the substitution runs on the registers, and a
-// maxvol swap is a broadcast of the swapped-in row through LDS and 2 n flops per thread.  Same arithmetic in the same order as
-// core_step and lu_maxvol: the same bits.
-template <int NRS>
+// At most QG NT rows (QG = 1 or 2 rows per thread) and NRS = 16 columns (car7d at its rank cap: 410 x 10): the WHOLE rows in
+// registers from the gather of the fiber values to the write of the core -- no matrix in LDS at all.  The LU is the column phase of
+// core_step_global with one panel (one barrier per column: every wavefront leaves its candidate's key and row in a slot, the
+// winner's slot is the pivot row), the pivot rows' multipliers go to L[rows] in LDS as they are chosen, the substitution runs on the
+// registers, and a maxvol swap is a broadcast of the swapped-in row through LDS and 2 n flops per row.  Same arithmetic in the same
+// order as core_step and lu_maxvol: the same bits.  (Which of a thread's rows is meant is always decided by BRANCHES over opaque
+// copies: a run-time index into the register rows, or a chain of selects the compiler turns into one, sends them to scratch.)
+template <int NRS, int QG>
 __device__ __forceinline__ void core_step_regs(const CoreArgs &P, int m, int n, double *Lr, int LS, double *rowv, double *pivabs, int *rows, int *srows,
                                                int *pos, unsigned long long *red, unsigned char *warmf, int *s_in, int *s_old)
 {
@@ -1014,34 +1016,54 @@ __device__ __forceinline__ void core_step_regs(const CoreArgs &P, int m, int n, 
 #endif
     __shared__ double slots[2 * (NT / 64) * NRS];
     const int tid = threadIdx.x, r0 = P.r0, N = P.N;
-    const bool has = tid < m;
-    const int i = has ? tid : 0;
-    double x[NRS];
-    {
+    bool has[QG];
+    int row[QG];
+    double x[QG][NRS];
+#pragma unroll
+    for (int qq = 0; qq < QG; qq++) {
+        row[qq] = tid + qq * NT;
+        has[qq] = row[qq] < m;
+        const int i = has[qq] ? row[qq] : 0;
         int base, step;
         if (P.dir == 0) { base = (i % r0) * N + i / r0; step = r0 * N; } // out[(a + r0 c) N + j], i = a + r0 j
         else { base = r0 * (i / N) * N + i % N; step = N; }              // out[(c + r0 b) N + j], i = j + N b
 #pragma unroll
-        for (int c = 0; c < NRS; c++) x[c] = c < n ? P.out[base + step * c] : 0.0; // +0 beyond n: stays +0 through every update
+        for (int c = 0; c < NRS; c++) x[qq][c] = c < n ? P.out[base + step * c] : 0.0; // +0 beyond n: stays +0 through every update
     }
     for (int e = tid; e < NRS * NRS; e += NT) Lr[(e / NRS) * LS + e % NRS] = 0.0; // L[rows]: rows filled as the pivots are chosen, +0 elsewhere
     CORE_STAMP(0);
     mark_warm_rows(P, m, n, warmf, s_in, s_old);
     CORE_STAMP(1);
-    const bool warm = has && warmf[i];
+    unsigned warmbits = 0, used = 0;
+    int mypos[QG];
+#pragma unroll
+    for (int qq = 0; qq < QG; qq++) { warmbits |= (has[qq] && warmf[has[qq] ? row[qq] : 0]) ? (1u << qq) : 0u; mypos[qq] = -1; }
     const double boost = (double)(1 << WARM_BOOST_LOG2);
-    int parity = 0, mypos = -1;
-    bool used = false;
+    int parity = 0;
     // ---- LU: one barrier per column
     static_for<0, NRS>([&](auto uu) {
         constexpr int u = decltype(uu)::value;
         if (u < n) {
-            const unsigned long long key = (has && !used) ? pivot_key(warm ? x[u] * boost : x[u], (unsigned long long)tid) : 0ull;
+            unsigned long long key = 0;
+            unsigned kbit = 0;
+#pragma unroll
+            for (int qq = 0; qq < QG; qq++) {
+                const double xv = x[qq][u];
+                const unsigned long long kk = (has[qq] && !((used >> qq) & 1u)) ? pivot_key(((warmbits >> qq) & 1u) ? xv * boost : xv, (unsigned long long)row[qq]) : 0ull;
+                const bool better = kk > key;
+                key = better ? kk : key;
+                kbit = better ? (1u << qq) : kbit;
+            }
             const unsigned long long wmax = wave_max_u64(key);
             double *slot = slots + (parity * (NT / 64) + (tid >> 6)) * NRS;
             if (key == wmax && key != 0) {
+                static_for<0, QG>([&](auto qv) {
+                    constexpr int qq = decltype(qv)::value;
+                    if (kbit == (1u << qq)) {
 #pragma unroll
-                for (int v = u; v < NRS; v++) slot[v] = x[v];
+                        for (int v = u; v < NRS; v++) { double t = x[qq][v]; asm volatile("" : "+v"(t)); slot[v] = t; }
+                    }
+                });
             }
             if ((tid & 63) == 0) red[parity * (NT / 64) + (tid >> 6)] = wmax;
             __syncthreads();
@@ -1055,65 +1077,89 @@ __device__ __forceinline__ void core_step_regs(const CoreArgs &P, int m, int n, 
             const double *win = slots + (parity * (NT / 64) + wb) * NRS;
             parity ^= 1;
             if (key == best && key != 0) { // the pivot row's owner: its multipliers are row u of L[rows]
-                used = true;
-                mypos = u;
+                used |= kbit;
+                static_for<0, QG>([&](auto qv) {
+                    constexpr int qq = decltype(qv)::value;
+                    if (kbit == (1u << qq)) {
+                        mypos[qq] = u;
 #pragma unroll
-                for (int j = 0; j < u; j++) Lr[u * LS + j] = x[j];
+                        for (int j = 0; j < u; j++) { double t = x[qq][j]; asm volatile("" : "+v"(t)); Lr[u * LS + j] = t; }
+                    }
+                });
             }
             const double dp = win[u];
             if (tid == 0) { rows[u] = (int)(IDX_MASK - (best & IDX_MASK)); pivabs[u] = fabs(dp); }
             const double inv = dp != 0.0 ? 1.0 / dp : 0.0;
-            if (has && !used) {
-                const double l = x[u] * inv;
-                x[u] = l;
 #pragma unroll
-                for (int v = u + 1; v < NRS; v++) x[v] -= l * win[v];
-            }
+            for (int qq = 0; qq < QG; qq++)
+                if (has[qq] && !((used >> qq) & 1u)) {
+                    const double l = x[qq][u] * inv;
+                    x[qq][u] = l;
+#pragma unroll
+                    for (int v = u + 1; v < NRS; v++) x[qq][v] -= l * win[v];
+                }
         }
     });
     __syncthreads();
     CORE_STAMP(2);
     // ---- B = L inv(L[rows]): pivot rows are unit vectors, the others solve x Lr = l in registers
-    if (has && used) {
 #pragma unroll
-        for (int t = 0; t < NRS; t++) x[t] = (t == mypos) ? 1.0 : 0.0;
-    } else if (has) {
-        static_for<0, NRS>([&](auto jj) {
-            constexpr int j = NRS - 1 - decltype(jj)::value;
-            double sacc = x[j];
+    for (int qq = 0; qq < QG; qq++) {
+        if (has[qq] && ((used >> qq) & 1u)) {
 #pragma unroll
-            for (int t = j + 1; t < NRS; t++) sacc -= x[t] * Lr[t * LS + j];
-            x[j] = sacc;
-        });
+            for (int t = 0; t < NRS; t++) x[qq][t] = (t == mypos[qq]) ? 1.0 : 0.0;
+        } else if (has[qq]) {
+            static_for<0, NRS>([&](auto jj) {
+                constexpr int j = NRS - 1 - decltype(jj)::value;
+                double sacc = x[qq][j];
+#pragma unroll
+                for (int t = j + 1; t < NRS; t++) sacc -= x[qq][t] * Lr[t * LS + j];
+                x[qq][j] = sacc;
+            });
+        }
     }
     CORE_STAMP(3);
     // ---- maxvol: the swapped-in row goes round through LDS, every thread updates its registers
     int nswaps = 0;
     for (int it = 0; it < 200; it++) {
-        RowBest rb = {0ull, 0};
+        unsigned long long key = 0;
 #pragma unroll
-        for (int t = 0; t < NRS; t++) track(rb, x[t], t);
-        const unsigned long long key = has ? row_key(rb, m, tid) : 0ull;
+        for (int qq = 0; qq < QG; qq++) {
+            RowBest rb = {0ull, 0};
+#pragma unroll
+            for (int t = 0; t < NRS; t++) track(rb, x[qq][t], t);
+            const unsigned long long kk = has[qq] ? row_key(rb, m, row[qq]) : 0ull;
+            key = kk > key ? kk : key;
+        }
         const unsigned long long best = block_max(key, red, parity);
         if (best == 0) break;
         const int lin = (int)(IDX_MASK - (best & IDX_MASK));
         const int bj = lin / m, bi = lin % m;
-        double xbj = x[0]; // the entry of column bj (a run-time column: selected, not indexed)
+        double xbj[QG]; // the entries of column bj (a run-time column: selected, not indexed)
 #pragma unroll
-        for (int t = 1; t < NRS; t++) xbj = (t == bj) ? x[t] : xbj;
-        if (tid == bi) {
+        for (int qq = 0; qq < QG; qq++) {
+            xbj[qq] = x[qq][0];
 #pragma unroll
-            for (int c = 0; c < NRS; c++) rowv[c] = x[c] - (c == bj ? 1.0 : 0.0);
-            rowv[NRS] = xbj;
+            for (int t = 1; t < NRS; t++) xbj[qq] = (t == bj) ? x[qq][t] : xbj[qq];
         }
+        static_for<0, QG>([&](auto qv) {
+            constexpr int qq = decltype(qv)::value;
+            if (row[qq] == bi) {
+#pragma unroll
+                for (int c = 0; c < NRS; c++) { double t = x[qq][c]; asm volatile("" : "+v"(t)); rowv[c] = t - (c == bj ? 1.0 : 0.0); }
+                rowv[NRS] = xbj[qq];
+            }
+        });
         __syncthreads();
         const double piv = rowv[NRS];
         if (!(fabs(piv) > 1.0 + P.swap_tol)) break;
-        if (has) {
-            const double cv = xbj / piv;
 #pragma unroll
-            for (int t = 0; t < NRS; t++) x[t] -= cv * rowv[t];
-        }
+        for (int qq = 0; qq < QG; qq++)
+            if (has[qq]) {
+                const double cv = xbj[qq] / piv;
+#pragma unroll
+                for (int t = 0; t < NRS; t++) x[qq][t] -= cv * rowv[t];
+            }
         if (tid == 0) rows[bj] = bi;
         nswaps++;
         // the barrier inside the next block_max stands between these reads of rowv and its next writer
@@ -1121,9 +1167,13 @@ __device__ __forceinline__ void core_step_regs(const CoreArgs &P, int m, int n, 
     __syncthreads();
     CORE_STAMP(4);
     sort_rows(n, rows, srows, pos);
-    if (P.dir == 1 && has) { // (a left-to-right step's core is never read: see core_step)
+    if (P.dir == 1) { // (a left-to-right step's core is never read: see core_step)
 #pragma unroll
-        for (int c = 0; c < NRS; c++) if (c < n) P.G[pos[c] + r0 * tid] = x[c]; // G[a' + r0 cc], cc = row
+        for (int qq = 0; qq < QG; qq++)
+            if (has[qq]) {
+#pragma unroll
+                for (int c = 0; c < NRS; c++) if (c < n) P.G[pos[c] + r0 * row[qq]] = x[qq][c]; // G[a' + r0 cc], cc = row
+            }
     }
     CORE_STAMP(5);
     write_sets_and_next(P, n, srows, pivabs, nswaps);

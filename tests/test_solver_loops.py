@@ -300,11 +300,12 @@ def test_speculative_first_iteration_same_bits_and_actually_used(name, kw, aargs
     ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=9, crossrank=40)),  # ranks above 32: global-scratch core steps
     ("car7d", dict(), dict(maxrank=10, kick=10, crossrank=26)),         # 1066 x 26 at full size: the global-scratch core step (left-looking LU, rows in registers) on real matrices
     ("car7d", dict(), dict(maxrank=10, kick=40, crossrank=48, cross_maxiter=1)),  # vi_iters_to_tol's configuration: 1968 x 48 and 1681 x 41 (padded to 48) steps
+    ("dubins3d", dict(ngrid=(101, 101, 101), rank=4), dict(maxrank=8, kick=2)),  # 808 x 8: two rows per thread in the register core step
     ("dubins3d", dict(ngrid=(101, 101, 101), rank=4), dict(maxrank=12, kick=12, crossrank=24)),  # 2424 x 24: more rows than the register panels hold (the plain left-looking LU of the global-scratch step)
     ("car7d", dict(ngrid=(9, 8, 10, 7, 6, 5, 11), rank=4), dict(maxrank=5, kick=3, crossrank=12, cross_maxiter=1)),  # one cross iteration per sweep
 ], ids=["car7d-small", "car7d-41", "dubins3d", "lqg2d", "car7d-small-crossrank10", "car7d-41-crossrank20", "car7d-small-crossrank40",
         "car7d-41-crossrank26", "car7d-41-crossrank48",
-        "dubins3d-101-crossrank24", "car7d-small-one-cross-iteration"])
+        "dubins3d-101-rank8", "dubins3d-101-crossrank24", "car7d-small-one-cross-iteration"])
 def test_device_resident_cross_iterations_match_the_host_driver(name, kw, aargs):
     """c3control_step_vi with whole cross iterations on the device (c3sc_hip_cross_*: fiber index lists, Bellman launches, node
     memo, pivoted factorisation + maxvol of every core step on one stream) against the same sweeps driven from the host

@@ -225,7 +225,9 @@ static inline void reflect(const double *v, double *c, size_t k, size_t m)
  * orthonormal).  Panels of QR_PANEL columns: the reflectors of a panel are formed one after the other (each applied to the
  * rest of the panel at once), then all of them to every trailing column -- a column sees the reflectors in the order 0, 1, 2, ...
  * as in the unblocked loop, so the bits are those of the unblocked loop, and the trailing columns are independent (threads). */
+#ifndef QR_PANEL
 #define QR_PANEL 8
+#endif
 struct qr_job { size_t m, k0, k1; double *A; const double *V; const unsigned char *has; };
 C3SC_CLONES static void qr_trailing_column(void *arg, size_t j)
 { /* the panel's reflectors k0 .. k1 - 1, in this order, on the trailing column j */

@@ -140,7 +140,7 @@ __device__ __forceinline__ void apply_glb(const double *__restrict__ G, double (
     // 16-18 doubles of the matrix in registers at a time.  Left alone the compiler hoists every load of the fold (three matrices
     // of a level, read through a const __restrict__ pointer: nothing orders them) above the first FMA and spills 200-500
     // registers.  An empty asm cannot fence them either -- it does not receive the noalias pointer, so loads through it may
-    // cross it.  Instead the chunk's base pointer is laundered through a volatile asm (its loads depend on the asm's output)
+    // cross it.  Instead the chunk's offset is laundered through a volatile asm (its loads depend on the asm's output)
     // and the accumulators are pinned by volatile asms after the chunk's FMAs: volatile asms keep their order, so chunk c+1 is
     // loaded after chunk c has been consumed.  The fold is short; other wavefronts cover its L2 round trips.
     constexpr int CH = (RP <= 4) ? RP : (RP <= 6 ? 3 : 2);
@@ -151,8 +151,9 @@ __device__ __forceinline__ void apply_glb(const double *__restrict__ G, double (
         for (int i = 0; i < RP; i++) t[s][i] = 0.0;
 #pragma unroll
     for (int b0 = 0; b0 < RP; b0 += CH) {
-        const double *Gc = G + b0 * RP;
-        asm volatile("" : "+v"(Gc));
+        int off = b0 * RP; // (the OFFSET is laundered, not the pointer: a laundered pointer loses its address space and every load
+        asm volatile("" : "+v"(off)); // through it becomes a FLAT load -- 90 of them in the dubins3d kernel until round 4)
+        const double *Gc = G + off;
         double g[CH][RP];
 #pragma unroll
         for (int b = 0; b < CH; b++)
